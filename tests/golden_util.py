@@ -1,0 +1,84 @@
+"""Helpers shared by the tests that read tests/golden/*.npz (made by tests/golden/make_golden.py
+from the reference itself)."""
+import glob
+import os
+
+import numpy as np
+
+from oracle import usp_oracle as O
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+# Stated parity tolerances: max-abs envelopes of 16-bit USP attention vs an
+# fp32/fp64 truth on N(0,1) inputs, with 2x head-room.  The reference's own bar is atol=1e-1 on the
+# forward only (test/test_hybrid_attn.py:386).
+TOL = {
+    "bfloat16": dict(out=(2e-2, 2e-2), grad=(5e-2, 5e-2)),
+    "float16": dict(out=(4e-3, 4e-3), grad=(1e-2, 1e-2)),
+    "float32": dict(out=(2e-5, 2e-5), grad=(1e-4, 1e-4)),
+}
+
+
+def golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+def make_inputs(B, S, Hq, Hkv, D, seed=0):
+    """Must stay identical to tests/golden/make_golden.py:make_inputs."""
+    rs = np.random.RandomState(seed)
+    q = rs.standard_normal((B, S, Hq, D)).astype(np.float32)
+    k = rs.standard_normal((B, S, Hkv, D)).astype(np.float32)
+    v = rs.standard_normal((B, S, Hkv, D)).astype(np.float32)
+    dout = rs.standard_normal((B, S, Hq, D)).astype(np.float32)
+    return q, k, v, dout
+
+
+def round_to(x, dtype_s):
+    """Round float32 values to the 16-bit dtype the fixture ran in (inputs were cast with
+    torch .to(dtype) == round-to-nearest-even)."""
+    if dtype_s == "bfloat16":
+        return O.bf16_bits_to_f32(O.f32_to_bf16_bits(x))
+    if dtype_s == "float16":
+        return x.astype(np.float16).astype(np.float32)
+    return x.astype(np.float32)
+
+
+def decode(arr, dtype_s):
+    if dtype_s == "bfloat16":
+        return O.bf16_bits_to_f32(arr)
+    if dtype_s == "float16":
+        return arr.view(np.float16).astype(np.float32)
+    return arr.astype(np.float32)
+
+
+class Golden:
+    def __init__(self, path):
+        z = np.load(path)
+        self.name = os.path.basename(path)[:-4]
+        for key in ("ws", "ud", "rd", "B", "S", "Hq", "Hkv", "D", "seed"):
+            setattr(self, key, int(z[key]))
+        self.impl = str(z["impl"])
+        self.dtype = str(z["dtype"])
+        self.bwd = bool(z["bwd"])
+        self.causal = bool(z["causal"])
+        q, k, v, dout = make_inputs(self.B, self.S, self.Hq, self.Hkv, self.D, self.seed)
+        self.q, self.k, self.v, self.dout = (round_to(t, self.dtype) for t in (q, k, v, dout))
+        self.out = [decode(z[f"out_r{r}"], self.dtype) for r in range(self.ws)]
+        if self.bwd:
+            self.dq = [decode(z[f"dq_r{r}"], self.dtype) for r in range(self.ws)]
+            self.dk = [decode(z[f"dk_r{r}"], self.dtype) for r in range(self.ws)]
+            self.dv = [decode(z[f"dv_r{r}"], self.dtype) for r in range(self.ws)]
+
+    def shard(self, x, rank):
+        return O.EXTRACT[self.impl](x, rank, self.ws, self.rd, self.ud)
+
+
+def assert_close(got, want, atol, rtol, what=""):
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    err = np.abs(got - want)
+    lim = atol + rtol * np.abs(want)
+    bad = err > lim
+    assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} elements out of tolerance "
+                           f"(atol={atol}, rtol={rtol}); max abs err {err.max():.3e} "
+                           f"at {np.unravel_index(err.argmax(), err.shape)}")
