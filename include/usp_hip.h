@@ -1,0 +1,159 @@
+/*
+ * usp_hip.h -- C ABI of libusp_hip.so, the MI355X (gfx950) device library behind the
+ * Unified-Sequence-Parallel attention path.
+ *
+ * The reference (feifeibear/long-context-attention, "yunchang" v0.6.4) is pure Python and has no
+ * FFI of its own: its device arithmetic lives in third-party ops reached through the selector
+ * seam `select_flash_attn_impl` (yunchang/kernels/__init__.py:63-65).  Each entry point below
+ * replaces one of those call sites (cited per function); the Python binding a maintainer adds is
+ * a ctypes stub, shown in INTEGRATION.md and implemented in long-context-attention_amd/_C.py.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated;
+ *   - tensors are (batch, seq, head, dim) with dim contiguous; strides are in ELEMENTS;
+ *   - nothing allocates, nothing synchronises, nothing touches any stream but `stream`
+ *     (a hipStream_t passed as void*; NULL = the legacy default stream);
+ *   - thread-safe and re-entrant: no mutable globals;
+ *   - return 0 on success, a negative USP_E* code otherwise (the launch is then not issued);
+ *     usp_strerror() maps codes to text.
+ */
+#ifndef USP_HIP_H
+#define USP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define USP_ABI_VERSION 1
+
+enum { USP_BF16 = 0, USP_FP16 = 1 };
+
+enum {
+  USP_OK = 0,
+  USP_EINVAL = -1,      /* bad argument (null pointer, non-positive size, bad dtype) */
+  USP_EUNSUPPORTED = -2,/* head_dim not in {32, 64, 128}, Hq % Hkv != 0, misaligned pointer/stride */
+  USP_ELAUNCH = -3      /* hipLaunchKernel reported an error */
+};
+
+/* A (batch, seq, head, dim) view: element pointer + element strides; dim stride is 1. */
+typedef struct usp_tensor {
+  void* ptr;
+  int64_t stride_b, stride_s, stride_h;
+} usp_tensor;
+
+/* ----------------------------------------------------------------------------------------------
+ * Blockwise flash-attention forward, with the ring LSE-merge fused into the epilogue.
+ *
+ * Replaces the `fwd-only` callable: pytorch_attn_forward(op_type="efficient")
+ * (yunchang/kernels/attention.py:44-136, aten op at :76-86) / flash_attn_forward (:165-202), as
+ * called by the ring schedules (yunchang/ring/zigzag_ring_flash_attn.py:29-43,
+ * yunchang/ring/ring_flash_attn.py:36-48), AND the update_out_and_lse that follows each call
+ * (yunchang/ring/utils.py:10-51; slice form used at zigzag_ring_flash_attn.py:61-67).
+ *
+ * Computes, for q (B,Sq,Hq,D), k/v (B,Sk,Hkv,D) [GQA: q head i uses kv head i / (Hq/Hkv)]:
+ *     S = q k^T * softmax_scale ; causal: key j visible to query i iff j <= i + (Sk - Sq)
+ *     blk_lse = logsumexp_j S ;  blk_out = softmax(S) v          (fp32 accumulate)
+ * then, per query row i of this call:
+ *     merge_in != 0 : (o, lse) = merge((acc[i], lse[i]), (blk_out, blk_lse))   [utils.py:25-26]
+ *     merge_in == 0 : (o, lse) = (blk_out, blk_lse)
+ *     lse[i] <- lse                                   (fp32, natural log; -inf for an empty row)
+ *     i in [final_begin, final_end) : out[i] <- o rounded to `dtype`   (needs out.ptr != NULL)
+ *     otherwise                      : acc[i] <- o  (fp32)             (needs acc.ptr != NULL)
+ * `lse` is (B,Hq,Sq) with seq stride 1.  A single non-ring call uses merge_in=0,
+ * final_begin=0, final_end=Sq, acc.ptr=NULL.
+ * -------------------------------------------------------------------------------------------- */
+typedef struct usp_fwd_args {
+  int32_t dtype;                 /* USP_BF16 | USP_FP16: element type of q,k,v,out */
+  int32_t B, Sq, Sk, Hq, Hkv, D;
+  int32_t causal;                /* 0 | 1 (bottom-right aligned) */
+  float softmax_scale;           /* > 0 */
+  usp_tensor q, k, v;            /* inputs */
+  usp_tensor out;                /* 16-bit output rows (final rows only); ptr may be NULL */
+  usp_tensor acc;                /* fp32 running output; ptr may be NULL */
+  float* lse;                    /* fp32 running / final logsumexp */
+  int64_t lse_stride_b, lse_stride_h;
+  int32_t merge_in;              /* 0 | 1 */
+  int32_t final_begin, final_end;/* row range of this call whose result is final */
+} usp_fwd_args;
+
+int usp_flash_fwd(const usp_fwd_args* args, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Blockwise flash-attention backward.
+ *
+ * Replaces the `bwd-only` callable flash_attn_backward (yunchang/kernels/attention.py:205-250;
+ * the TORCH_* variant pytorch_attn_backward :138-159 raises), as called at
+ * zigzag_ring_flash_attn.py:115-137 / ring_flash_attn.py:102-122, AND the fp32 accumulation the
+ * ring schedule performs on its results (zigzag_ring_flash_attn.py:147-170).
+ *
+ * Inputs: dout,q (B,Sq,Hq,D); k,v (B,Sk,Hkv,D); lse (B,Hq,Sq) = the GLOBAL logsumexp of the rows
+ * (not this block's); delta (B,Hq,Sq) = rowsum(dout * out_global) from usp_bwd_delta().
+ *     P = exp(S - lse) ; dV = P^T dO ; dP = dO V^T ; dS = P * (dP - delta) * scale
+ *     dQ = dS K ; dK = dS^T Q                  (GQA: dK,dV summed over the Hq/Hkv query heads)
+ * Outputs are fp32 (B,S,H,D) tensors: dq (+)= dQ, dk (+)= dK, dv (+)= dV, where "+=" is used when
+ * the matching accum_* flag is non-zero and "=" otherwise.  Deterministic (no atomics).
+ * -------------------------------------------------------------------------------------------- */
+typedef struct usp_bwd_args {
+  int32_t dtype;
+  int32_t B, Sq, Sk, Hq, Hkv, D;
+  int32_t causal;
+  float softmax_scale;
+  usp_tensor dout, q, k, v;      /* 16-bit inputs */
+  const float* lse;              /* (B,Hq,Sq), seq stride 1 */
+  const float* delta;            /* (B,Hq,Sq), seq stride 1 */
+  int64_t lse_stride_b, lse_stride_h;
+  int64_t delta_stride_b, delta_stride_h;
+  usp_tensor dq, dk, dv;         /* fp32 outputs */
+  int32_t accum_dq, accum_dk, accum_dv;
+} usp_bwd_args;
+
+int usp_flash_bwd(const usp_bwd_args* args, void* stream);
+
+/* delta[b,h,s] = sum_d dout[b,s,h,d] * out[b,s,h,d]   (fp32; delta is (B,H,S), seq stride 1).
+ * The "softmax_d" term flash-attn's backward derives from `out` (its 5th positional argument,
+ * kernels/attention.py:205). */
+int usp_bwd_delta(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t D,
+                  const usp_tensor* dout, const usp_tensor* out,
+                  float* delta, int64_t delta_stride_b, int64_t delta_stride_h, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Stand-alone LSE merge: update_out_and_lse (yunchang/ring/utils.py:10-51) as one kernel.
+ *   acc (B,S,H,D) fp32, lse (B,H,S) fp32 are updated in place with a block result
+ *   blk_out (B,S,H,D) 16-bit, blk_lse (B,H,S) fp32.  first != 0: adopt the block (utils.py:38-42).
+ * -------------------------------------------------------------------------------------------- */
+int usp_lse_merge(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t D,
+                  const usp_tensor* acc, float* lse, int64_t lse_stride_b, int64_t lse_stride_h,
+                  const usp_tensor* blk_out, const float* blk_lse, int64_t blk_lse_stride_b,
+                  int64_t blk_lse_stride_h, int32_t first, void* stream);
+
+/* ----------------------------------------------------------------------------------------------
+ * Row-gather copy used to build / unpack the Ulysses all-to-all buffers
+ * (the two `.contiguous()` transposes of yunchang/comm/all_to_all.py:39-49,62-65,76-84,98-100).
+ *   for i0<n0, i1<n1, i2<n2, i3<n3:
+ *     dst[i0*ds0 + i1*ds1 + i2*ds2 + i3*ds3 + (0..row_bytes)] = src[i0*ss0 + ... ]
+ * Strides in BYTES; row_bytes, all strides and both pointers must be multiples of 16.
+ * -------------------------------------------------------------------------------------------- */
+int usp_copy_rows(void* dst, const void* src, int64_t row_bytes,
+                  int64_t n0, int64_t n1, int64_t n2, int64_t n3,
+                  int64_t ds0, int64_t ds1, int64_t ds2, int64_t ds3,
+                  int64_t ss0, int64_t ss1, int64_t ss2, int64_t ss3, void* stream);
+
+/* dst16[i] = round(src32[i]) for i < n, `rows` rows of `n` contiguous elements with row strides
+ * (elements) -- the `.to(q.dtype)` casts at zigzag_ring_flash_attn.py:74,183. */
+int usp_cast_from_f32(int32_t dtype, void* dst, int64_t dst_row_stride, const float* src,
+                      int64_t src_row_stride, int64_t rows, int64_t n, void* stream);
+
+/* dst[r, i] = a[r, i] + b[r, i]  (fp32; any of the three may alias) -- the dk/dv accumulator adds
+ * at zigzag_ring_flash_attn.py:161-170 / ring_flash_attn.py:130-131. */
+int usp_add_f32(float* dst, int64_t dst_row_stride, const float* a, int64_t a_row_stride,
+                const float* b, int64_t b_row_stride, int64_t rows, int64_t n, void* stream);
+
+int usp_abi_version(void);
+const char* usp_strerror(int code);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USP_HIP_H */

@@ -1,0 +1,402 @@
+// kbench -- native test/bench harness for libusp_hip.so (no python, no torch: starts in ms on a
+// fresh GPU box).  TEST TOOL: links the CPU oracle (oracle/attn_oracle.c) as the checker.
+//
+//   kbench probe                         hardware-layout probes (MFMA operand/result maps, tr-read)
+//   kbench fwd  B Sq Sk Hq Hkv D causal dtype check iters    forward: check vs oracle and/or time
+//   kbench fwdmerge B Sq Sk Hq Hkv D dtype                    fused-merge path vs oracle (2 KV halves)
+//   kbench bwd  B Sq Sk Hq Hkv D causal dtype check iters    backward
+//   kbench suite                          the standard correctness list + C2-shape timings
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "usp_hip.h"
+
+extern "C" {
+void usp_oracle_attn_fwd(const float* q, const float* k, const float* v, int B, int Sq, int Sk, int Hq,
+                         int Hkv, int D, float scale, int causal, float* out, float* lse);
+void usp_oracle_attn_bwd(const float* dout, const float* q, const float* k, const float* v,
+                         const float* out, const float* lse, int B, int Sq, int Sk, int Hq, int Hkv,
+                         int D, float scale, int causal, float* dq, float* dk, float* dv);
+}
+
+#define HIP_OK(x)                                                                       \
+  do {                                                                                  \
+    hipError_t e_ = (x);                                                                \
+    if (e_ != hipSuccess) {                                                             \
+      fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(2);                                                                          \
+    }                                                                                   \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// host-side 16-bit helpers
+// ---------------------------------------------------------------------------------------------
+static uint16_t f2bf(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  if ((u & 0x7fffffff) > 0x7f800000) return 0x7fc0;
+  u += 0x7fff + ((u >> 16) & 1);
+  return (uint16_t)(u >> 16);
+}
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+static uint16_t enc(float f, int dt) { return dt == 0 ? f2bf(f) : f2h(f); }
+static float dec(uint16_t u, int dt) { return dt == 0 ? bf2f(u) : h2f(u); }
+
+struct Rng {
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 1) {}
+  uint32_t next() { s = s * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(s >> 33); }
+  float uni() { return (next() + 0.5f) / 2147483648.0f; }
+  float normal() { float u1 = uni(), u2 = uni(); return sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2); }
+};
+
+// random N(0,1) tensor rounded to the 16-bit dtype: `bits` for the device, `vals` for the oracle
+static void fill(std::vector<uint16_t>& bits, std::vector<float>& vals, size_t n, int dt, uint64_t seed,
+                 float scale = 1.f) {
+  bits.resize(n); vals.resize(n);
+  Rng r(seed);
+  for (size_t i = 0; i < n; ++i) { bits[i] = enc(r.normal() * scale, dt); vals[i] = dec(bits[i], dt); }
+}
+
+template <typename T> static T* dev_upload(const std::vector<T>& h) {
+  T* d; HIP_OK(hipMalloc(&d, h.size() * sizeof(T)));
+  HIP_OK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  return d;
+}
+template <typename T> static T* dev_alloc(size_t n, int fillbyte = 0xff) {
+  T* d; HIP_OK(hipMalloc(&d, n * sizeof(T)));
+  HIP_OK(hipMemset(d, fillbyte, n * sizeof(T)));
+  return d;
+}
+template <typename T> static std::vector<T> dev_download(const T* d, size_t n) {
+  std::vector<T> h(n);
+  HIP_OK(hipMemcpy(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost));
+  return h;
+}
+
+static usp_tensor bshd(void* p, int S, int H, int D) {
+  usp_tensor t; t.ptr = p; t.stride_b = (int64_t)S * H * D; t.stride_s = (int64_t)H * D; t.stride_h = D;
+  return t;
+}
+
+struct Err { double max_abs = 0, max_rel_viol = 0; size_t bad = 0, n = 0, nan = 0; };
+static Err compare(const float* got, const float* want, size_t n, double atol, double rtol) {
+  Err e; e.n = n;
+  for (size_t i = 0; i < n; ++i) {
+    if (isinf(want[i]) && isinf(got[i]) && (want[i] < 0) == (got[i] < 0)) continue;
+    if (got[i] != got[i]) { e.nan++; e.bad++; continue; }
+    double d = fabs((double)got[i] - want[i]);
+    if (d > e.max_abs) e.max_abs = d;
+    if (d > atol + rtol * fabs(want[i])) e.bad++;
+  }
+  return e;
+}
+
+static double attn_flops(int B, int Sq, int Sk, int Hq, int D, int causal) {
+  double pairs = 0;
+  if (!causal) pairs = (double)Sq * Sk;
+  else for (int i = 0; i < Sq; ++i) { long v = (long)i + (Sk - Sq) + 1; if (v > Sk) v = Sk; if (v > 0) pairs += v; }
+  return 4.0 * B * Hq * pairs * D;
+}
+
+// ---------------------------------------------------------------------------------------------
+// probes
+// ---------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+__global__ void probe_mfma(const uint16_t* A /*[32][16]*/, const uint16_t* Bm /*[16][32]*/, float* Dm /*[32][32]*/) {
+  const int l = threadIdx.x, l31 = l & 31, hi = l >> 5;
+  union { bf16x8 v; uint16_t u[8]; } a, b;
+  for (int e = 0; e < 8; ++e) { a.u[e] = A[l31 * 16 + 8 * hi + e]; b.u[e] = Bm[(8 * hi + e) * 32 + l31]; }
+  f32x16 c;
+  for (int r = 0; r < 16; ++r) c[r] = 0.f;
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+  for (int r = 0; r < 16; ++r) Dm[((r & 3) + 8 * (r >> 2) + 4 * hi) * 32 + l31] = c[r];
+}
+
+__global__ void probe_tr(uint16_t* out /*[64][4]*/) {
+  __shared__ __attribute__((aligned(16))) uint16_t lds[4 * 64];   // 4 groups x [4][16]
+  const int l = threadIdx.x;
+  for (int i = l; i < 256; i += 64) lds[i] = (uint16_t)i;
+  __syncthreads();
+  const int grp = l >> 4, i = l & 15;
+  // lane i of a group supplies chunk i of its [4][16] block: row i>>2, cols 4*(i&3)..
+  const uint16_t* p = lds + grp * 64 + (i >> 2) * 16 + (i & 3) * 4;
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  for (int j = 0; j < 4; ++j) out[l * 4 + j] = (uint16_t)v[j];
+}
+
+__global__ void probe_swap(uint32_t* out /*[64][2]*/) {
+  const uint32_t u = threadIdx.x;
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  out[threadIdx.x * 2] = r[0];
+  out[threadIdx.x * 2 + 1] = r[1];
+}
+
+static int run_probe() {
+  int fails = 0;
+  {  // MFMA layout, asymmetric small-integer operands (exact in bf16)
+    std::vector<uint16_t> A(32 * 16), Bm(16 * 32);
+    std::vector<float> Af(32 * 16), Bf(16 * 32);
+    for (int i = 0; i < 32; ++i) for (int k = 0; k < 16; ++k) { float x = (float)((i * 3 + k * 5) % 7 - 3); A[i * 16 + k] = f2bf(x); Af[i * 16 + k] = x; }
+    for (int k = 0; k < 16; ++k) for (int j = 0; j < 32; ++j) { float x = (float)((k * 11 + j * 13) % 5 - 2); Bm[k * 32 + j] = f2bf(x); Bf[k * 32 + j] = x; }
+    uint16_t* dA = dev_upload(A); uint16_t* dB = dev_upload(Bm); float* dD = dev_alloc<float>(32 * 32);
+    hipLaunchKernelGGL(probe_mfma, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    HIP_OK(hipDeviceSynchronize());
+    auto Dh = dev_download(dD, 32 * 32);
+    int bad = 0;
+    for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) {
+      float ref = 0; for (int k = 0; k < 16; ++k) ref += Af[i * 16 + k] * Bf[k * 32 + j];
+      if (Dh[i * 32 + j] != ref) { if (bad < 5) printf("  mfma mismatch D[%d][%d] = %g want %g\n", i, j, Dh[i * 32 + j], ref); bad++; }
+    }
+    printf("PROBE mfma_32x32x16_bf16 layout: %s (%d mismatches)\n", bad ? "FAIL" : "ok", bad);
+    fails += bad != 0;
+  }
+  {  // ds_read_b64_tr_b16: lane i of a 16-group gets column i of the group's [4][16] block
+    uint16_t* d = dev_alloc<uint16_t>(256);
+    hipLaunchKernelGGL(probe_tr, dim3(1), dim3(64), 0, 0, d);
+    HIP_OK(hipDeviceSynchronize());
+    auto h = dev_download(d, 256);
+    int bad = 0;
+    for (int l = 0; l < 64; ++l) for (int j = 0; j < 4; ++j) {
+      int want = (l >> 4) * 64 + j * 16 + (l & 15);
+      if (h[l * 4 + j] != want) bad++;
+    }
+    printf("PROBE ds_read_b64_tr_b16 semantics: %s (%d mismatches)\n", bad ? "FAIL" : "ok", bad);
+    if (bad) for (int l = 0; l < 64; ++l) printf("  lane %2d: %3d %3d %3d %3d\n", l, h[l * 4], h[l * 4 + 1], h[l * 4 + 2], h[l * 4 + 3]);
+    fails += bad != 0;
+  }
+  {
+    uint32_t* d = dev_alloc<uint32_t>(128);
+    hipLaunchKernelGGL(probe_swap, dim3(1), dim3(64), 0, 0, d);
+    HIP_OK(hipDeviceSynchronize());
+    auto h = dev_download(d, 128);
+    int bad = 0;
+    for (int l = 0; l < 64; ++l) { if (h[2 * l] != (uint32_t)(l & 31)) bad++; if (h[2 * l + 1] != (uint32_t)((l & 31) + 32)) bad++; }
+    printf("PROBE permlane32_swap(u,u) -> {[lo|lo],[hi|hi]}: %s\n", bad ? "FAIL" : "ok");
+    if (bad) for (int l = 0; l < 64; l += 8) printf("  lane %2d: r0=%u r1=%u\n", l, h[2 * l], h[2 * l + 1]);
+    fails += bad != 0;
+  }
+  hipDeviceProp_t prop; HIP_OK(hipGetDeviceProperties(&prop, 0));
+  printf("DEVICE %s  CUs=%d  clock=%d MHz  LDS/block=%zu\n", prop.gcnArchName, prop.multiProcessorCount,
+         prop.clockRate / 1000, prop.sharedMemPerBlock);
+  return fails;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+struct Tol { double out_atol, out_rtol, lse_atol; };
+static Tol tol_for(int dt) { return dt == 0 ? Tol{2e-2, 2e-2, 2e-3} : Tol{4e-3, 4e-3, 1e-3}; }
+
+static int run_fwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, int dt, int check, int iters) {
+  const size_t nq = (size_t)B * Sq * Hq * D, nk = (size_t)B * Sk * Hkv * D, nl = (size_t)B * Hq * Sq;
+  std::vector<uint16_t> qb, kb, vb; std::vector<float> qf, kf, vf;
+  fill(qb, qf, nq, dt, 1); fill(kb, kf, nk, dt, 2); fill(vb, vf, nk, dt, 3);
+  uint16_t *dq = dev_upload(qb), *dk = dev_upload(kb), *dv = dev_upload(vb);
+  uint16_t* dout = dev_alloc<uint16_t>(nq);
+  float* dlse = dev_alloc<float>(nl);
+  usp_fwd_args a; memset(&a, 0, sizeof(a));
+  a.dtype = dt; a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.causal = causal;
+  a.softmax_scale = 1.f / sqrtf((float)D);
+  a.q = bshd(dq, Sq, Hq, D); a.k = bshd(dk, Sk, Hkv, D); a.v = bshd(dv, Sk, Hkv, D);
+  a.out = bshd(dout, Sq, Hq, D);
+  a.lse = dlse; a.lse_stride_b = (int64_t)Hq * Sq; a.lse_stride_h = Sq;
+  a.merge_in = 0; a.final_begin = 0; a.final_end = Sq;
+  int rc = usp_flash_fwd(&a, nullptr);
+  if (rc) { printf("FWD launch failed: %s\n", usp_strerror(rc)); return 1; }
+  HIP_OK(hipDeviceSynchronize());
+  int fail = 0;
+  char tag[160];
+  snprintf(tag, sizeof tag, "fwd B%d Sq%d Sk%d Hq%d Hkv%d D%d %s %s", B, Sq, Sk, Hq, Hkv, D,
+           causal ? "causal" : "full", dt ? "fp16" : "bf16");
+  if (check) {
+    std::vector<float> ro(nq), rl(nl);
+    usp_oracle_attn_fwd(qf.data(), kf.data(), vf.data(), B, Sq, Sk, Hq, Hkv, D, a.softmax_scale, causal, ro.data(), rl.data());
+    auto ob = dev_download(dout, nq); auto lh = dev_download(dlse, nl);
+    std::vector<float> of(nq); for (size_t i = 0; i < nq; ++i) of[i] = dec(ob[i], dt);
+    Tol t = tol_for(dt);
+    Err eo = compare(of.data(), ro.data(), nq, t.out_atol, t.out_rtol);
+    Err el = compare(lh.data(), rl.data(), nl, t.lse_atol, 1e-4);
+    fail = (eo.bad || el.bad);
+    printf("CHECK %-58s out max|err| %.3e bad %zu nan %zu | lse max|err| %.3e bad %zu  %s\n", tag, eo.max_abs,
+           eo.bad, eo.nan, el.max_abs, el.bad, fail ? "FAIL" : "ok");
+  }
+  if (iters > 0) {
+    hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) usp_flash_fwd(&a, nullptr);
+    HIP_OK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) usp_flash_fwd(&a, nullptr);
+    HIP_OK(hipEventRecord(e1, 0)); HIP_OK(hipEventSynchronize(e1));
+    float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    double fl = attn_flops(B, Sq, Sk, Hq, D, causal);
+    printf("TIME  %-58s %.4f ms  %.1f TFLOP/s  (%.1f%% of 2500)\n", tag, ms, fl / ms * 1e-9, fl / ms * 1e-9 / 25.0);
+  }
+  hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); hipFree(dlse);
+  return fail;
+}
+
+// fused merge: KV split in two halves, two calls (acc write, then merge_in + final) == one full call.
+// Also exercises the row-range logic: rows [0, Sq/2) are declared final already in call 1 when
+// `partial_final` is set (they then must NOT be touched by call 2, which only covers rows Sq/2..).
+static int run_fwdmerge(int B, int Sq, int Sk, int Hq, int Hkv, int D, int dt) {
+  const size_t nq = (size_t)B * Sq * Hq * D, nk = (size_t)B * Sk * Hkv * D, nl = (size_t)B * Hq * Sq;
+  std::vector<uint16_t> qb, kb, vb; std::vector<float> qf, kf, vf;
+  fill(qb, qf, nq, dt, 11); fill(kb, kf, nk, dt, 12); fill(vb, vf, nk, dt, 13);
+  uint16_t *dq = dev_upload(qb), *dk = dev_upload(kb), *dv = dev_upload(vb);
+  uint16_t* dout = dev_alloc<uint16_t>(nq);
+  float* dacc = dev_alloc<float>(nq);
+  float* dlse = dev_alloc<float>(nl);
+  const int h1 = (Sk / 2 + 7) / 8 * 8 > 0 ? (Sk / 2) : 1;
+  usp_fwd_args a; memset(&a, 0, sizeof(a));
+  a.dtype = dt; a.B = B; a.Sq = Sq; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.causal = 0;
+  a.softmax_scale = 1.f / sqrtf((float)D);
+  a.q = bshd(dq, Sq, Hq, D); a.out = bshd(dout, Sq, Hq, D); a.acc = bshd(dacc, Sq, Hq, D);
+  a.lse = dlse; a.lse_stride_b = (int64_t)Hq * Sq; a.lse_stride_h = Sq;
+  // call 1: keys [0,h1), write acc
+  a.Sk = h1; a.k = bshd(dk, Sk, Hkv, D); a.v = bshd(dv, Sk, Hkv, D);
+  a.merge_in = 0; a.final_begin = 0; a.final_end = 0;
+  int rc = usp_flash_fwd(&a, nullptr);
+  // call 2: keys [h1,Sk), merge + final
+  a.Sk = Sk - h1;
+  a.k.ptr = dk + (size_t)h1 * Hkv * D; a.v.ptr = dv + (size_t)h1 * Hkv * D;
+  a.merge_in = 1; a.final_begin = 0; a.final_end = Sq;
+  rc |= usp_flash_fwd(&a, nullptr);
+  if (rc) { printf("FWDMERGE launch failed: %s\n", usp_strerror(rc)); return 1; }
+  HIP_OK(hipDeviceSynchronize());
+  std::vector<float> ro(nq), rl(nl);
+  usp_oracle_attn_fwd(qf.data(), kf.data(), vf.data(), B, Sq, Sk, Hq, Hkv, D, a.softmax_scale, 0, ro.data(), rl.data());
+  auto ob = dev_download(dout, nq); auto lh = dev_download(dlse, nl);
+  std::vector<float> of(nq); for (size_t i = 0; i < nq; ++i) of[i] = dec(ob[i], dt);
+  Tol t = tol_for(dt);
+  Err eo = compare(of.data(), ro.data(), nq, t.out_atol, t.out_rtol);
+  Err el = compare(lh.data(), rl.data(), nl, t.lse_atol, 1e-4);
+  int fail = (eo.bad || el.bad);
+  printf("CHECK fwdmerge B%d Sq%d Sk%d(%d+%d) Hq%d Hkv%d D%d %s : out max|err| %.3e bad %zu | lse max|err| %.3e bad %zu  %s\n",
+         B, Sq, Sk, h1, Sk - h1, Hq, Hkv, D, dt ? "fp16" : "bf16", eo.max_abs, eo.bad, el.max_abs, el.bad, fail ? "FAIL" : "ok");
+  hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); hipFree(dacc); hipFree(dlse);
+  return fail;
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------
+static int run_bwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, int dt, int check, int iters) {
+  const size_t nq = (size_t)B * Sq * Hq * D, nk = (size_t)B * Sk * Hkv * D, nl = (size_t)B * Hq * Sq;
+  std::vector<uint16_t> qb, kb, vb, dob; std::vector<float> qf, kf, vf, dof;
+  fill(qb, qf, nq, dt, 21); fill(kb, kf, nk, dt, 22); fill(vb, vf, nk, dt, 23); fill(dob, dof, nq, dt, 24);
+  uint16_t *dq_ = dev_upload(qb), *dk_ = dev_upload(kb), *dv_ = dev_upload(vb), *ddo = dev_upload(dob);
+  uint16_t* dout = dev_alloc<uint16_t>(nq);
+  float* dlse = dev_alloc<float>(nl);
+  float* ddelta = dev_alloc<float>(nl);
+  float *gdq = dev_alloc<float>(nq), *gdk = dev_alloc<float>(nk), *gdv = dev_alloc<float>(nk);
+  const float scale = 1.f / sqrtf((float)D);
+  usp_fwd_args f; memset(&f, 0, sizeof(f));
+  f.dtype = dt; f.B = B; f.Sq = Sq; f.Sk = Sk; f.Hq = Hq; f.Hkv = Hkv; f.D = D; f.causal = causal;
+  f.softmax_scale = scale;
+  f.q = bshd(dq_, Sq, Hq, D); f.k = bshd(dk_, Sk, Hkv, D); f.v = bshd(dv_, Sk, Hkv, D); f.out = bshd(dout, Sq, Hq, D);
+  f.lse = dlse; f.lse_stride_b = (int64_t)Hq * Sq; f.lse_stride_h = Sq; f.final_end = Sq;
+  int rc = usp_flash_fwd(&f, nullptr);
+  usp_tensor tdo = bshd(ddo, Sq, Hq, D), tout = bshd(dout, Sq, Hq, D);
+  rc |= usp_bwd_delta(dt, B, Sq, Hq, D, &tdo, &tout, ddelta, (int64_t)Hq * Sq, Sq, nullptr);
+  usp_bwd_args a; memset(&a, 0, sizeof(a));
+  a.dtype = dt; a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.causal = causal;
+  a.softmax_scale = scale;
+  a.dout = tdo; a.q = f.q; a.k = f.k; a.v = f.v;
+  a.lse = dlse; a.delta = ddelta;
+  a.lse_stride_b = a.delta_stride_b = (int64_t)Hq * Sq; a.lse_stride_h = a.delta_stride_h = Sq;
+  a.dq = bshd(gdq, Sq, Hq, D); a.dk = bshd(gdk, Sk, Hkv, D); a.dv = bshd(gdv, Sk, Hkv, D);
+  rc |= usp_flash_bwd(&a, nullptr);
+  if (rc) { printf("BWD launch failed: %s\n", usp_strerror(rc)); return 1; }
+  HIP_OK(hipDeviceSynchronize());
+  char tag[160];
+  snprintf(tag, sizeof tag, "bwd B%d Sq%d Sk%d Hq%d Hkv%d D%d %s %s", B, Sq, Sk, Hq, Hkv, D,
+           causal ? "causal" : "full", dt ? "fp16" : "bf16");
+  int fail = 0;
+  if (check) {
+    std::vector<float> ro(nq), rl(nl), rdq(nq), rdk(nk), rdv(nk);
+    usp_oracle_attn_fwd(qf.data(), kf.data(), vf.data(), B, Sq, Sk, Hq, Hkv, D, scale, causal, ro.data(), rl.data());
+    usp_oracle_attn_bwd(dof.data(), qf.data(), kf.data(), vf.data(), ro.data(), rl.data(), B, Sq, Sk, Hq, Hkv, D,
+                        scale, causal, rdq.data(), rdk.data(), rdv.data());
+    auto hq = dev_download(gdq, nq); auto hk = dev_download(gdk, nk); auto hv = dev_download(gdv, nk);
+    const double at = dt == 0 ? 5e-2 : 1e-2;
+    Err e1 = compare(hq.data(), rdq.data(), nq, at, at), e2 = compare(hk.data(), rdk.data(), nk, at, at),
+        e3 = compare(hv.data(), rdv.data(), nk, at, at);
+    fail = e1.bad || e2.bad || e3.bad;
+    printf("CHECK %-58s dq %.3e (%zu bad) dk %.3e (%zu bad) dv %.3e (%zu bad)  %s\n", tag, e1.max_abs, e1.bad,
+           e2.max_abs, e2.bad, e3.max_abs, e3.bad, fail ? "FAIL" : "ok");
+  }
+  if (iters > 0) {
+    hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) usp_flash_bwd(&a, nullptr);
+    HIP_OK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) usp_flash_bwd(&a, nullptr);
+    HIP_OK(hipEventRecord(e1, 0)); HIP_OK(hipEventSynchronize(e1));
+    float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    double fl = 2.5 * attn_flops(B, Sq, Sk, Hq, D, causal);
+    printf("TIME  %-58s %.4f ms  %.1f TFLOP/s  (%.1f%% of 2500)\n", tag, ms, fl / ms * 1e-9, fl / ms * 1e-9 / 25.0);
+  }
+  hipFree(dq_); hipFree(dk_); hipFree(dv_); hipFree(ddo); hipFree(dout); hipFree(dlse); hipFree(ddelta);
+  hipFree(gdq); hipFree(gdk); hipFree(gdv);
+  return fail;
+}
+
+static int suite(bool with_bwd) {
+  int f = 0;
+  f += run_probe();
+  // correctness: tile-aligned, ragged, GQA, Sq != Sk (bottom-right causal), all head dims, both dtypes
+  struct C { int B, Sq, Sk, Hq, Hkv, D, causal, dt; };
+  const C cs[] = {
+      {1, 256, 256, 1, 1, 128, 0, 0}, {1, 256, 256, 1, 1, 128, 1, 0}, {2, 512, 512, 4, 4, 128, 1, 0},
+      {1, 1024, 1024, 8, 8, 64, 1, 0}, {1, 1024, 1024, 8, 8, 64, 1, 1}, {1, 384, 640, 4, 2, 128, 0, 0},
+      {1, 320, 320, 4, 1, 128, 1, 1}, {2, 77, 77, 2, 2, 64, 1, 0}, {1, 200, 333, 3, 1, 128, 1, 0},
+      {1, 333, 200, 2, 2, 128, 1, 0}, {1, 1, 1, 1, 1, 128, 1, 0}, {1, 65, 191, 2, 1, 32, 0, 1},
+      {1, 512, 256, 2, 2, 128, 0, 0}, {1, 256, 512, 2, 2, 128, 0, 0}, {1, 2048, 2048, 2, 1, 128, 1, 0},
+  };
+  for (const C& c : cs) f += run_fwd(c.B, c.Sq, c.Sk, c.Hq, c.Hkv, c.D, c.causal, c.dt, 1, 0);
+  f += run_fwdmerge(1, 256, 512, 2, 2, 128, 0);
+  f += run_fwdmerge(2, 300, 200, 4, 2, 64, 1);
+  f += run_fwdmerge(1, 64, 192, 2, 1, 128, 0);
+  if (with_bwd) {
+    const C bs[] = {{1, 256, 256, 1, 1, 128, 0, 0}, {1, 256, 256, 2, 2, 128, 1, 0}, {2, 512, 512, 4, 2, 128, 1, 0},
+                    {1, 384, 640, 4, 2, 64, 0, 1},  {1, 200, 333, 3, 1, 128, 1, 0}, {1, 333, 200, 2, 2, 64, 1, 0},
+                    {2, 77, 77, 2, 2, 32, 1, 0},    {1, 1024, 1024, 8, 8, 64, 1, 0}};
+    for (const C& c : bs) f += run_bwd(c.B, c.Sq, c.Sk, c.Hq, c.Hkv, c.D, c.causal, c.dt, 1, 0);
+  }
+  printf("SUITE %s (%d failing groups)\n", f ? "FAIL" : "PASS", f);
+  // timings at BASELINE shapes (C2 = B2 S8192 H16 D128 bf16 causal) and the C5 per-rank ring blocks
+  run_fwd(2, 8192, 8192, 16, 16, 128, 1, 0, 0, 20);
+  run_fwd(2, 8192, 8192, 16, 16, 128, 0, 0, 0, 10);
+  run_fwd(1, 16384, 16384, 16, 2, 128, 1, 0, 0, 5);
+  run_fwd(1, 16384, 8192, 16, 2, 128, 0, 0, 0, 5);
+  run_fwd(1, 8192, 16384, 16, 2, 128, 0, 0, 0, 5);
+  if (with_bwd) {
+    run_bwd(2, 8192, 8192, 16, 16, 128, 1, 0, 0, 5);
+    run_bwd(1, 16384, 16384, 16, 2, 128, 1, 0, 0, 3);
+  }
+  return f;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: kbench probe|fwd|fwdmerge|bwd|suite ...\n"); return 64; }
+  std::string cmd = argv[1];
+  auto I = [&](int i) { return atoi(argv[i]); };
+  if (cmd == "probe") return run_probe();
+  if (cmd == "suite") return suite(argc > 2 && std::string(argv[2]) == "bwd");
+  if (cmd == "fwd" && argc >= 12) return run_fwd(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
+  if (cmd == "bwd" && argc >= 12) return run_bwd(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
+  if (cmd == "fwdmerge" && argc >= 9) return run_fwdmerge(I(2), I(3), I(4), I(5), I(6), I(7), I(8));
+  fprintf(stderr, "bad arguments\n");
+  return 64;
+}

@@ -1,0 +1,100 @@
+// Shared device-side helpers for the gfx950 (CDNA4) kernels of libusp_hip.so.
+// Wave = 64 lanes everywhere; MFMA shape used throughout is v_mfma_f32_32x32x16_{bf16,f16}:
+//   A operand: lane l holds A[i = l&31][k = 8*(l>>5) + 0..7]      (8 x 16-bit = 4 VGPRs)
+//   B operand: lane l holds B[k = 8*(l>>5) + 0..7][j = l&31]
+//   C/D      : lane l, reg r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31]
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace usp {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+
+#define USP_LDS __attribute__((address_space(3)))
+#define USP_DEV __device__ __forceinline__
+
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+#define USP_NEG_INF (-__builtin_inff())
+
+// Element traits: DT = 0 bf16, 1 fp16.
+template <int DT> struct Elem;
+template <> struct Elem<0> {
+  static USP_DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+  }
+  static USP_DEV uint32_t pack2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  }
+  static USP_DEV float lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+  static USP_DEV float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+};
+template <> struct Elem<1> {
+  static USP_DEV f32x16 mfma(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  }
+  static USP_DEV uint32_t pack2(float lo, float hi) {
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+  }
+  static USP_DEV float lo(uint32_t w) {
+    return (float)__builtin_bit_cast(f16x2, w)[0];
+  }
+  static USP_DEV float hi(uint32_t w) {
+    return (float)__builtin_bit_cast(f16x2, w)[1];
+  }
+};
+
+// Exchange a value with the other half-wave (lane l <-> lane l^32).
+// v_permlane32_swap(vdst, src): lanes 32-63 of vdst swap with lanes 0-31 of src, so with both
+// operands holding x the results are r[0] = {x.lo | x.lo}, r[1] = {x.hi | x.hi}.
+// hipcc (ROCm 7.2) mis-folds the builtin's two results when they are consumed as floats
+// (`r[0] + r[1]` was emitted as v_add_f32 r0, r0 -- reproduced in a 6-line kernel, also with an
+// opaque copy), so the copy + swap are done in one asm statement.  The s_nop 1 covers the
+// "VALU write -> v_permlane read" hazard (2 wait states) that hipcc does not pad inside asm.
+USP_DEV void xhalf_pair(float x, float& lo, float& hi) {
+  uint32_t a = __builtin_bit_cast(uint32_t, x), b;
+  asm volatile("v_mov_b32 %1, %0\n\ts_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "=&v"(b));
+  lo = __builtin_bit_cast(float, a);
+  hi = __builtin_bit_cast(float, b);
+}
+USP_DEV float xhalf_max(float x) {
+  float lo, hi;
+  xhalf_pair(x, lo, hi);
+  return fmaxf(lo, hi);
+}
+USP_DEV float xhalf_sum(float x) {
+  float lo, hi;
+  xhalf_pair(x, lo, hi);
+  return lo + hi;
+}
+
+// LDS transpose read: 16 lanes supply the 16 8-byte chunks of a [4][16] 16-bit block (chunk m =
+// row m/4, cols 4*(m%4)..+3); lane i of the group receives column i (4 rows).
+USP_DEV u32x2 lds_read_tr16(USP_LDS const char* p) {
+  s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((USP_LDS s16x4*)p);
+  return __builtin_bit_cast(u32x2, v);
+}
+
+USP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// XCD-aware work-item order: the dispatcher places block id on XCD id % 8; give every XCD a
+// contiguous range of the logical work list so that blocks sharing K/V share an L2.
+USP_DEV int xcd_remap(int id, int n) {
+  return ((n & 7) == 0) ? (id & 7) * (n >> 3) + (id >> 3) : id;
+}
+
+}  // namespace usp

@@ -1,0 +1,274 @@
+// HBM-bound helper kernels of libusp_hip.so: backward delta, stand-alone LSE merge, the row-gather
+// copy behind the Ulysses all-to-all pack/unpack, fp32 -> 16-bit cast and fp32 add.
+// All are pure streaming kernels: 16-byte accesses per lane, grid-stride loops capped at
+// 256 CUs x 8 blocks (cdna_hip_programming.md Guideline 11/13).
+#include "usp_common.hpp"
+#include "usp_hip.h"
+
+namespace usp {
+
+constexpr int kEwThreads = 256;
+static inline int ew_grid(int64_t work_items) {
+  int64_t g = (work_items + kEwThreads - 1) / kEwThreads;
+  if (g < 1) g = 1;
+  if (g > 2048) g = 2048;
+  return (int)g;
+}
+
+template <int DT> USP_DEV void unpack8(const u32x4& w, float (&f)[8]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = Elem<DT>::lo(w[i]);
+    f[2 * i + 1] = Elem<DT>::hi(w[i]);
+  }
+}
+
+// ---- delta[b,h,s] = sum_d dout * out --------------------------------------------------------------
+// One (b,s,h) row per group of D/8 lanes (each lane 8 elements = 16 B), reduced with shuffles.
+template <int D, int DT>
+__global__ __launch_bounds__(kEwThreads) void delta_kernel(
+    const char* dout, int64_t do_sb, int64_t do_ss, int64_t do_sh, const char* out, int64_t o_sb,
+    int64_t o_ss, int64_t o_sh, float* delta, int64_t d_sb, int64_t d_sh, int B, int S, int H) {
+  constexpr int LPR = D / 8;                       // lanes per row
+  constexpr int RPB = kEwThreads / LPR;            // rows per block per iteration
+  const int sub = threadIdx.x % LPR;
+  const int64_t nrows = (int64_t)B * S * H;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR; r < nrows;
+       r += (int64_t)gridDim.x * RPB) {
+    const int h = (int)(r % H);
+    const int64_t bs = r / H;
+    const int s = (int)(bs % S);
+    const int b = (int)(bs / S);
+    const u32x4 a = *(const u32x4*)(dout + 2 * (b * do_sb + (int64_t)s * do_ss + h * do_sh) + 16 * sub);
+    const u32x4 c = *(const u32x4*)(out + 2 * (b * o_sb + (int64_t)s * o_ss + h * o_sh) + 16 * sub);
+    float fa[8], fc[8];
+    unpack8<DT>(a, fa);
+    unpack8<DT>(c, fc);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc += fa[i] * fc[i];
+#pragma unroll
+    for (int m = LPR / 2; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if (sub == 0) delta[b * d_sb + h * d_sh + s] = acc;
+  }
+}
+
+// ---- stand-alone LSE merge ------------------------------------------------------------------------
+template <int D, int DT>
+__global__ __launch_bounds__(kEwThreads) void merge_kernel(
+    float* acc, int64_t a_sb, int64_t a_ss, int64_t a_sh, float* lse, int64_t l_sb, int64_t l_sh,
+    const char* bo, int64_t bo_sb, int64_t bo_ss, int64_t bo_sh, const float* bl, int64_t bl_sb,
+    int64_t bl_sh, int B, int S, int H, int first) {
+  constexpr int LPR = D / 8;
+  constexpr int RPB = kEwThreads / LPR;
+  const int sub = threadIdx.x % LPR;
+  const int64_t nrows = (int64_t)B * S * H;
+  for (int64_t r = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR; r < nrows;
+       r += (int64_t)gridDim.x * RPB) {
+    const int h = (int)(r % H);
+    const int64_t bs = r / H;
+    const int s = (int)(bs % S);
+    const int b = (int)(bs / S);
+    const u32x4 w = *(const u32x4*)(bo + 2 * (b * bo_sb + (int64_t)s * bo_ss + h * bo_sh) + 16 * sub);
+    float fb[8];
+    unpack8<DT>(w, fb);
+    const float blk = bl[b * bl_sb + h * bl_sh + s];
+    float* ap = acc + b * a_sb + (int64_t)s * a_ss + h * a_sh + 8 * sub;
+    float* lp = lse + b * l_sb + h * l_sh + s;
+    float w_old = 0.f, w_blk = 1.f, nl = blk;
+    if (!first) {
+      const float old = *lp;
+      const float mx = fmaxf(old, blk);
+      if (mx == USP_NEG_INF) {
+        w_old = 0.f; w_blk = 0.f; nl = USP_NEG_INF;
+      } else {
+        const float eo = exp2f((old - mx) * kLog2e), eb = exp2f((blk - mx) * kLog2e);
+        const float sum = eo + eb;
+        nl = mx + log2f(sum) * kLn2;
+        w_old = eo / sum;
+        w_blk = eb / sum;
+      }
+    }
+    f32x4 v0 = {fb[0] * w_blk, fb[1] * w_blk, fb[2] * w_blk, fb[3] * w_blk};
+    f32x4 v1 = {fb[4] * w_blk, fb[5] * w_blk, fb[6] * w_blk, fb[7] * w_blk};
+    if (!first) {
+      v0 += *(const f32x4*)ap * w_old;
+      v1 += *(const f32x4*)(ap + 4) * w_old;
+    }
+    *(f32x4*)ap = v0;
+    *(f32x4*)(ap + 4) = v1;
+    // every lane of the row group read `old` above; the row's lanes sit in one wave
+    if (sub == 0) *lp = nl;
+  }
+}
+
+// ---- row-gather copy -------------------------------------------------------------------------------
+__global__ __launch_bounds__(kEwThreads) void copy_rows_kernel(
+    char* dst, const char* src, int64_t chunks_per_row, int64_t n1, int64_t n2, int64_t n3,
+    int64_t total_chunks, int64_t ds0, int64_t ds1, int64_t ds2, int64_t ds3, int64_t ss0,
+    int64_t ss1, int64_t ss2, int64_t ss3) {
+  for (int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x; i < total_chunks;
+       i += (int64_t)gridDim.x * kEwThreads) {
+    const int64_t cc = i % chunks_per_row;
+    int64_t r = i / chunks_per_row;
+    const int64_t i3 = r % n3; r /= n3;
+    const int64_t i2 = r % n2; r /= n2;
+    const int64_t i1 = r % n1;
+    const int64_t i0 = r / n1;
+    const u32x4 v = *(const u32x4*)(src + i0 * ss0 + i1 * ss1 + i2 * ss2 + i3 * ss3 + 16 * cc);
+    *(u32x4*)(dst + i0 * ds0 + i1 * ds1 + i2 * ds2 + i3 * ds3 + 16 * cc) = v;
+  }
+}
+
+// ---- fp32 -> 16-bit cast ---------------------------------------------------------------------------
+template <int DT>
+__global__ __launch_bounds__(kEwThreads) void cast_kernel(char* dst, int64_t d_rs, const float* src,
+                                                          int64_t s_rs, int64_t rows, int64_t n8) {
+  const int64_t total = rows * n8;
+  for (int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kEwThreads) {
+    const int64_t r = i / n8, c = i % n8;
+    const float* sp = src + r * s_rs + 8 * c;
+    const f32x4 a = *(const f32x4*)sp, b = *(const f32x4*)(sp + 4);
+    u32x4 w = {Elem<DT>::pack2(a[0], a[1]), Elem<DT>::pack2(a[2], a[3]),
+               Elem<DT>::pack2(b[0], b[1]), Elem<DT>::pack2(b[2], b[3])};
+    *(u32x4*)(dst + 2 * (r * d_rs + 8 * c)) = w;
+  }
+}
+
+// ---- fp32 add --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kEwThreads) void add_kernel(float* dst, int64_t d_rs, const float* a,
+                                                         int64_t a_rs, const float* b, int64_t b_rs,
+                                                         int64_t rows, int64_t n4) {
+  const int64_t total = rows * n4;
+  for (int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * kEwThreads) {
+    const int64_t r = i / n4, c = i % n4;
+    const f32x4 x = *(const f32x4*)(a + r * a_rs + 4 * c);
+    const f32x4 y = *(const f32x4*)(b + r * b_rs + 4 * c);
+    *(f32x4*)(dst + r * d_rs + 4 * c) = x + y;
+  }
+}
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static bool t16(const usp_tensor* t, int esize) {
+  const int m = 16 / esize;
+  return t && t->ptr && al16(t->ptr) && t->stride_b % m == 0 && t->stride_s % m == 0 &&
+         t->stride_h % m == 0;
+}
+static int launched() { return hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH; }
+
+}  // namespace usp
+
+using namespace usp;
+
+extern "C" int usp_bwd_delta(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t D,
+                             const usp_tensor* dout, const usp_tensor* out, float* delta,
+                             int64_t d_sb, int64_t d_sh, void* stream) {
+  if (!dout || !out || !delta || B <= 0 || S <= 0 || H <= 0) return USP_EINVAL;
+  if (dtype != USP_BF16 && dtype != USP_FP16) return USP_EINVAL;
+  if (D != 32 && D != 64 && D != 128) return USP_EUNSUPPORTED;
+  if (!t16(dout, 2) || !t16(out, 2)) return USP_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * S * H;
+  const int grid = ew_grid(rows * (D / 8));
+#define USP_DELTA(DD, TT)                                                                         \
+  hipLaunchKernelGGL((delta_kernel<DD, TT>), dim3(grid), dim3(kEwThreads), 0, st,                 \
+                     (const char*)dout->ptr, dout->stride_b, dout->stride_s, dout->stride_h,      \
+                     (const char*)out->ptr, out->stride_b, out->stride_s, out->stride_h, delta,   \
+                     d_sb, d_sh, B, S, H)
+  switch (D * 2 + dtype) {
+    case 64: USP_DELTA(32, 0); break;
+    case 65: USP_DELTA(32, 1); break;
+    case 128: USP_DELTA(64, 0); break;
+    case 129: USP_DELTA(64, 1); break;
+    case 256: USP_DELTA(128, 0); break;
+    case 257: USP_DELTA(128, 1); break;
+  }
+#undef USP_DELTA
+  return launched();
+}
+
+extern "C" int usp_lse_merge(int32_t dtype, int32_t B, int32_t S, int32_t H, int32_t D,
+                             const usp_tensor* acc, float* lse, int64_t l_sb, int64_t l_sh,
+                             const usp_tensor* bo, const float* bl, int64_t bl_sb, int64_t bl_sh,
+                             int32_t first, void* stream) {
+  if (!acc || !lse || !bo || !bl || B <= 0 || S <= 0 || H <= 0) return USP_EINVAL;
+  if (dtype != USP_BF16 && dtype != USP_FP16) return USP_EINVAL;
+  if (D != 32 && D != 64 && D != 128) return USP_EUNSUPPORTED;
+  if (!t16(acc, 4) || !t16(bo, 2)) return USP_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = (int64_t)B * S * H;
+  const int grid = ew_grid(rows * (D / 8));
+#define USP_MERGE(DD, TT)                                                                         \
+  hipLaunchKernelGGL((merge_kernel<DD, TT>), dim3(grid), dim3(kEwThreads), 0, st,                 \
+                     (float*)acc->ptr, acc->stride_b, acc->stride_s, acc->stride_h, lse, l_sb,    \
+                     l_sh, (const char*)bo->ptr, bo->stride_b, bo->stride_s, bo->stride_h, bl,    \
+                     bl_sb, bl_sh, B, S, H, first ? 1 : 0)
+  switch (D * 2 + dtype) {
+    case 64: USP_MERGE(32, 0); break;
+    case 65: USP_MERGE(32, 1); break;
+    case 128: USP_MERGE(64, 0); break;
+    case 129: USP_MERGE(64, 1); break;
+    case 256: USP_MERGE(128, 0); break;
+    case 257: USP_MERGE(128, 1); break;
+  }
+#undef USP_MERGE
+  return launched();
+}
+
+extern "C" int usp_copy_rows(void* dst, const void* src, int64_t row_bytes, int64_t n0, int64_t n1,
+                             int64_t n2, int64_t n3, int64_t ds0, int64_t ds1, int64_t ds2,
+                             int64_t ds3, int64_t ss0, int64_t ss1, int64_t ss2, int64_t ss3,
+                             void* stream) {
+  if (!dst || !src || row_bytes <= 0 || n0 <= 0 || n1 <= 0 || n2 <= 0 || n3 <= 0) return USP_EINVAL;
+  const int64_t all = row_bytes | ds0 | ds1 | ds2 | ds3 | ss0 | ss1 | ss2 | ss3;
+  if ((all & 15) || !al16(dst) || !al16(src)) return USP_EUNSUPPORTED;
+  const int64_t cpr = row_bytes / 16;
+  const int64_t total = cpr * n0 * n1 * n2 * n3;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(ew_grid(total)), dim3(kEwThreads), 0,
+                     (hipStream_t)stream, (char*)dst, (const char*)src, cpr, n1, n2, n3, total, ds0,
+                     ds1, ds2, ds3, ss0, ss1, ss2, ss3);
+  return launched();
+}
+
+extern "C" int usp_cast_from_f32(int32_t dtype, void* dst, int64_t d_rs, const float* src,
+                                 int64_t s_rs, int64_t rows, int64_t n, void* stream) {
+  if (!dst || !src || rows <= 0 || n <= 0) return USP_EINVAL;
+  if (dtype != USP_BF16 && dtype != USP_FP16) return USP_EINVAL;
+  if ((n & 7) || (d_rs & 7) || (s_rs & 3) || !al16(dst) || !al16(src)) return USP_EUNSUPPORTED;
+  const int64_t n8 = n / 8;
+  const int grid = ew_grid(rows * n8);
+  if (dtype == USP_BF16)
+    hipLaunchKernelGGL(cast_kernel<0>, dim3(grid), dim3(kEwThreads), 0, (hipStream_t)stream,
+                       (char*)dst, d_rs, src, s_rs, rows, n8);
+  else
+    hipLaunchKernelGGL(cast_kernel<1>, dim3(grid), dim3(kEwThreads), 0, (hipStream_t)stream,
+                       (char*)dst, d_rs, src, s_rs, rows, n8);
+  return launched();
+}
+
+extern "C" int usp_add_f32(float* dst, int64_t d_rs, const float* a, int64_t a_rs, const float* b,
+                           int64_t b_rs, int64_t rows, int64_t n, void* stream) {
+  if (!dst || !a || !b || rows <= 0 || n <= 0) return USP_EINVAL;
+  if ((n & 3) || (d_rs & 3) || (a_rs & 3) || (b_rs & 3) || !al16(dst) || !al16(a) || !al16(b))
+    return USP_EUNSUPPORTED;
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(add_kernel, dim3(ew_grid(rows * n4)), dim3(kEwThreads), 0, (hipStream_t)stream,
+                     dst, d_rs, a, a_rs, b, b_rs, rows, n4);
+  return launched();
+}
+
+extern "C" int usp_abi_version(void) { return USP_ABI_VERSION; }
+
+extern "C" const char* usp_strerror(int code) {
+  switch (code) {
+    case USP_OK: return "ok";
+    case USP_EINVAL: return "invalid argument (null pointer, non-positive size or bad dtype)";
+    case USP_EUNSUPPORTED:
+      return "unsupported shape/layout (head_dim must be 32/64/128, Hq % Hkv == 0, 16-byte aligned "
+             "pointers and strides)";
+    case USP_ELAUNCH: return "HIP kernel launch failed";
+  }
+  return "unknown error";
+}

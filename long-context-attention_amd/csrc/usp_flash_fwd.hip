@@ -1,0 +1,376 @@
+// Blockwise flash-attention forward for gfx950 with the ring LSE-merge fused into the epilogue.
+// C ABI: usp_flash_fwd (include/usp_hip.h).  Replaces the reference's `fwd-only` block kernel
+// (yunchang/kernels/attention.py:44-136) and update_out_and_lse (yunchang/ring/utils.py:10-51).
+//
+// Structure (one workgroup = 8 waves = 256 query rows of one (batch, head); KV tile = 64 keys):
+//   * "fully swapped" MFMA orientation: S^T = K Q^T and O^T = V^T P^T with
+//     v_mfma_f32_32x32x16, so that every lane owns ONE query row (q = lane & 31) in both
+//     accumulators; the two half-waves hold complementary key / dim subsets.  Row max / sum /
+//     rescale / LSE merge are therefore lane-local (+ one v_permlane32_swap per row statistic).
+//   * Q fragments live in registers for the whole kernel (B operand of K Q^T).
+//   * K tile in LDS row-major with a 16-byte-slot XOR swizzle -> conflict-free ds_read_b128.
+//   * V tile in LDS as [4 keys][32 dims] 256-byte blocks -> ds_read_b64_tr_b16 delivers the
+//     A operand of V^T P^T directly; one block = exactly one LDS bank row per half-wave.
+//   * P needs no cross-lane shuffle: the key order of each PV k-step is DEFINED as the order in
+//     which the S^T accumulator holds keys, and V is read in that same order.
+//   * K/V are register-staged and double-buffered: global loads for tile t+1 are issued before
+//     the MFMAs of tile t and written to the other LDS buffer after them (one barrier per tile).
+//   * exp2 with softmax_scale*log2(e) folded into one FMA per score.
+#include "usp_common.hpp"
+#include "usp_hip.h"
+
+namespace usp {
+
+struct FwdParams {
+  const char* q; const char* k; const char* v;
+  char* out; float* acc; float* lse;
+  int64_t q_sb, q_ss, q_sh;
+  int64_t k_sb, k_ss, k_sh;
+  int64_t v_sb, v_ss, v_sh;
+  int64_t o_sb, o_ss, o_sh;
+  int64_t a_sb, a_ss, a_sh;
+  int64_t lse_sb, lse_sh;
+  int B, Sq, Sk, Hq, Hkv, G, nq;
+  int causal_off;                 // Sk - Sq
+  float scale, scale_log2;
+  int merge_in, final_begin, final_end;
+};
+
+constexpr int kBM = 256;   // query rows per workgroup
+constexpr int kBN = 64;    // keys per KV tile
+constexpr int kThreads = 512;
+
+template <int D> struct KSwz {
+  // 16-byte slots per K row and rows per 256-byte LDS bank row
+  static constexpr int SPR = D / 8;
+  static constexpr int RPB = 16 / SPR < 1 ? 1 : 16 / SPR;
+  static USP_DEV int of(int row) { return (row / RPB) & (SPR - 1); }
+};
+
+template <int D, int DT, bool CAUSAL>
+__global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams p) {
+  using E = Elem<DT>;
+  constexpr int ROWB = D * 2;                 // bytes per K row
+  constexpr int KBYTES = kBN * ROWB;          // one K (or V) tile
+  constexpr int BUFB = 2 * KBYTES;            // K + V
+  constexpr int NKT = D / 16;                 // k-steps of K Q^T
+  constexpr int NDJ = D / 32;                 // 32-wide dim tiles of O^T
+  constexpr int NCH = kBN * D / 8;            // 16-byte chunks per tile
+  constexpr int NP = (NCH + kThreads - 1) / kThreads;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  USP_LDS char* smem = (USP_LDS char*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+
+  // ---- which (batch, head, query tile) ------------------------------------------------------
+  int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int qt_r = w % p.nq;
+  int rest = w / p.nq;
+  const int qt = CAUSAL ? (p.nq - 1 - qt_r) : qt_r;      // heavy (late) tiles first
+  const int g = rest % p.G;
+  rest /= p.G;
+  const int hkv = rest % p.Hkv;
+  const int b = rest / p.Hkv;
+  const int h = hkv * p.G + g;
+
+  const int q0 = qt * kBM;
+  const int qw = q0 + wave * 32;
+  const int row = qw + l31;
+  const int row_c = row < p.Sq ? row : p.Sq - 1;
+  const int off = p.causal_off;
+
+  // ---- KV range -----------------------------------------------------------------------------
+  int blk_kv_end = p.Sk, wave_kv_end = p.Sk;
+  if (CAUSAL) {
+    const int blk_last = (q0 + kBM < p.Sq ? q0 + kBM : p.Sq) - 1;
+    const int wav_last = (qw + 32 < p.Sq ? qw + 32 : p.Sq) - 1;
+    blk_kv_end = blk_last + off + 1 < p.Sk ? blk_last + off + 1 : p.Sk;
+    wave_kv_end = wav_last + off + 1 < p.Sk ? wav_last + off + 1 : p.Sk;
+  }
+  if (qw >= p.Sq) wave_kv_end = 0;
+  const int nt = blk_kv_end > 0 ? (blk_kv_end + kBN - 1) / kBN : 0;
+
+  // ---- Q fragments (B operand: lane holds Q[row][16t + 8hi .. +7]) ---------------------------
+  u32x4 qf[NKT];
+  {
+    const char* qp = p.q + 2 * (b * p.q_sb + (int64_t)row_c * p.q_ss + h * p.q_sh) + 16 * hi;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) qf[t] = *(const u32x4*)(qp + 32 * t);
+  }
+
+  // ---- staging maps (per thread, tile independent) -------------------------------------------
+  const char* kbase = p.k + 2 * (b * p.k_sb + hkv * p.k_sh);
+  const char* vbase = p.v + 2 * (b * p.v_sb + hkv * p.v_sh);
+  int k_row[NP], k_goff[NP], k_loff[NP], v_row[NP], v_goff[NP], v_loff[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int c = i * kThreads + tid;
+    {  // K: row-major, swizzled slots
+      const int r = c / (D / 8), c8 = c % (D / 8);
+      k_row[i] = r;
+      k_goff[i] = c8 * 16;
+      k_loff[i] = r * ROWB + ((c8 ^ KSwz<D>::of(r)) * 16);
+    }
+    {  // V: 16 consecutive threads fill one [4 keys][32 dims] block
+      const int q4 = c & 3, kr = (c >> 2) & 3, r2 = c >> 4;
+      const int dj = r2 % NDJ, kb = r2 / NDJ;
+      v_row[i] = 4 * kb + kr;
+      v_goff[i] = (32 * dj + 8 * q4) * 2;
+      v_loff[i] = KBYTES + (kb * NDJ + dj) * 256 + kr * 64 + q4 * 16;
+    }
+  }
+  u32x4 kst[NP], vst[NP];
+  auto stage_load = [&](int tile) {
+    const int k0 = tile * kBN;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (NCH % kThreads == 0 || i * kThreads + tid < NCH) {
+        int kr = k0 + k_row[i];
+        kr = kr < p.Sk ? kr : p.Sk - 1;
+        kst[i] = *(const u32x4*)(kbase + 2 * (int64_t)kr * p.k_ss + k_goff[i]);
+        int vr = k0 + v_row[i];
+        vr = vr < p.Sk ? vr : p.Sk - 1;
+        vst[i] = *(const u32x4*)(vbase + 2 * (int64_t)vr * p.v_ss + v_goff[i]);
+      }
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      if (NCH % kThreads == 0 || i * kThreads + tid < NCH) {
+        *(USP_LDS u32x4*)(smem + buf * BUFB + k_loff[i]) = kst[i];
+        *(USP_LDS u32x4*)(smem + buf * BUFB + v_loff[i]) = vst[i];
+      }
+    }
+  };
+
+  // ---- per-lane LDS read bases -----------------------------------------------------------------
+  // K fragment (A operand) for key half n32, k-step t: row 32*n32 + l31, slot (2t + hi) ^ swz.
+  const int k_rd_row = l31 * ROWB;
+  const int k_rd_x = hi ^ KSwz<D>::of(l31);          // (2t + hi) ^ s == (2t) ^ (hi ^ s)
+  // V fragment for (dj, ks, e): block (4ks + hi + 2e) * NDJ + dj; chunk of lane i in its 16-group.
+  const int v_rd = KBYTES + hi * NDJ * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 +
+                   (lane & 3) * 8;
+
+  // ---- accumulators ----------------------------------------------------------------------------
+  f32x16 o[NDJ];
+#pragma unroll
+  for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dj][r] = 0.f;
+  float m_run = USP_NEG_INF;   // running row max, raw score units
+  float l_run = 0.f;           // this lane's share of the row sum
+  const float c = p.scale_log2;
+
+  if (nt > 0) {
+    stage_load(0);
+    stage_store(0);
+  }
+  __syncthreads();
+
+  for (int t = 0; t < nt; ++t) {
+    const int buf = t & 1;
+    const int kt0 = t * kBN;
+    if (t + 1 < nt) stage_load(t + 1);
+
+    if (kt0 < wave_kv_end) {
+      USP_LDS const char* kb = smem + buf * BUFB;
+      // ---- S^T = K Q^T --------------------------------------------------------------------
+      f32x16 s0, s1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const int slot = ((2 * kt) ^ k_rd_x) * 16;
+        u32x4 ka = *(USP_LDS const u32x4*)(kb + k_rd_row + slot);
+        u32x4 kc = *(USP_LDS const u32x4*)(kb + 32 * ROWB + k_rd_row + slot);
+        s0 = E::mfma(ka, qf[kt], s0);
+        s1 = E::mfma(kc, qf[kt], s1);
+      }
+      // ---- mask ---------------------------------------------------------------------------
+      const bool need_mask = (kt0 + kBN > p.Sk) || (CAUSAL && kt0 + kBN - 1 > qw + off);
+      if (need_mask) {
+        int klim = p.Sk - 1;
+        if (CAUSAL) klim = row + off < klim ? row + off : klim;
+        const int kb0 = kt0 + 4 * hi;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb0 + (r & 3) + 8 * (r >> 2);
+          if (key > klim) s0[r] = USP_NEG_INF;
+          if (key + 32 > klim) s1[r] = USP_NEG_INF;
+        }
+      }
+      // ---- online softmax (lane-local row) --------------------------------------------------
+      float mt = s0[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s0[r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s1[r]);
+      mt = xhalf_max(mt);
+      const float m_new = fmaxf(m_run, mt);
+      const float m_use = (m_new == USP_NEG_INF) ? 0.f : m_new;
+      const float mc = m_use * c;
+      const float alpha = fast_exp2(m_run * c - mc);
+      m_run = m_new;
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = fast_exp2(__builtin_fmaf(s0[r], c, -mc));
+        s1[r] = fast_exp2(__builtin_fmaf(s1[r], c, -mc));
+        rs += s0[r] + s1[r];
+      }
+      l_run = l_run * alpha + rs;
+#pragma unroll
+      for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
+      // ---- P (B operand of V^T P^T): k-step ks = 2*n32 + (r>>3), element e = r & 7 ---------
+      u32x4 pf[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pf[0][j] = E::pack2(s0[2 * j], s0[2 * j + 1]);
+        pf[1][j] = E::pack2(s0[8 + 2 * j], s0[8 + 2 * j + 1]);
+        pf[2][j] = E::pack2(s1[2 * j], s1[2 * j + 1]);
+        pf[3][j] = E::pack2(s1[8 + 2 * j], s1[8 + 2 * j + 1]);
+      }
+      // ---- O^T += V^T P^T ------------------------------------------------------------------
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+        for (int dj = 0; dj < NDJ; ++dj) {
+          USP_LDS const char* vp = kb + v_rd + (4 * ks * NDJ + dj) * 256;
+          u32x2 v0 = lds_read_tr16(vp);
+          u32x2 v1 = lds_read_tr16(vp + 2 * NDJ * 256);
+          u32x4 va = {v0[0], v0[1], v1[0], v1[1]};
+          o[dj] = E::mfma(va, pf[ks], o[dj]);
+        }
+      }
+    }
+
+    if (t + 1 < nt) stage_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: normalise, merge with the running result, store -------------------------------
+  const float l_tot = xhalf_sum(l_run);
+  const bool empty = !(l_tot > 0.f);
+  const float inv = empty ? 0.f : 1.f / l_tot;
+  const float blk_lse = empty ? USP_NEG_INF : (m_run * c + log2f(l_tot)) * kLn2;
+  float w_blk = inv, w_old = 0.f, new_lse = blk_lse;
+  float* lse_p = p.lse + b * p.lse_sb + h * p.lse_sh + row;
+  if (row < p.Sq) {
+    if (p.merge_in) {
+      const float old = *lse_p;
+      const float mx = fmaxf(old, blk_lse);
+      if (mx == USP_NEG_INF) {
+        new_lse = USP_NEG_INF; w_old = 0.f; w_blk = 0.f;
+      } else {
+        const float e_old = exp2f((old - mx) * kLog2e);
+        const float e_blk = exp2f((blk_lse - mx) * kLog2e);
+        const float sum = e_old + e_blk;
+        new_lse = mx + log2f(sum) * kLn2;
+        w_old = e_old / sum;
+        w_blk = e_blk / sum * inv;
+      }
+    }
+    if (hi == 0) *lse_p = new_lse;
+    const bool fin = row >= p.final_begin && row < p.final_end;
+    const int64_t arow = b * p.a_sb + (int64_t)row * p.a_ss + h * p.a_sh;
+    const int64_t orow = b * p.o_sb + (int64_t)row * p.o_ss + h * p.o_sh;
+#pragma unroll
+    for (int dj = 0; dj < NDJ; ++dj) {
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = 32 * dj + 8 * g4 + 4 * hi;
+        f32x4 val = {o[dj][4 * g4] * w_blk, o[dj][4 * g4 + 1] * w_blk, o[dj][4 * g4 + 2] * w_blk,
+                     o[dj][4 * g4 + 3] * w_blk};
+        if (p.merge_in) {
+          const f32x4 a = *(const f32x4*)(p.acc + arow + d0);
+          val += a * w_old;
+        }
+        if (fin) {
+          u32x2 pk = {E::pack2(val[0], val[1]), E::pack2(val[2], val[3])};
+          *(u32x2*)(p.out + 2 * (orow + d0)) = pk;
+        } else {
+          *(f32x4*)(p.acc + arow + d0) = val;
+        }
+      }
+    }
+  }
+}
+
+template <int D, int DT>
+static int launch_fwd(const FwdParams& p, bool causal, hipStream_t st) {
+  const int grid = p.B * p.Hq * p.nq;
+  const size_t lds = 2 * 2 * kBN * D * 2;
+  if (causal)
+    hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true>), dim3(grid), dim3(kThreads), lds, st, p);
+  else
+    hipLaunchKernelGGL((flash_fwd_kernel<D, DT, false>), dim3(grid), dim3(kThreads), lds, st, p);
+  return hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
+}
+
+static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
+static bool tensor16_ok(const usp_tensor& t, int esize) {
+  const int m = 16 / esize;
+  return t.ptr && aligned16(t.ptr) && t.stride_b % m == 0 && t.stride_s % m == 0 &&
+         t.stride_h % m == 0;
+}
+
+}  // namespace usp
+
+extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
+  using namespace usp;
+  if (!a || !a->lse) return USP_EINVAL;
+  if (a->dtype != USP_BF16 && a->dtype != USP_FP16) return USP_EINVAL;
+  if (a->B <= 0 || a->Sq <= 0 || a->Sk <= 0 || a->Hq <= 0 || a->Hkv <= 0) return USP_EINVAL;
+  if (!(a->softmax_scale > 0.f)) return USP_EINVAL;
+  if (a->D != 32 && a->D != 64 && a->D != 128) return USP_EUNSUPPORTED;
+  if (a->Hq % a->Hkv != 0) return USP_EUNSUPPORTED;
+  if (!tensor16_ok(a->q, 2) || !tensor16_ok(a->k, 2) || !tensor16_ok(a->v, 2))
+    return USP_EUNSUPPORTED;
+  int fb = a->final_begin < 0 ? 0 : a->final_begin;
+  int fe = a->final_end > a->Sq ? a->Sq : a->final_end;
+  if (fe < fb) fe = fb;
+  const bool any_final = fe > fb, any_acc = (fb > 0 || fe < a->Sq);
+  if (any_final && !(a->out.ptr && (reinterpret_cast<uintptr_t>(a->out.ptr) & 7) == 0 &&
+                     a->out.stride_b % 4 == 0 && a->out.stride_s % 4 == 0 &&
+                     a->out.stride_h % 4 == 0))
+    return a->out.ptr ? USP_EUNSUPPORTED : USP_EINVAL;
+  if ((any_acc || a->merge_in) && !tensor16_ok(a->acc, 4))
+    return a->acc.ptr ? USP_EUNSUPPORTED : USP_EINVAL;
+
+  FwdParams p;
+  p.q = (const char*)a->q.ptr; p.k = (const char*)a->k.ptr; p.v = (const char*)a->v.ptr;
+  p.out = (char*)a->out.ptr; p.acc = (float*)a->acc.ptr; p.lse = a->lse;
+  p.q_sb = a->q.stride_b; p.q_ss = a->q.stride_s; p.q_sh = a->q.stride_h;
+  p.k_sb = a->k.stride_b; p.k_ss = a->k.stride_s; p.k_sh = a->k.stride_h;
+  p.v_sb = a->v.stride_b; p.v_ss = a->v.stride_s; p.v_sh = a->v.stride_h;
+  p.o_sb = a->out.stride_b; p.o_ss = a->out.stride_s; p.o_sh = a->out.stride_h;
+  p.a_sb = a->acc.stride_b; p.a_ss = a->acc.stride_s; p.a_sh = a->acc.stride_h;
+  p.lse_sb = a->lse_stride_b; p.lse_sh = a->lse_stride_h;
+  p.B = a->B; p.Sq = a->Sq; p.Sk = a->Sk; p.Hq = a->Hq; p.Hkv = a->Hkv;
+  p.G = a->Hq / a->Hkv;
+  p.nq = (a->Sq + kBM - 1) / kBM;
+  p.causal_off = a->Sk - a->Sq;
+  p.scale = a->softmax_scale;
+  p.scale_log2 = a->softmax_scale * kLog2e;
+  p.merge_in = a->merge_in ? 1 : 0;
+  p.final_begin = fb; p.final_end = fe;
+  hipStream_t st = (hipStream_t)stream;
+  const bool causal = a->causal != 0;
+  switch (a->D * 2 + a->dtype) {
+    case 32 * 2 + 0: return launch_fwd<32, 0>(p, causal, st);
+    case 32 * 2 + 1: return launch_fwd<32, 1>(p, causal, st);
+    case 64 * 2 + 0: return launch_fwd<64, 0>(p, causal, st);
+    case 64 * 2 + 1: return launch_fwd<64, 1>(p, causal, st);
+    case 128 * 2 + 0: return launch_fwd<128, 0>(p, causal, st);
+    case 128 * 2 + 1: return launch_fwd<128, 1>(p, causal, st);
+  }
+  return USP_EUNSUPPORTED;
+}
