@@ -1,0 +1,244 @@
+"""ctypes binding of libusp_hip.so (C ABI: include/usp_hip.h).
+
+This is the ONLY device backend of the package.  There is no CPU or eager-PyTorch fallback: if the
+library is missing, or a tensor is not a CUDA(ROCm) tensor, the call raises.  PyTorch is used for
+device memory and streams only; every kernel runs on ``torch.cuda.current_stream()``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libusp_hip.so")
+_lib = None
+
+USP_BF16, USP_FP16 = 0, 1
+ABI_VERSION = 1
+
+
+class UspTensor(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("stride_b", ctypes.c_int64),
+                ("stride_s", ctypes.c_int64), ("stride_h", ctypes.c_int64)]
+
+
+class UspFwdArgs(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int32), ("B", ctypes.c_int32), ("Sq", ctypes.c_int32),
+                ("Sk", ctypes.c_int32), ("Hq", ctypes.c_int32), ("Hkv", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("causal", ctypes.c_int32),
+                ("softmax_scale", ctypes.c_float),
+                ("q", UspTensor), ("k", UspTensor), ("v", UspTensor),
+                ("out", UspTensor), ("acc", UspTensor),
+                ("lse", ctypes.c_void_p), ("lse_stride_b", ctypes.c_int64),
+                ("lse_stride_h", ctypes.c_int64),
+                ("merge_in", ctypes.c_int32), ("final_begin", ctypes.c_int32),
+                ("final_end", ctypes.c_int32)]
+
+
+class UspBwdArgs(ctypes.Structure):
+    _fields_ = [("dtype", ctypes.c_int32), ("B", ctypes.c_int32), ("Sq", ctypes.c_int32),
+                ("Sk", ctypes.c_int32), ("Hq", ctypes.c_int32), ("Hkv", ctypes.c_int32),
+                ("D", ctypes.c_int32), ("causal", ctypes.c_int32),
+                ("softmax_scale", ctypes.c_float),
+                ("dout", UspTensor), ("q", UspTensor), ("k", UspTensor), ("v", UspTensor),
+                ("lse", ctypes.c_void_p), ("delta", ctypes.c_void_p),
+                ("lse_stride_b", ctypes.c_int64), ("lse_stride_h", ctypes.c_int64),
+                ("delta_stride_b", ctypes.c_int64), ("delta_stride_h", ctypes.c_int64),
+                ("dq", UspTensor), ("dk", UspTensor), ("dv", UspTensor),
+                ("accum_dq", ctypes.c_int32), ("accum_dk", ctypes.c_int32),
+                ("accum_dv", ctypes.c_int32)]
+
+
+EXPORTS = ("usp_flash_fwd", "usp_flash_bwd", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
+           "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror")
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load libusp_hip.so (once).  Raises RuntimeError, loudly, when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(
+            f"libusp_hip.so not found at {_LIB_PATH}: the HIP extension is not built. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` or "
+            f"`make -C long-context-attention_amd/csrc`. There is no CPU fallback.")
+    L = ctypes.CDLL(_LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise RuntimeError(f"{_LIB_PATH} does not export {name} (stale build?)")
+    L.usp_strerror.restype = ctypes.c_char_p
+    L.usp_abi_version.restype = ctypes.c_int
+    if L.usp_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libusp_hip.so ABI {L.usp_abi_version()} != binding ABI {ABI_VERSION}")
+    i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+    L.usp_flash_fwd.argtypes = [ctypes.POINTER(UspFwdArgs), vp]
+    L.usp_flash_bwd.argtypes = [ctypes.POINTER(UspBwdArgs), vp]
+    L.usp_bwd_delta.argtypes = [i32, i32, i32, i32, i32, ctypes.POINTER(UspTensor),
+                                ctypes.POINTER(UspTensor), vp, i64, i64, vp]
+    L.usp_lse_merge.argtypes = [i32, i32, i32, i32, i32, ctypes.POINTER(UspTensor), vp, i64, i64,
+                                ctypes.POINTER(UspTensor), vp, i64, i64, i32, vp]
+    L.usp_copy_rows.argtypes = [vp, vp] + [i64] * 13 + [vp]
+    L.usp_cast_from_f32.argtypes = [i32, vp, i64, vp, i64, i64, i64, vp]
+    L.usp_add_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, vp]
+    for name in EXPORTS[:7]:
+        getattr(L, name).restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what} failed: {load().usp_strerror(rc).decode()} (code {rc})")
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.bfloat16:
+        return USP_BF16
+    if dtype == torch.float16:
+        return USP_FP16
+    raise TypeError(f"libusp_hip supports bfloat16 / float16 inputs, got {dtype}")
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "libusp_hip kernels need ROCm device tensors (got a CPU tensor); there is no CPU "
+                "fallback in this package")
+
+
+def _t4(t: Optional[torch.Tensor]) -> UspTensor:
+    """(B,S,H,D) view with unit dim stride -> usp_tensor."""
+    if t is None:
+        return UspTensor(None, 0, 0, 0)
+    assert t.dim() == 4, t.shape
+    if t.stride(3) != 1:
+        raise ValueError("last (head_dim) stride must be 1")
+    return UspTensor(t.data_ptr(), t.stride(0), t.stride(1), t.stride(2))
+
+
+def _lse3(t: torch.Tensor):
+    """(B,H,S) fp32 with unit seq stride -> (ptr, stride_b, stride_h)."""
+    assert t.dim() == 3 and t.dtype == torch.float32
+    if t.shape[2] > 1 and t.stride(2) != 1:
+        raise ValueError("lse/delta must have unit stride along the sequence")
+    return ctypes.c_void_p(t.data_ptr()), t.stride(0), t.stride(1)
+
+
+def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=None,
+              merge_in: bool = False, final_begin: int = 0, final_end: Optional[int] = None):
+    """usp_flash_fwd (include/usp_hip.h).  q (B,Sq,Hq,D); k,v (B,Sk,Hkv,D); lse (B,Hq,Sq) fp32;
+    out 16-bit / acc fp32 (B,Sq,Hq,D).  All may be strided views (unit dim stride)."""
+    _require_cuda(q, k, v, lse, out, acc)
+    B, Sq, Hq, D = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    a = UspFwdArgs()
+    a.dtype = dtype_code(q.dtype)
+    a.B, a.Sq, a.Sk, a.Hq, a.Hkv, a.D = B, Sq, Sk, Hq, Hkv, D
+    a.causal = 1 if causal else 0
+    a.softmax_scale = float(softmax_scale)
+    a.q, a.k, a.v, a.out, a.acc = _t4(q), _t4(k), _t4(v), _t4(out), _t4(acc)
+    a.lse, a.lse_stride_b, a.lse_stride_h = _lse3(lse)
+    a.merge_in = 1 if merge_in else 0
+    a.final_begin = final_begin
+    a.final_end = Sq if final_end is None else final_end
+    _check(load().usp_flash_fwd(ctypes.byref(a), _stream()), "usp_flash_fwd")
+
+
+def bwd_delta(dout, out, delta):
+    _require_cuda(dout, out, delta)
+    B, S, H, D = dout.shape
+    td, to = _t4(dout), _t4(out)
+    p, sb, sh = _lse3(delta)
+    _check(load().usp_bwd_delta(dtype_code(dout.dtype), B, S, H, D, ctypes.byref(td),
+                                ctypes.byref(to), p, sb, sh, _stream()), "usp_bwd_delta")
+
+
+def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causal: bool,
+              accum_dq=False, accum_dk=False, accum_dv=False):
+    """usp_flash_bwd.  dq/dk/dv are fp32 (B,S,H,D) views, written or accumulated."""
+    _require_cuda(dout, q, k, v, lse, delta, dq, dk, dv)
+    B, Sq, Hq, D = q.shape
+    Sk, Hkv = k.shape[1], k.shape[2]
+    a = UspBwdArgs()
+    a.dtype = dtype_code(q.dtype)
+    a.B, a.Sq, a.Sk, a.Hq, a.Hkv, a.D = B, Sq, Sk, Hq, Hkv, D
+    a.causal = 1 if causal else 0
+    a.softmax_scale = float(softmax_scale)
+    a.dout, a.q, a.k, a.v = _t4(dout), _t4(q), _t4(k), _t4(v)
+    a.lse, a.lse_stride_b, a.lse_stride_h = _lse3(lse)
+    a.delta, a.delta_stride_b, a.delta_stride_h = _lse3(delta)
+    for t in (dq, dk, dv):
+        if t.dtype != torch.float32:
+            raise TypeError("dq/dk/dv buffers of usp_flash_bwd are fp32")
+    a.dq, a.dk, a.dv = _t4(dq), _t4(dk), _t4(dv)
+    a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
+    _check(load().usp_flash_bwd(ctypes.byref(a), _stream()), "usp_flash_bwd")
+
+
+def lse_merge(acc, lse, blk_out, blk_lse, first: bool):
+    _require_cuda(acc, lse, blk_out, blk_lse)
+    B, S, H, D = acc.shape
+    ta, tb = _t4(acc), _t4(blk_out)
+    p, sb, sh = _lse3(lse)
+    p2, sb2, sh2 = _lse3(blk_lse)
+    _check(load().usp_lse_merge(dtype_code(blk_out.dtype), B, S, H, D, ctypes.byref(ta), p, sb, sh,
+                                ctypes.byref(tb), p2, sb2, sh2, 1 if first else 0, _stream()),
+           "usp_lse_merge")
+
+
+def copy_rows(dst, src, row_bytes, sizes, dst_strides, src_strides):
+    """usp_copy_rows: strides in BYTES, 4 outer dims."""
+    _require_cuda(dst, src)
+    n = list(sizes) + [1] * (4 - len(sizes))
+    ds = list(dst_strides) + [0] * (4 - len(dst_strides))
+    ss = list(src_strides) + [0] * (4 - len(src_strides))
+    _check(load().usp_copy_rows(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()),
+                                row_bytes, *n, *ds, *ss, _stream()), "usp_copy_rows")
+
+
+def _rows2d(t: torch.Tensor):
+    """View a tensor as `rows` rows of `n` contiguous elements with one row stride."""
+    if t.is_contiguous():
+        return 1, t.numel(), t.numel()
+    if t.dim() == 4 and t[0].is_contiguous():          # (B, ...) slices of a bigger batch stride
+        return t.shape[0], t[0].numel(), t.stride(0)
+    raise ValueError("expected a contiguous tensor or a batch of contiguous slices")
+
+
+def cast_from_f32(dst16, src32):
+    _require_cuda(dst16, src32)
+    r1, n1, s1 = _rows2d(dst16)
+    r2, n2, s2 = _rows2d(src32)
+    if (r1, n1) != (r2, n2):
+        r1, n1, s1, s2 = dst16.shape[0], dst16[0].numel(), dst16.stride(0), src32.stride(0)
+        assert dst16[0].is_contiguous() and src32[0].is_contiguous()
+    _check(load().usp_cast_from_f32(dtype_code(dst16.dtype), ctypes.c_void_p(dst16.data_ptr()), s1,
+                                    ctypes.c_void_p(src32.data_ptr()), s2, r1, n1, _stream()),
+           "usp_cast_from_f32")
+
+
+def add_f32(dst, a, b):
+    """dst = a + b (fp32), tensors contiguous or batches of contiguous slices of equal shape."""
+    _require_cuda(dst, a, b)
+    assert dst.shape == a.shape == b.shape
+    if dst.is_contiguous() and a.is_contiguous() and b.is_contiguous():
+        rows, n, sd, sa, sb_ = 1, dst.numel(), dst.numel(), a.numel(), b.numel()
+    else:
+        assert dst[0].is_contiguous() and a[0].is_contiguous() and b[0].is_contiguous()
+        rows, n = dst.shape[0], dst[0].numel()
+        sd, sa, sb_ = dst.stride(0), a.stride(0), b.stride(0)
+    _check(load().usp_add_f32(ctypes.c_void_p(dst.data_ptr()), sd, ctypes.c_void_p(a.data_ptr()), sa,
+                              ctypes.c_void_p(b.data_ptr()), sb_, rows, n, _stream()), "usp_add_f32")

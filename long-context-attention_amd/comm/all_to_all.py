@@ -1,0 +1,128 @@
+"""Ulysses head <-> sequence all-to-all: same surface as yunchang/comm/all_to_all.py:15-134.
+
+MI355X-first differences (results identical):
+  * one HBM pass per exchange instead of two: the reference copies before AND after
+    `all_to_all_single` (all_to_all.py:45-49 and :62-65 / :76-84 and :98-100).  Here the receive
+    buffer of the head-scatter exchange is returned as a strided (B,S,H/P,D) VIEW of its natural
+    (S,B,H/P,D) layout -- the attention kernels take strides -- and the send buffer of the
+    sequence-scatter exchange is that same layout, which the kernels write directly;
+  * the remaining pack / unpack is one `usp_copy_rows` launch (16-byte lanes, rows of H/P*D);
+  * P == 1 moves no bytes at all (the reference still makes two copies).
+The collective itself is `torch.distributed.all_to_all_single` == RCCL over xGMI on ROCm.
+"""
+from typing import Any, Tuple
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from ..kernels.attention import get_block_backend
+
+
+def seq_major_empty(B, S, H, D, dtype, device):
+    """A (B,S,H,D) view over an (S,B,H,D)-contiguous buffer: the layout both all-to-all directions
+    exchange without a copy."""
+    return torch.empty((S, B, H, D), dtype=dtype, device=device).transpose(0, 1)
+
+
+def is_seq_major(x: Tensor) -> bool:
+    B, S, H, D = x.shape
+    return x.transpose(0, 1).is_contiguous()
+
+
+def _copy_rows(dst: Tensor, src: Tensor, row_elems: int, sizes, dst_strides, src_strides):
+    """dst/src: base tensors; strides in elements.  Device tensors -> usp_copy_rows; host tensors
+    (gloo orchestration tests) -> as_strided copy."""
+    es = src.element_size()
+    if src.is_cuda:
+        get_block_backend().copy_rows(dst, src, row_elems * es, list(sizes),
+                                      [s * es for s in dst_strides], [s * es for s in src_strides])
+    else:
+        d = torch.as_strided(dst, list(sizes) + [row_elems], list(dst_strides) + [1],
+                             dst.storage_offset())
+        s = torch.as_strided(src, list(sizes) + [row_elems], list(src_strides) + [1],
+                             src.storage_offset())
+        d.copy_(s)
+
+
+def _exchange(send: Tensor, group, use_sync: bool) -> Tensor:
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv, send, group=group)
+    if use_sync and send.is_cuda:
+        torch.cuda.synchronize()
+    return recv
+
+
+def heads_to_seq(x: Tensor, group, use_sync: bool = False, contiguous: bool = False) -> Tensor:
+    """scatter heads / gather sequence: (B, S/P, H, D) -> (B, S, H/P, D)  (all_to_all.py:36-67)."""
+    P = dist.get_world_size(group)
+    if P == 1:
+        return x
+    B, Sl, H, D = x.shape
+    assert H % P == 0, f"head count {H} not divisible by ulysses degree {P}"
+    hp = H // P
+    if x.stride(3) != 1 or x.stride(2) != D:
+        x = x.contiguous()
+    send = torch.empty((P, Sl, B, hp, D), dtype=x.dtype, device=x.device)
+    _copy_rows(send, x, hp * D, (P, Sl, B), (Sl * B * hp * D, B * hp * D, hp * D),
+               (hp * D, x.stride(1), x.stride(0)))
+    recv = _exchange(send, group, use_sync)
+    out = recv.view(P * Sl, B, hp, D).transpose(0, 1)
+    return out.contiguous() if contiguous else out
+
+
+def seq_to_heads(x: Tensor, group, use_sync: bool = False) -> Tensor:
+    """scatter sequence / gather heads: (B, S, H/P, D) -> (B, S/P, H, D)  (all_to_all.py:69-102)."""
+    P = dist.get_world_size(group)
+    if P == 1:
+        return x
+    B, S, hp, D = x.shape
+    assert S % P == 0, f"sequence {S} not divisible by ulysses degree {P}"
+    Sl, H = S // P, hp * P
+    if is_seq_major(x):
+        send = x.transpose(0, 1)                       # already (S,B,hp,D) contiguous: no copy
+    else:
+        if x.stride(3) != 1 or x.stride(2) != D:
+            x = x.contiguous()
+        send = torch.empty((S, B, hp, D), dtype=x.dtype, device=x.device)
+        _copy_rows(send, x, hp * D, (S, B), (B * hp * D, hp * D), (x.stride(1), x.stride(0)))
+    recv = _exchange(send.view(P, Sl, B, hp, D), group, use_sync)
+    out = torch.empty((B, Sl, H, D), dtype=x.dtype, device=x.device)
+    _copy_rows(out, recv, hp * D, (P, Sl, B), (hp * D, H * D, Sl * H * D),
+               (Sl * B * hp * D, B * hp * D, hp * D))
+    return out
+
+
+def all_to_all_4D(input: torch.Tensor, scatter_idx: int = 2, gather_idx: int = 1, group=None,
+                  use_sync: bool = False) -> torch.Tensor:
+    """Public function with the reference's semantics (contiguous result)."""
+    assert input.dim() == 4, f"input must be 4D tensor, got {input.dim()} and shape {input.shape}"
+    if scatter_idx == 2 and gather_idx == 1:
+        return heads_to_seq(input, group, use_sync, contiguous=True)
+    if scatter_idx == 1 and gather_idx == 2:
+        return seq_to_heads(input, group, use_sync)
+    raise RuntimeError("scatter_idx must be 1 or 2 and gather_idx must be 1 or 2")
+
+
+class SeqAllToAll4D(torch.autograd.Function):
+    """all_to_all.py:105-134: forward = the exchange, backward = the inverse exchange."""
+
+    @staticmethod
+    def forward(ctx: Any, group, input: Tensor, scatter_idx: int, gather_idx: int,
+                use_sync: bool = False) -> Tensor:
+        ctx.group = group
+        ctx.scatter_idx = scatter_idx
+        ctx.gather_idx = gather_idx
+        ctx.use_sync = use_sync
+        if scatter_idx == 2 and gather_idx == 1:
+            return heads_to_seq(input, group, use_sync)
+        if scatter_idx == 1 and gather_idx == 2:
+            return seq_to_heads(input, group, use_sync)
+        raise RuntimeError("scatter_idx must be 1 or 2 and gather_idx must be 1 or 2")
+
+    @staticmethod
+    def backward(ctx: Any, *grad_output: Tensor) -> Tuple[None, Tensor, None, None, None]:
+        return (None,
+                SeqAllToAll4D.apply(ctx.group, grad_output[0], ctx.gather_idx, ctx.scatter_idx,
+                                    ctx.use_sync),
+                None, None, None)

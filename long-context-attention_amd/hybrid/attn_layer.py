@@ -1,0 +1,73 @@
+"""LongContextAttention: same surface as yunchang/hybrid/attn_layer.py:14-161.
+
+forward = Ulysses head all-to-all of q, k, v (attn_layer.py:111-119) -> ring attention over the
+ring group (:132-147) -> all-to-all of the output back to sequence sharding (:156-158).
+"""
+from typing import Any
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from ..comm.all_to_all import SeqAllToAll4D
+from ..globals import PROCESS_GROUP
+from ..kernels import AttnType
+from .utils import RING_IMPL_DICT
+
+
+class LongContextAttention(torch.nn.Module):
+    """Unified sequence parallel attention (ulysses x ring).
+
+    Arguments (identical to the reference):
+        scatter_idx (int): scatter_idx for all2all comm (2 = heads)
+        gather_idx (int): gather_idx for all2all comm (1 = sequence)
+        ring_impl_type (str): key of RING_IMPL_DICT ("basic" | "zigzag")
+        use_pack_qkv (bool): accepted for compatibility; q, k, v are always exchanged separately
+            (the reference's packed branch is dead code: `.continous()` typo at attn_layer.py:88,
+            and it cannot express GQA)
+        use_sync (bool): synchronise the device after each all-to-all
+        attn_type (AttnType): any dense type; all are served by the gfx950 kernel
+    """
+
+    def __init__(self, scatter_idx: int = 2, gather_idx: int = 1, ring_impl_type: str = "basic",
+                 use_pack_qkv: bool = False, use_sync: bool = False,
+                 attn_type: AttnType = AttnType.FA, attn_processor: torch.nn.Module = None) -> None:
+        super(LongContextAttention, self).__init__()
+        self.ring_pg = PROCESS_GROUP.RING_PG
+        self.ulysses_pg = PROCESS_GROUP.ULYSSES_PG
+        self.use_pack_qkv = use_pack_qkv
+        self.use_sync = use_sync
+        self.attn_type = attn_type
+        assert (
+            self.ulysses_pg is not None or self.ring_pg is not None
+        ), f"use set_seq_parallel_pg() first. Now ulysses pg {self.ulysses_pg} and ring pg {self.ring_pg}"
+        self.scatter_idx = scatter_idx
+        self.gather_idx = gather_idx
+        self.attn_processor = attn_processor
+        self.ring_attn_fn = RING_IMPL_DICT[ring_impl_type]
+
+    def forward(self, query: Tensor, key: Tensor, value: Tensor, dropout_p=0.0, softmax_scale=None,
+                causal=False, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+                deterministic=False, return_attn_probs=False, *args: Any) -> Tensor:
+        """query (bs, seq_len/N, head_cnt, head_size); key/value (bs, seq_len/N, kv_head_cnt,
+        head_size) -> context (bs, seq_len/N, head_cnt, head_size)."""
+        # (bs, seq_len/N, head_cnt, head_size) -> (bs, seq_len, head_cnt/N, head_size)
+        query_layer = SeqAllToAll4D.apply(self.ulysses_pg, query, self.scatter_idx, self.gather_idx,
+                                          self.use_sync)
+        key_layer = SeqAllToAll4D.apply(self.ulysses_pg, key, self.scatter_idx, self.gather_idx,
+                                        self.use_sync)
+        value_layer = SeqAllToAll4D.apply(self.ulysses_pg, value, self.scatter_idx, self.gather_idx,
+                                          self.use_sync)
+        out = self.ring_attn_fn(
+            query_layer, key_layer, value_layer, dropout_p=dropout_p, softmax_scale=softmax_scale,
+            causal=causal, window_size=window_size, softcap=softcap, alibi_slopes=alibi_slopes,
+            deterministic=deterministic, return_attn_probs=return_attn_probs, group=self.ring_pg,
+            attn_type=self.attn_type, attn_processor=self.attn_processor)
+        if type(out) == tuple:
+            context_layer, _, _ = out
+        else:
+            context_layer = out
+        # (bs, seq_len, head_cnt/N, head_size) -> (bs, seq_len/N, head_cnt, head_size)
+        output = SeqAllToAll4D.apply(self.ulysses_pg, context_layer, self.gather_idx,
+                                     self.scatter_idx, self.use_sync)
+        return output

@@ -1,0 +1,149 @@
+"""Block attention kernels of the USP path, backed by libusp_hip.so.
+
+Mirrors the callables yunchang/kernels/attention.py exposes to the ring schedules:
+  * hip_attn_forward  <->  pytorch_attn_forward(op_type="efficient") (attention.py:44-136) /
+                           flash_attn_forward (:165-202)            [the `fwd-only` contract]
+  * hip_attn_backward <->  flash_attn_backward (:205-250)           [the `bwd-only` contract;
+                           pytorch_attn_backward (:138-159) raises in the reference]
+and defines the richer internal seam (`BlockBackend`) the ring schedules of THIS package use, in
+which the LSE merge (ring/utils.py:10-51) and the fp32 gradient accumulation
+(zigzag_ring_flash_attn.py:147-170) are fused into the kernels.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _C
+
+
+class HipBlockBackend:
+    """The device backend: thin adapter over the C ABI (include/usp_hip.h)."""
+
+    name = "hip"
+
+    def fwd(self, q, k, v, softmax_scale, causal, lse, out=None, acc=None, merge_in=False,
+            final_begin=0, final_end=None):
+        _C.flash_fwd(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end)
+
+    def delta(self, dout, out, delta):
+        _C.bwd_delta(dout, out, delta)
+
+    def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
+            accum_dk=False, accum_dv=False):
+        _C.flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq,
+                     accum_dk, accum_dv)
+
+    def merge(self, acc, lse, blk_out, blk_lse, first):
+        _C.lse_merge(acc, lse, blk_out, blk_lse, first)
+
+    def cast(self, dst16, src32):
+        _C.cast_from_f32(dst16, src32)
+
+    def add(self, dst, a, b):
+        _C.add_f32(dst, a, b)
+
+    def copy_rows(self, dst, src, row_bytes, sizes, dst_strides, src_strides):
+        _C.copy_rows(dst, src, row_bytes, sizes, dst_strides, src_strides)
+
+
+_BACKEND = HipBlockBackend()
+
+
+def get_block_backend():
+    return _BACKEND
+
+
+def set_block_backend(backend):
+    """Replace the block backend.  Exists for the CPU/gloo orchestration tests, which plug the
+    CPU oracle in here (tests/oracle_backend.py); the package itself only ever installs
+    HipBlockBackend and has no CPU path.  Returns the previous backend."""
+    global _BACKEND
+    prev, _BACKEND = _BACKEND, backend
+    return prev
+
+
+def _default_scale(q, softmax_scale):
+    return q.shape[-1] ** (-0.5) if softmax_scale is None else softmax_scale
+
+
+def _check_plain(dropout_p, window_size, softcap, alibi_slopes):
+    # the hot path only ever passes these defaults (zigzag_ring_flash_attn.py:207,
+    # hybrid/attn_layer.py:132-147); anything else is outside this package's scope.
+    if dropout_p not in (0, 0.0):
+        raise NotImplementedError("dropout_p != 0 is not supported by the HIP attention kernel")
+    if window_size is not None and tuple(window_size) != (-1, -1):
+        raise NotImplementedError("sliding-window attention is not supported by the HIP attention kernel")
+    if softcap not in (None, 0, 0.0):
+        raise NotImplementedError("softcap is not supported by the HIP attention kernel")
+    if alibi_slopes is not None:
+        raise NotImplementedError("alibi_slopes is not supported by the HIP attention kernel")
+
+
+def hip_attn_forward(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+                     softcap=None, alibi_slopes=None, return_softmax=False):
+    """`fwd-only` contract of the reference selector (kernels/__init__.py:63-65; call sites
+    zigzag_ring_flash_attn.py:29-43, ring_flash_attn.py:36-48):
+        (block_out (B,Sq,Hq,D) q.dtype, block_lse (B,Hq,Sq) fp32)
+    Unlike the TORCH_* wrappers (attention.py:135) the LSE is NOT rounded to q.dtype."""
+    _check_plain(dropout_p, window_size, softcap, alibi_slopes)
+    B, Sq, Hq, D = q.shape
+    out = torch.empty((B, Sq, Hq, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
+    get_block_backend().fwd(q, k, v, _default_scale(q, softmax_scale), bool(causal), lse, out=out)
+    return out, lse
+
+
+def hip_attn_backward(dout, q, k, v, out, softmax_lse, block_dq_buffer, block_dk_buffer,
+                      block_dv_buffer, dropout_p=0.0, softmax_scale=None, bwd_causal=False,
+                      window_size=(-1, -1), softcap=None, alibi_slopes=None, deterministic=False,
+                      rng_state=None, *args, **kwargs):
+    """`bwd-only` contract (argument order of kernels/attention.py:205-206): writes dq/dk/dv into
+    the caller's (possibly sliced, 16-bit) buffers; `out`/`softmax_lse` are the GLOBAL rows' values
+    (zigzag_ring_flash_attn.py:115-137)."""
+    _check_plain(dropout_p, window_size, softcap, alibi_slopes)
+    be = get_block_backend()
+    B, Sq, Hq, D = q.shape
+    dev = q.device
+    delta = torch.empty((B, Hq, Sq), dtype=torch.float32, device=dev)
+    be.delta(dout, out, delta)
+    lse = softmax_lse if softmax_lse.dtype == torch.float32 else softmax_lse.float()
+    if lse.stride(-1) != 1:
+        lse = lse.contiguous()
+    dq = torch.empty(q.shape, dtype=torch.float32, device=dev)
+    dk = torch.empty(k.shape, dtype=torch.float32, device=dev)
+    dv = torch.empty(v.shape, dtype=torch.float32, device=dev)
+    be.bwd(dout, q, k, v, lse, delta, dq, dk, dv, _default_scale(q, softmax_scale), bool(bwd_causal))
+    for src, dst in ((dq, block_dq_buffer), (dk, block_dk_buffer), (dv, block_dv_buffer)):
+        if dst.is_contiguous() or (dst.dim() == 4 and dst[0].is_contiguous()):
+            be.cast(dst, src)
+        else:
+            tmp = torch.empty(src.shape, dtype=dst.dtype, device=dev)
+            be.cast(tmp, src)
+            dst.copy_(tmp)
+
+
+class _HipAttnFunc(torch.autograd.Function):
+    """`fwd-bwd` stage: an autograd-aware single-device attention (what UlyssesAttention would use,
+    yunchang/ulysses/attn_layer.py:48,101-113)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, softmax_scale, causal):
+        scale = _default_scale(q, softmax_scale)
+        out, lse = hip_attn_forward(q, k, v, softmax_scale=scale, causal=causal)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.scale, ctx.causal = scale, bool(causal)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        hip_attn_backward(dout, q, k, v, out, lse, dq, dk, dv, 0.0, ctx.scale, ctx.causal)
+        return dq, dk, dv, None, None
+
+
+def hip_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+                  softcap=0.0, alibi_slopes=None, deterministic=False, return_attn_probs=False,
+                  *args, **kwargs):
+    _check_plain(dropout_p, window_size, softcap, alibi_slopes)
+    return _HipAttnFunc.apply(q, k, v, softmax_scale, causal)

@@ -1,0 +1,159 @@
+"""Basic (contiguous-layout) ring attention: same surface as yunchang/ring/ring_flash_attn.py.
+
+Block structure as the reference (:29-56 forward, :93-143 backward): ring step s sees the K/V of
+ring rank r-s; under causal only steps <= r compute and only step 0 is causal.  At ring degree 1
+(BASELINE configs C2, C3) this is one kernel call.  The MI355X-first differences are those listed
+in zigzag_ring_flash_attn.py (fused merge, fp32 in-place gradient accumulation, K/V relay on a
+side stream); additionally dq is returned in q.dtype (the reference hard-codes bfloat16 at :147).
+"""
+import torch
+import torch.distributed as dist
+
+from ..comm.all_to_all import seq_major_empty
+from ..kernels import AttnType
+from ..kernels.attention import get_block_backend
+from .utils import KVRelay, RingComm
+from .zigzag_ring_flash_attn import _cast, _check_hot_path_args
+
+
+def ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, causal=True,
+                            window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
+                            attn_type: AttnType = AttnType.HIP, attn_processor=None):
+    be = get_block_backend()
+    P = dist.get_world_size(process_group)
+    r = dist.get_rank(process_group)
+    B, S, H, D = q.shape
+    dev = q.device
+    out = seq_major_empty(B, S, H, D, q.dtype, dev)
+    lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+    last_compute = r if causal else P - 1
+    acc = torch.empty((B, S, H, D), dtype=torch.float32, device=dev) if last_compute > 0 else None
+
+    relay = KVRelay(process_group, k, v)
+    for step in range(P):
+        kk, vv = relay.get(step)
+        if not causal or step <= r:
+            fe = S if step == last_compute else 0
+            be.fwd(q, kk, vv, softmax_scale, bool(causal and step == 0), lse, out, acc, step > 0, 0, fe)
+    relay.finish()
+    return out, lse
+
+
+def ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, softmax_scale,
+                             dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
+                             alibi_slopes=None, deterministic=False,
+                             attn_type: AttnType = AttnType.HIP):
+    be = get_block_backend()
+    P = dist.get_world_size(process_group)
+    r = dist.get_rank(process_group)
+    B, S, H, D = q.shape
+    dev = q.device
+    f32 = torch.float32
+    delta = torch.empty((B, H, S), dtype=f32, device=dev)
+    be.delta(dout, out, delta)
+    dq_acc = torch.empty((B, S, H, D), dtype=f32, device=dev)
+    dk_blk = dv_blk = None
+    if P > 1:
+        dk_blk = torch.empty(k.shape, dtype=f32, device=dev)
+        dv_blk = torch.empty(v.shape, dtype=f32, device=dev)
+
+    relay = KVRelay(process_group, k, v)
+    d_comm = None
+    dk_acc = dv_acc = next_dk = next_dv = None
+    for step in range(P):
+        kk, vv = relay.get(step)
+        if step == 0:
+            dk_acc = torch.empty(k.shape, dtype=f32, device=dev)
+            dv_acc = torch.empty(v.shape, dtype=f32, device=dev)
+            be.bwd(dout, q, kk, vv, softmax_lse, delta, dq_acc, dk_acc, dv_acc, softmax_scale,
+                   bool(causal))
+        elif not causal or step <= r:
+            be.bwd(dout, q, kk, vv, softmax_lse, delta, dq_acc, dk_blk, dv_blk, softmax_scale, False,
+                   accum_dq=True)
+            d_comm.wait()
+            dk_acc, dv_acc = next_dk, next_dv
+            be.add(dk_acc, dk_acc, dk_blk)
+            be.add(dv_acc, dv_acc, dv_blk)
+        else:
+            d_comm.wait()
+            dk_acc, dv_acc = next_dk, next_dv
+        if P > 1:
+            d_comm = RingComm(process_group)
+            next_dk = d_comm.send_recv(dk_acc)
+            next_dv = d_comm.send_recv(dv_acc)
+            d_comm.commit()
+    if P > 1:
+        d_comm.wait()
+        dk_acc, dv_acc = next_dk, next_dv
+    relay.finish()
+
+    dq = seq_major_empty(B, S, H, D, q.dtype, dev)
+    dk = seq_major_empty(*k.shape, k.dtype, dev)
+    dv = seq_major_empty(*v.shape, v.dtype, dev)
+    _cast(be, dq, dq_acc)
+    _cast(be, dk, dk_acc)
+    _cast(be, dv, dv_acc)
+    return dq, dk, dv
+
+
+class RingFlashAttnFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                deterministic, return_softmax, group, attn_type, attn_processor):
+        if softmax_scale is None:
+            softmax_scale = q.shape[-1] ** (-0.5)
+        assert alibi_slopes is None
+        _check_hot_path_args(dropout_p, window_size, softcap)
+        out, softmax_lse = ring_flash_attn_forward(
+            group, q, k, v, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
+            window_size=window_size, softcap=softcap, alibi_slopes=alibi_slopes, deterministic=False,
+            attn_type=attn_type, attn_processor=attn_processor)
+        ctx.save_for_backward(q, k, v, out, softmax_lse)
+        ctx.dropout_p = dropout_p
+        ctx.softmax_scale = softmax_scale
+        ctx.causal = causal
+        ctx.window_size = window_size
+        ctx.softcap = softcap
+        ctx.alibi_slopes = alibi_slopes
+        ctx.deterministic = deterministic
+        ctx.group = group
+        ctx.attn_type = attn_type
+        ctx.attn_processor = attn_processor
+        return out if not return_softmax else (out, softmax_lse, None)
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        q, k, v, out, softmax_lse = ctx.saved_tensors
+        dq, dk, dv = ring_flash_attn_backward(
+            ctx.group, dout, q, k, v, out, softmax_lse, softmax_scale=ctx.softmax_scale,
+            dropout_p=ctx.dropout_p, causal=ctx.causal, window_size=ctx.window_size,
+            softcap=ctx.softcap, alibi_slopes=ctx.alibi_slopes, deterministic=ctx.deterministic,
+            attn_type=ctx.attn_type)
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None, None, None
+
+
+def ring_flash_attn_qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=False,
+                                   window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+                                   deterministic=False, return_attn_probs=False, group=None,
+                                   attn_type: AttnType = AttnType.HIP):
+    return RingFlashAttnFunc.apply(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p, softmax_scale,
+                                   causal, window_size, softcap, alibi_slopes, deterministic,
+                                   return_attn_probs, group, attn_type, None)
+
+
+def ring_flash_attn_kvpacked_func(q, kv, dropout_p=0.0, softmax_scale=None, causal=False,
+                                  window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+                                  deterministic=False, return_attn_probs=False, group=None,
+                                  attn_type: AttnType = AttnType.HIP):
+    return RingFlashAttnFunc.apply(q, kv[:, :, 0], kv[:, :, 1], dropout_p, softmax_scale, causal,
+                                   window_size, softcap, alibi_slopes, deterministic,
+                                   return_attn_probs, group, attn_type, None)
+
+
+def ring_flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False,
+                         window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
+                         return_attn_probs=False, group=None, attn_type: AttnType = AttnType.HIP,
+                         attn_processor=None):
+    return RingFlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap,
+                                   alibi_slopes, deterministic, return_attn_probs, group, attn_type,
+                                   attn_processor)

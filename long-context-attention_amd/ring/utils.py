@@ -1,0 +1,156 @@
+"""Ring plumbing of the USP path: same surface as yunchang/ring/utils.py (RingComm :118-161,
+update_out_and_lse :10-51), plus the side-stream relay this package's schedules use.
+
+Transport is torch.distributed point-to-point (`batch_isend_irecv` == grouped RCCL send/recv over
+xGMI on ROCm; gloo on CPU for the orchestration tests).
+"""
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from ..kernels.attention import get_block_backend
+
+__all__ = ["update_out_and_lse", "RingComm", "KVRelay"]
+
+
+def update_out_and_lse(out: Optional[torch.Tensor], lse: Optional[torch.Tensor],
+                       block_out: torch.Tensor, block_lse: torch.Tensor, slice_=None
+                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """ring/utils.py:30-51 as ONE kernel (usp_lse_merge) instead of ~6 elementwise passes.
+    out (B,S,H,D) fp32, lse (B,S,H,1) fp32 [the reference's layout], block_lse (B,H,Sb).
+    The schedules of this package do not call this (the merge is fused into the attention
+    kernel's epilogue); it is kept for callers of the reference's helper."""
+    be = get_block_backend()
+    blk_lse = block_lse if block_lse.dtype == torch.float32 else block_lse.float()
+    if blk_lse.stride(-1) != 1:
+        blk_lse = blk_lse.contiguous()
+    if out is None:
+        if slice_ is not None:
+            raise RuntimeError("first update_out_and_lse should not pass slice_ args")
+        B, S, H, D = block_out.shape
+        out = torch.empty((B, S, H, D), dtype=torch.float32, device=block_out.device)
+        lse_bhs = torch.empty((B, H, S), dtype=torch.float32, device=block_out.device)
+        be.merge(out, lse_bhs, block_out, blk_lse, True)
+        return out, lse_bhs.transpose(1, 2).unsqueeze(-1)
+    lse_bhs = lse.squeeze(-1).transpose(1, 2)          # (B,H,S) view, unit seq stride if we made it
+    if lse_bhs.stride(-1) != 1:
+        lse_c = lse_bhs.contiguous()
+    else:
+        lse_c = lse_bhs
+    o_view, l_view = out, lse_c
+    if slice_ is not None:
+        o_view = out[slice_]
+        l_view = lse_c[:, :, slice_[1]]
+    be.merge(o_view, l_view, block_out, blk_lse, False)
+    if lse_c is not lse_bhs:
+        lse = lse_c.transpose(1, 2).unsqueeze(-1)
+    return out, lse
+
+
+class RingComm:
+    """ring/utils.py:118-161.  send_recv queues an isend to ring rank+1 and an irecv from ring
+    rank-1; commit posts them as one batch; wait blocks (stream-wise on a GPU) until done."""
+
+    def __init__(self, process_group: dist.ProcessGroup):
+        self._process_group = process_group
+        self._ops = []
+        self.rank = dist.get_rank(self._process_group)
+        self.world_size = dist.get_world_size(self._process_group)
+        self._reqs = None
+        self.send_rank = (self.rank + 1) % self.world_size
+        self.recv_rank = (self.rank - 1) % self.world_size
+        if process_group is not None:
+            self.send_rank = dist.get_global_rank(self._process_group, self.send_rank)
+            self.recv_rank = dist.get_global_rank(self._process_group, self.recv_rank)
+
+    def send_recv(self, to_send: torch.Tensor, recv_tensor: Optional[torch.Tensor] = None) -> torch.Tensor:
+        res = torch.empty_like(to_send) if recv_tensor is None else recv_tensor
+        self._ops.append(dist.P2POp(dist.isend, to_send, self.send_rank, group=self._process_group))
+        self._ops.append(dist.P2POp(dist.irecv, res, self.recv_rank, group=self._process_group))
+        return res
+
+    def commit(self):
+        if self._reqs is not None:
+            raise RuntimeError("commit called twice")
+        self._reqs = dist.batch_isend_irecv(self._ops)
+
+    def wait(self):
+        if self._reqs is None:
+            raise RuntimeError("wait called before commit")
+        for req in self._reqs:
+            req.wait()
+        self._reqs = None
+        self._ops = []
+
+
+class KVRelay:
+    """Relays K and V around the ring AHEAD of the attention kernels.
+
+    The reference posts the transfer for step s+1 from the compute stream at the top of step s
+    (zigzag_ring_flash_attn.py:46-49), so RCCL only starts it once attention(s-1) has finished.
+    Here the whole relay chain (P-1 hops, one receive slot per hop: HBM is not the constraint on a
+    288 GB part) is queued up-front on a side HIP stream; hop s+1 starts the moment hop s has
+    landed, independent of the attention kernels, and the compute stream only waits on the event of
+    the hop it is about to consume.  On host tensors (gloo tests) the same chain runs inline.
+    """
+
+    def __init__(self, process_group, k: torch.Tensor, v: torch.Tensor):
+        self.P = dist.get_world_size(process_group)
+        self.slots: List[Tuple[torch.Tensor, torch.Tensor]] = [(k, v)]
+        self.events = [None]
+        self._stream = None
+        if self.P == 1:
+            return
+        cuda = k.is_cuda
+        if cuda:
+            self._main = torch.cuda.current_stream()
+            self._stream = _side_stream(k.device)
+            self._stream.wait_stream(self._main)          # k, v are produced on the compute stream
+        ctx = torch.cuda.stream(self._stream) if cuda else _NullCtx()
+        with ctx:
+            cur_k, cur_v = k, v
+            for _ in range(self.P - 1):
+                comm = RingComm(process_group)
+                nk = comm.send_recv(cur_k)
+                nv = comm.send_recv(cur_v)
+                comm.commit()
+                comm.wait()
+                ev = None
+                if cuda:
+                    ev = torch.cuda.Event()
+                    ev.record(self._stream)
+                self.slots.append((nk, nv))
+                self.events.append(ev)
+                cur_k, cur_v = nk, nv
+
+    def get(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """K, V held after `step` hops; makes the current stream wait for that hop."""
+        ev = self.events[step]
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+        return self.slots[step]
+
+    def finish(self):
+        """Order the side stream before anything the compute stream does next, so buffers handed
+        back to the caching allocator cannot be reused while a hop still reads or writes them."""
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device) -> "torch.cuda.Stream":
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]

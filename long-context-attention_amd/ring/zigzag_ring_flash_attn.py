@@ -1,0 +1,231 @@
+"""Zigzag ring attention: same surface as yunchang/ring/zigzag_ring_flash_attn.py.
+
+Schedule (identical block structure to the reference, :45-72 forward / :139-179 backward): with
+the local sequence = [chunk r | chunk 2P-1-r] of length 2c, ring step `s` sees the K/V of ring rank
+r-s and computes
+    s == 0 : causal  q[0:2c] x k[0:2c]
+    s <= r : full    q[0:2c] x k[0:c]
+    s >  r : full    q[c:2c] x k[0:2c]          (only rows c: are updated)
+so every step costs 2c^2 score entries on every rank.
+
+MI355X-first differences (results identical up to fp32 rounding order):
+  * the LSE merge (`update_out_and_lse`, ring/utils.py:10-51) is fused into the attention kernel's
+    epilogue: the block result never makes a 16-bit round trip through HBM, the running output is
+    fp32 (`acc`) and the LSE stays fp32 (the reference TORCH_* path rounds it to bf16,
+    kernels/attention.py:135); rows are emitted in 16-bit exactly once, by the step that
+    finalises them (rows [0,c) at step r, rows [c,2c) at step P-1);
+  * the backward kernels accumulate dQ in place in fp32 and emit fp32 dK/dV blocks, replacing the
+    16-bit dq/dk/dv buffers + fp32 adds of :115-170;
+  * K/V are relayed ahead of the kernels on a side HIP stream (ring/utils.py KVRelay).
+"""
+import torch
+import torch.distributed as dist
+
+from ..comm.all_to_all import seq_major_empty
+from ..kernels import AttnType
+from ..kernels.attention import get_block_backend
+from .utils import KVRelay, RingComm
+
+
+
+def zigzag_fwd_step(be, r, P, step, q, kk, vv, softmax_scale, lse, out, acc):
+    """One ring step of the forward on ring rank `r` of `P`, given the K/V that arrived after
+    `step` hops.  Pure schedule logic (no communication): also driven by the single-GPU tests,
+    which emulate the ring with virtual ranks."""
+    S2 = q.shape[1]
+    c = S2 // 2
+    last = step == P - 1
+    if step == 0:                                   # zigzag_ring_flash_attn.py:51-53
+        fe = S2 if last else (c if r == 0 else 0)
+        be.fwd(q, kk, vv, softmax_scale, True, lse, out, acc, False, 0, fe)
+    elif step <= r:                                 # :54-58
+        fe = S2 if last else (c if step == r else 0)
+        be.fwd(q, kk[:, :c], vv[:, :c], softmax_scale, False, lse, out, acc, True, 0, fe)
+    else:                                           # :59-67
+        be.fwd(q[:, c:], kk, vv, softmax_scale, False, lse[:, :, c:], out[:, c:], acc[:, c:], True,
+               0, c if last else 0)
+
+
+def zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, dk_dst,
+                     dv_dst):
+    """Block backward of ring step `step`: dq accumulates in place into dq_acc (fp32), the dK/dV
+    block is written to dk_dst/dv_dst (fp32; at step 0 these ARE the travelling accumulators)."""
+    c = q.shape[1] // 2
+    if step == 0:                                   # zigzag_ring_flash_attn.py:145-149
+        be.bwd(dout, q, kk, vv, lse, delta, dq_acc, dk_dst, dv_dst, softmax_scale, True)
+    elif step <= r:                                 # :151-155
+        be.bwd(dout, q, kk[:, :c], vv[:, :c], lse, delta, dq_acc, dk_dst[:, :c], dv_dst[:, :c],
+               softmax_scale, False, accum_dq=True)
+    else:                                           # :156-159
+        be.bwd(dout[:, c:], q[:, c:], kk, vv, lse[:, :, c:], delta[:, :, c:], dq_acc[:, c:], dk_dst,
+               dv_dst, softmax_scale, False, accum_dq=True)
+
+
+def zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk):
+    """Add this step's dK/dV block into the accumulators that just arrived (:161-170)."""
+    if step <= r:
+        be.add(dk_acc[:, :c], dk_acc[:, :c], dk_blk[:, :c])
+        be.add(dv_acc[:, :c], dv_acc[:, :c], dv_blk[:, :c])
+    else:
+        be.add(dk_acc, dk_acc, dk_blk)
+        be.add(dv_acc, dv_acc, dv_blk)
+
+
+def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, causal=True,
+                                   window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+                                   deterministic=False, attn_type: AttnType = AttnType.HIP):
+    assert causal == True, "zigzag ring is meaningless for causal=False"
+    be = get_block_backend()
+    P = dist.get_world_size(process_group)
+    r = dist.get_rank(process_group)
+    B, S2, H, D = q.shape
+    assert S2 % 2 == 0, "zigzag layout needs an even local sequence length"
+    c = S2 // 2
+    dev = q.device
+    out = seq_major_empty(B, S2, H, D, q.dtype, dev)
+    lse = torch.empty((B, H, S2), dtype=torch.float32, device=dev)
+    acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev) if P > 1 else None
+
+    relay = KVRelay(process_group, k, v)
+    for step in range(P):
+        kk, vv = relay.get(step)
+        zigzag_fwd_step(be, r, P, step, q, kk, vv, softmax_scale, lse, out, acc)
+    relay.finish()
+    return out, lse
+
+
+def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, softmax_scale,
+                                    dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
+                                    alibi_slopes=None, deterministic=False,
+                                    attn_type: AttnType = AttnType.HIP):
+    assert causal == True, "zigzag ring is meaningless for causal=False"
+    be = get_block_backend()
+    P = dist.get_world_size(process_group)
+    r = dist.get_rank(process_group)
+    B, S2, H, D = q.shape
+    c = S2 // 2
+    dev = q.device
+    f32 = torch.float32
+    lse = softmax_lse
+    delta = torch.empty((B, H, S2), dtype=f32, device=dev)
+    be.delta(dout, out, delta)
+    dq_acc = torch.empty((B, S2, H, D), dtype=f32, device=dev)
+    dk_blk = dv_blk = None
+    if P > 1:
+        dk_blk = torch.empty(k.shape, dtype=f32, device=dev)
+        dv_blk = torch.empty(v.shape, dtype=f32, device=dev)
+
+    relay = KVRelay(process_group, k, v)
+    d_comm = None
+    dk_acc = dv_acc = next_dk = next_dv = None
+    for step in range(P):
+        kk, vv = relay.get(step)
+        if step == 0:
+            dk_acc = torch.empty(k.shape, dtype=f32, device=dev)
+            dv_acc = torch.empty(v.shape, dtype=f32, device=dev)
+            zigzag_bwd_block(be, r, P, 0, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, dk_acc,
+                             dv_acc)
+        else:
+            zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc,
+                             dk_blk, dv_blk)
+            d_comm.wait()                       # the travelling accumulators of step-1 have landed
+            dk_acc, dv_acc = next_dk, next_dv
+            zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk)
+        if P > 1:
+            d_comm = RingComm(process_group)
+            next_dk = d_comm.send_recv(dk_acc)
+            next_dv = d_comm.send_recv(dv_acc)
+            d_comm.commit()
+    if P > 1:
+        d_comm.wait()
+        dk_acc, dv_acc = next_dk, next_dv
+    relay.finish()
+
+    dq = seq_major_empty(B, S2, H, D, q.dtype, dev)
+    dk = seq_major_empty(*k.shape, k.dtype, dev)
+    dv = seq_major_empty(*v.shape, v.dtype, dev)
+    _cast(be, dq, dq_acc)
+    _cast(be, dk, dk_acc)
+    _cast(be, dv, dv_acc)
+    return dq, dk, dv
+
+
+def _cast(be, dst16, src32):
+    """fp32 (B,S,H,D) contiguous -> 16-bit seq-major view."""
+    if dst16.shape[0] == 1:
+        be.cast(dst16, src32)
+    else:   # seq-major dst is not batch-sliceable: cast contiguous, then one strided copy
+        tmp = torch.empty(src32.shape, dtype=dst16.dtype, device=src32.device)
+        be.cast(tmp, src32)
+        dst16.copy_(tmp)
+
+
+class ZigZagRingFlashAttnFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                deterministic, return_softmax, group, attn_type):
+        if softmax_scale is None:
+            softmax_scale = q.shape[-1] ** (-0.5)
+        assert alibi_slopes is None
+        _check_hot_path_args(dropout_p, window_size, softcap)
+        out, softmax_lse = zigzag_ring_flash_attn_forward(
+            group, q, k, v, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
+            window_size=window_size, softcap=softcap, alibi_slopes=alibi_slopes, deterministic=False,
+            attn_type=attn_type)
+        ctx.save_for_backward(q, k, v, out, softmax_lse)
+        ctx.dropout_p = dropout_p
+        ctx.softmax_scale = softmax_scale
+        ctx.causal = causal
+        ctx.window_size = window_size
+        ctx.softcap = softcap
+        ctx.alibi_slopes = alibi_slopes
+        ctx.deterministic = deterministic
+        ctx.group = group
+        ctx.attn_type = attn_type
+        return out if not return_softmax else (out, softmax_lse, None)
+
+    @staticmethod
+    def backward(ctx, dout, *args):
+        q, k, v, out, softmax_lse = ctx.saved_tensors
+        dq, dk, dv = zigzag_ring_flash_attn_backward(
+            ctx.group, dout, q, k, v, out, softmax_lse, softmax_scale=ctx.softmax_scale,
+            dropout_p=ctx.dropout_p, causal=ctx.causal, window_size=ctx.window_size,
+            softcap=ctx.softcap, alibi_slopes=ctx.alibi_slopes, deterministic=ctx.deterministic,
+            attn_type=ctx.attn_type)
+        return dq, dk, dv, None, None, None, None, None, None, None, None, None, None
+
+
+def _check_hot_path_args(dropout_p, window_size, softcap):
+    if dropout_p not in (0, 0.0):
+        raise NotImplementedError("dropout_p != 0 is not supported by the HIP ring attention")
+    if window_size is not None and tuple(window_size) != (-1, -1):
+        raise NotImplementedError("sliding-window attention is not supported by the HIP ring attention")
+    if softcap not in (None, 0, 0.0):
+        raise NotImplementedError("softcap is not supported by the HIP ring attention")
+
+
+def zigzag_ring_flash_attn_qkvpacked_func(qkv, dropout_p=0.0, softmax_scale=None, causal=False,
+                                          window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+                                          deterministic=False, return_attn_probs=False, group=None,
+                                          attn_type: AttnType = AttnType.HIP):
+    return ZigZagRingFlashAttnFunc.apply(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], dropout_p,
+                                         softmax_scale, causal, window_size, softcap, alibi_slopes,
+                                         deterministic, return_attn_probs, group, attn_type)
+
+
+def zigzag_ring_flash_attn_kvpacked_func(q, kv, dropout_p=0.0, softmax_scale=None, causal=False,
+                                         window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+                                         deterministic=False, return_attn_probs=False, group=None,
+                                         attn_type: AttnType = AttnType.HIP):
+    return ZigZagRingFlashAttnFunc.apply(q, kv[:, :, 0], kv[:, :, 1], dropout_p, softmax_scale,
+                                         causal, window_size, softcap, alibi_slopes, deterministic,
+                                         return_attn_probs, group, attn_type)
+
+
+def zigzag_ring_flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False,
+                                window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+                                deterministic=False, return_attn_probs=False, group=None,
+                                attn_type: AttnType = AttnType.HIP, attn_processor=None):
+    return ZigZagRingFlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size,
+                                         softcap, alibi_slopes, deterministic, return_attn_probs,
+                                         group, attn_type)

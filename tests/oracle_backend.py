@@ -1,0 +1,85 @@
+"""TEST-ONLY block backend: implements the BlockBackend seam of yunchang_amd.kernels.attention with
+the CPU oracle (oracle/usp_oracle.py), so the distributed orchestration (all-to-all, ring relay,
+schedule, autograd glue) can run on CPU tensors under gloo.  Never installed by the package."""
+import numpy as np
+import torch
+
+from oracle import usp_oracle as O
+
+
+def _np(t):
+    return t.detach().to(torch.float64).numpy()
+
+
+def _put(dst, arr):
+    dst.copy_(torch.from_numpy(np.ascontiguousarray(arr)).to(dst.dtype))
+
+
+class OracleBlockBackend:
+    name = "oracle"
+
+    def __init__(self):
+        self.calls = []
+
+    def fwd(self, q, k, v, softmax_scale, causal, lse, out=None, acc=None, merge_in=False,
+            final_begin=0, final_end=None):
+        Sq = q.shape[1]
+        fe = Sq if final_end is None else final_end
+        self.calls.append(("fwd", tuple(q.shape), tuple(k.shape), bool(causal), bool(merge_in),
+                           final_begin, fe))
+        bo, bl = O.block_fwd(_np(q), _np(k), _np(v), softmax_scale, causal)      # (B,Sq,H,D), (B,H,Sq)
+        if merge_in:
+            o_run = _np(acc)
+            l_run = np.swapaxes(_np(lse), 1, 2)[..., None]                       # (B,S,H,1)
+            o_new, l_new = O.update_out_and_lse(o_run, l_run, bo, bl)
+            bl = np.swapaxes(l_new[..., 0], 1, 2)
+            bo = o_new
+        _put(lse, bl)
+        if fe > final_begin:
+            _put(out[:, final_begin:fe], bo[:, final_begin:fe])
+        if final_begin > 0:
+            _put(acc[:, :final_begin], bo[:, :final_begin])
+        if fe < Sq:
+            _put(acc[:, fe:], bo[:, fe:])
+
+    def delta(self, dout, out, delta):
+        _put(delta, np.einsum("bshd,bshd->bhs", _np(dout), _np(out)))
+
+    def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
+            accum_dk=False, accum_dv=False):
+        self.calls.append(("bwd", tuple(q.shape), tuple(k.shape), bool(causal)))
+        # block_bwd derives delta from `out`; feed it an `out` whose rowsum(dout*out) equals the
+        # supplied delta is not possible in general, so restate with delta directly:
+        qn, kn, vn, don = _np(q), _np(k), _np(v), _np(dout)
+        ln, dl = _np(lse), _np(delta)
+        B, Sq, Hq, D = qn.shape
+        Sk, Hkv = kn.shape[1], kn.shape[2]
+        g = Hq // Hkv
+        s = O._scores(qn, kn, softmax_scale, causal)
+        fin = np.isfinite(ln)
+        p = np.where(fin[..., None], np.exp(s - np.where(fin, ln, 0.0)[..., None]), 0.0)
+        vv, kk = np.repeat(vn, g, axis=2), np.repeat(kn, g, axis=2)
+        gdv = np.einsum("bhts,bthd->bshd", p, don).reshape(B, Sk, Hkv, g, D).sum(3)
+        dp = np.einsum("bthd,bshd->bhts", don, vv)
+        ds = p * (dp - dl[..., None]) * softmax_scale
+        gdq = np.einsum("bhts,bshd->bthd", ds, kk)
+        gdk = np.einsum("bhts,bthd->bshd", ds, qn).reshape(B, Sk, Hkv, g, D).sum(3)
+        for dst, val, accum in ((dq, gdq, accum_dq), (dk, gdk, accum_dk), (dv, gdv, accum_dv)):
+            _put(dst, val + _np(dst) if accum else val)
+
+    def merge(self, acc, lse, blk_out, blk_lse, first):
+        if first:
+            _put(acc, _np(blk_out)); _put(lse, _np(blk_lse))
+            return
+        l_run = np.swapaxes(_np(lse), 1, 2)[..., None]
+        o_new, l_new = O.update_out_and_lse(_np(acc), l_run, _np(blk_out), _np(blk_lse))
+        _put(acc, o_new); _put(lse, np.swapaxes(l_new[..., 0], 1, 2))
+
+    def cast(self, dst16, src32):
+        dst16.copy_(src32.to(dst16.dtype))
+
+    def add(self, dst, a, b):
+        torch.add(a, b, out=dst)
+
+    def copy_rows(self, dst, src, row_bytes, sizes, dst_strides, src_strides):
+        raise AssertionError("host tensors take the as_strided path in comm/all_to_all.py")
