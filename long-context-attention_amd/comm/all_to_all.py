@@ -53,11 +53,8 @@ def _exchange(send: Tensor, group, use_sync: bool) -> Tensor:
     return recv
 
 
-def heads_to_seq(x: Tensor, group, use_sync: bool = False, contiguous: bool = False) -> Tensor:
-    """scatter heads / gather sequence: (B, S/P, H, D) -> (B, S, H/P, D)  (all_to_all.py:36-67)."""
-    P = dist.get_world_size(group)
-    if P == 1:
-        return x
+def pack_heads(x: Tensor, P: int) -> Tensor:
+    """(B, S/P, H, D) -> send buffer (P, S/P, B, H/P, D): chunk p goes to ulysses rank p."""
     B, Sl, H, D = x.shape
     assert H % P == 0, f"head count {H} not divisible by ulysses degree {P}"
     hp = H // P
@@ -66,8 +63,45 @@ def heads_to_seq(x: Tensor, group, use_sync: bool = False, contiguous: bool = Fa
     send = torch.empty((P, Sl, B, hp, D), dtype=x.dtype, device=x.device)
     _copy_rows(send, x, hp * D, (P, Sl, B), (Sl * B * hp * D, B * hp * D, hp * D),
                (hp * D, x.stride(1), x.stride(0)))
-    recv = _exchange(send, group, use_sync)
-    out = recv.view(P * Sl, B, hp, D).transpose(0, 1)
+    return send
+
+
+def view_seq(recv: Tensor) -> Tensor:
+    """receive buffer (P, S/P, B, H/P, D) -> (B, S, H/P, D) strided view (no copy)."""
+    P, Sl, B, hp, D = recv.shape
+    return recv.view(P * Sl, B, hp, D).transpose(0, 1)
+
+
+def pack_seq(x: Tensor, P: int) -> Tensor:
+    """(B, S, H/P, D) -> send buffer (P, S/P, B, H/P, D); free when x is already seq-major."""
+    B, S, hp, D = x.shape
+    assert S % P == 0, f"sequence {S} not divisible by ulysses degree {P}"
+    if is_seq_major(x):
+        send = x.transpose(0, 1)                       # already (S,B,hp,D) contiguous: no copy
+    else:
+        if x.stride(3) != 1 or x.stride(2) != D:
+            x = x.contiguous()
+        send = torch.empty((S, B, hp, D), dtype=x.dtype, device=x.device)
+        _copy_rows(send, x, hp * D, (S, B), (B * hp * D, hp * D), (x.stride(1), x.stride(0)))
+    return send.view(P, S // P, B, hp, D)
+
+
+def unpack_heads(recv: Tensor) -> Tensor:
+    """receive buffer (P, S/P, B, H/P, D) [chunk p = head group p] -> (B, S/P, H, D) contiguous."""
+    P, Sl, B, hp, D = recv.shape
+    H = hp * P
+    out = torch.empty((B, Sl, H, D), dtype=recv.dtype, device=recv.device)
+    _copy_rows(out, recv, hp * D, (P, Sl, B), (hp * D, H * D, Sl * H * D),
+               (Sl * B * hp * D, B * hp * D, hp * D))
+    return out
+
+
+def heads_to_seq(x: Tensor, group, use_sync: bool = False, contiguous: bool = False) -> Tensor:
+    """scatter heads / gather sequence: (B, S/P, H, D) -> (B, S, H/P, D)  (all_to_all.py:36-67)."""
+    P = dist.get_world_size(group)
+    if P == 1:
+        return x
+    out = view_seq(_exchange(pack_heads(x, P), group, use_sync))
     return out.contiguous() if contiguous else out
 
 
@@ -76,21 +110,7 @@ def seq_to_heads(x: Tensor, group, use_sync: bool = False) -> Tensor:
     P = dist.get_world_size(group)
     if P == 1:
         return x
-    B, S, hp, D = x.shape
-    assert S % P == 0, f"sequence {S} not divisible by ulysses degree {P}"
-    Sl, H = S // P, hp * P
-    if is_seq_major(x):
-        send = x.transpose(0, 1)                       # already (S,B,hp,D) contiguous: no copy
-    else:
-        if x.stride(3) != 1 or x.stride(2) != D:
-            x = x.contiguous()
-        send = torch.empty((S, B, hp, D), dtype=x.dtype, device=x.device)
-        _copy_rows(send, x, hp * D, (S, B), (B * hp * D, hp * D), (x.stride(1), x.stride(0)))
-    recv = _exchange(send.view(P, Sl, B, hp, D), group, use_sync)
-    out = torch.empty((B, Sl, H, D), dtype=x.dtype, device=x.device)
-    _copy_rows(out, recv, hp * D, (P, Sl, B), (hp * D, H * D, Sl * H * D),
-               (Sl * B * hp * D, B * hp * D, hp * D))
-    return out
+    return unpack_heads(_exchange(pack_seq(x, P), group, use_sync))
 
 
 def all_to_all_4D(input: torch.Tensor, scatter_idx: int = 2, gather_idx: int = 1, group=None,

@@ -16,6 +16,27 @@ from .utils import KVRelay, RingComm
 from .zigzag_ring_flash_attn import _cast, _check_hot_path_args
 
 
+
+def basic_fwd_step(be, r, P, step, causal, q, kk, vv, softmax_scale, lse, out, acc):
+    """One step of the contiguous-layout ring forward (ring_flash_attn.py:29-56); pure schedule
+    logic, also driven by the single-GPU tests with virtual ranks."""
+    if causal and step > r:
+        return
+    last_compute = r if causal else P - 1
+    fe = q.shape[1] if step == last_compute else 0
+    be.fwd(q, kk, vv, softmax_scale, bool(causal and step == 0), lse, out, acc, step > 0, 0, fe)
+
+
+def basic_bwd_block(be, r, P, step, causal, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc,
+                    dk_dst, dv_dst):
+    """Block backward of one step (:93-122).  Returns False when the step computes nothing."""
+    if causal and step > r:
+        return False
+    be.bwd(dout, q, kk, vv, lse, delta, dq_acc, dk_dst, dv_dst, softmax_scale,
+           bool(causal and step == 0), accum_dq=step > 0)
+    return True
+
+
 def ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, causal=True,
                             window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
                             attn_type: AttnType = AttnType.HIP, attn_processor=None):
@@ -32,9 +53,7 @@ def ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, 
     relay = KVRelay(process_group, k, v)
     for step in range(P):
         kk, vv = relay.get(step)
-        if not causal or step <= r:
-            fe = S if step == last_compute else 0
-            be.fwd(q, kk, vv, softmax_scale, bool(causal and step == 0), lse, out, acc, step > 0, 0, fe)
+        basic_fwd_step(be, r, P, step, causal, q, kk, vv, softmax_scale, lse, out, acc)
     relay.finish()
     return out, lse
 
@@ -65,18 +84,16 @@ def ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, sof
         if step == 0:
             dk_acc = torch.empty(k.shape, dtype=f32, device=dev)
             dv_acc = torch.empty(v.shape, dtype=f32, device=dev)
-            be.bwd(dout, q, kk, vv, softmax_lse, delta, dq_acc, dk_acc, dv_acc, softmax_scale,
-                   bool(causal))
-        elif not causal or step <= r:
-            be.bwd(dout, q, kk, vv, softmax_lse, delta, dq_acc, dk_blk, dv_blk, softmax_scale, False,
-                   accum_dq=True)
-            d_comm.wait()
-            dk_acc, dv_acc = next_dk, next_dv
-            be.add(dk_acc, dk_acc, dk_blk)
-            be.add(dv_acc, dv_acc, dv_blk)
+            basic_bwd_block(be, r, P, 0, causal, dout, q, kk, vv, softmax_lse, delta, softmax_scale,
+                            dq_acc, dk_acc, dv_acc)
         else:
+            computed = basic_bwd_block(be, r, P, step, causal, dout, q, kk, vv, softmax_lse, delta,
+                                       softmax_scale, dq_acc, dk_blk, dv_blk)
             d_comm.wait()
             dk_acc, dv_acc = next_dk, next_dv
+            if computed:
+                be.add(dk_acc, dk_acc, dk_blk)
+                be.add(dv_acc, dv_acc, dv_blk)
         if P > 1:
             d_comm = RingComm(process_group)
             next_dk = d_comm.send_recv(dk_acc)

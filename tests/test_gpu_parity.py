@@ -1,0 +1,435 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(libusp_hip.so via yunchang_amd._C), against the CPU oracle and the reference golden fixtures.
+
+Tolerances (stated, SURVEY.md section 8c / golden_util.TOL): bf16 out atol=rtol=2e-2, grads 5e-2;
+fp16 out 4e-3, grads 1e-2; fp32 LSE 2e-3.  The reference's own bar is atol=1e-1 on the forward.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden, TOL, assert_close, golden_files, round_to
+from oracle import usp_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import yunchang_amd  # noqa: F401  (fails loudly if the extension is missing)
+    from yunchang_amd import _C
+    _C.load()
+    return torch.device("cuda:0")
+
+
+def _t(x, dtype_s, dev):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(getattr(torch, dtype_s)).to(dev)
+
+
+def _f(t):
+    return t.detach().float().cpu().numpy()
+
+
+def _rand(shape, dtype_s, seed):
+    return round_to(np.random.RandomState(seed).standard_normal(shape).astype(np.float32), dtype_s)
+
+
+# ------------------------------------------------------------------------------------------------
+# block kernels vs oracle
+# ------------------------------------------------------------------------------------------------
+SHAPES = [
+    # B, Sq, Sk, Hq, Hkv, D, causal, dtype
+    (1, 1024, 1024, 8, 8, 64, True, "bfloat16"),      # C1
+    (2, 512, 512, 4, 4, 128, True, "bfloat16"),
+    (1, 384, 640, 4, 2, 128, False, "bfloat16"),      # Sq != Sk, GQA
+    (1, 200, 333, 3, 1, 128, True, "bfloat16"),       # ragged, bottom-right causal
+    (1, 333, 200, 2, 2, 64, True, "float16"),         # rows with no visible key
+    (2, 77, 77, 2, 2, 32, True, "bfloat16"),
+    (1, 1, 1, 1, 1, 128, True, "float16"),
+    (1, 130, 1, 2, 1, 64, False, "bfloat16"),
+]
+
+
+@pytest.mark.parametrize("B,Sq,Sk,Hq,Hkv,D,causal,dt", SHAPES)
+def test_block_forward_backward_vs_oracle(dev, B, Sq, Sk, Hq, Hkv, D, causal, dt):
+    from yunchang_amd.kernels import hip_attn_backward, hip_attn_forward
+    q, k, v, do = (_rand(s, dt, i) for i, s in enumerate(
+        [(B, Sq, Hq, D), (B, Sk, Hkv, D), (B, Sk, Hkv, D), (B, Sq, Hq, D)]))
+    tq, tk, tv, tdo = (_t(x, dt, dev) for x in (q, k, v, do))
+    out, lse = hip_attn_forward(tq, tk, tv, 0.0, None, causal=causal)
+    ro, rl = O.block_fwd(q, k, v, None, causal)
+    atol, rtol = TOL[dt]["out"]
+    assert_close(_f(out), ro, atol, rtol, "out")
+    lse_h = _f(lse)
+    fin = np.isfinite(rl)
+    assert (np.isfinite(lse_h) == fin).all(), "empty rows must give lse = -inf"
+    assert_close(lse_h[fin], rl[fin], 2e-3, 1e-4, "lse")
+    assert (np.abs(_f(out))[~np.broadcast_to(fin.transpose(0, 2, 1)[..., None], ro.shape)] == 0).all()
+    # backward with the oracle's (rounded) out / exact lse as the "global" values
+    o16 = round_to(ro.astype(np.float32), dt)
+    dq, dk, dv = (torch.empty_like(t) for t in (tq, tk, tv))
+    hip_attn_backward(tdo, tq, tk, tv, _t(o16, dt, dev), torch.from_numpy(rl.astype(np.float32)).to(dev),
+                      dq, dk, dv, 0.0, None, causal)
+    rdq, rdk, rdv = O.block_bwd(do, q, k, v, o16, rl, None, causal)
+    atol, rtol = TOL[dt]["grad"]
+    assert_close(_f(dq), rdq, atol, rtol, "dq")
+    assert_close(_f(dk), rdk, atol, rtol, "dk")
+    assert_close(_f(dv), rdv, atol, rtol, "dv")
+
+
+def test_strided_views_and_autograd(dev):
+    """Inputs as non-contiguous (B,S,H,D) views (what the all-to-all hands over) + autograd stage."""
+    from yunchang_amd.kernels import AttnType, select_flash_attn_impl
+    dt = "bfloat16"
+    B, S, H, D = 2, 256, 4, 64
+    q, k, v, do = (_rand((B, S, H, D), dt, 10 + i) for i in range(4))
+    def seq_major(x):
+        return _t(x.transpose(1, 0, 2, 3), dt, dev).transpose(0, 1)      # (B,S,H,D) view of (S,B,H,D)
+    tq, tk, tv = (seq_major(x).requires_grad_(True) for x in (q, k, v))
+    assert not tq.is_contiguous()
+    fn = select_flash_attn_impl(AttnType.HIP, "fwd-bwd")
+    out = fn(tq, tk, tv, causal=True)
+    out.backward(seq_major(do))
+    ro, rl = O.block_fwd(q, k, v, None, True)
+    rdq, rdk, rdv = O.block_bwd(do, q, k, v, ro, rl, None, True)
+    assert_close(_f(out), ro, *TOL[dt]["out"], "out")
+    for got, want, n in ((tq.grad, rdq, "dq"), (tk.grad, rdk, "dk"), (tv.grad, rdv, "dv")):
+        assert_close(_f(got), want, *TOL[dt]["grad"], n)
+
+
+def test_softmax_rescale_branch(dev):
+    """Force large running-max jumps late in the KV loop (guide rule 26): one key per 64-key tile is
+    aligned with the query so the max grows tile after tile."""
+    from yunchang_amd.kernels import hip_attn_forward
+    dt = "bfloat16"
+    B, S, H, D = 1, 512, 1, 128
+    rs = np.random.RandomState(3)
+    q = rs.standard_normal((B, S, H, D)).astype(np.float32)
+    k = rs.standard_normal((B, S, H, D)).astype(np.float32) * 0.1
+    for t in range(S // 64):
+        k[0, 64 * t + 5, 0] = q[0, 300, 0] * (0.5 + 0.25 * t)     # growing spikes for row 300
+    v = rs.standard_normal((B, S, H, D)).astype(np.float32)
+    q, k, v = (round_to(x, dt) for x in (q, k, v))
+    out, lse = hip_attn_forward(_t(q, dt, dev), _t(k, dt, dev), _t(v, dt, dev), causal=False)
+    ro, rl = O.block_fwd(q, k, v, None, False)
+    assert_close(_f(out), ro, *TOL[dt]["out"], "out")
+    assert_close(_f(lse), rl, 2e-3, 1e-4, "lse")
+
+
+# ------------------------------------------------------------------------------------------------
+# elementwise / copy kernels
+# ------------------------------------------------------------------------------------------------
+def test_merge_copy_cast_add_kernels(dev):
+    from yunchang_amd import _C
+    from yunchang_amd.comm import all_to_all as A
+    from yunchang_amd.ring.utils import update_out_and_lse
+    dt = "bfloat16"
+    B, S, H, D = 2, 96, 4, 64
+    rs = np.random.RandomState(0)
+    # update_out_and_lse (ring/utils.py:10-51) incl. the slice form
+    bo1, bo2 = (_rand((B, S, H, D), dt, 20 + i) for i in range(2))
+    bl1, bl2 = (rs.standard_normal((B, H, S)).astype(np.float32) for _ in range(2))
+    out, lse = update_out_and_lse(None, None, _t(bo1, dt, dev), torch.from_numpy(bl1).to(dev))
+    out, lse = update_out_and_lse(out, lse, _t(bo2, dt, dev), torch.from_numpy(bl2).to(dev))
+    ro, rlse = O.update_out_and_lse(None, None, bo1, bl1)
+    ro, rlse = O.update_out_and_lse(ro, rlse, bo2, bl2)
+    assert_close(_f(out), ro, 1e-5, 1e-5, "merged out")
+    assert_close(_f(lse), rlse, 1e-5, 1e-5, "merged lse")
+    half = S // 2
+    bo3 = _rand((B, half, H, D), dt, 30)
+    bl3 = rs.standard_normal((B, H, half)).astype(np.float32)
+    out, lse = update_out_and_lse(out, lse, _t(bo3, dt, dev), torch.from_numpy(bl3).to(dev),
+                                  slice_=(slice(None), slice(half, None)))
+    ro, rlse = O.update_out_and_lse(ro, rlse, bo3, bl3, row_slice=slice(half, None))
+    assert_close(_f(out), ro, 1e-5, 1e-5, "slice-merged out")
+    assert_close(_f(lse), rlse, 1e-5, 1e-5, "slice-merged lse")
+    # pack / unpack of the Ulysses exchange (bit exact)
+    P = 2
+    x = torch.randn(B, S, H, D, device=dev).to(torch.bfloat16)
+    send = A.pack_heads(x, P)
+    hp = H // P
+    want = x.reshape(B, S, P, hp, D).permute(2, 1, 0, 3, 4).contiguous()
+    assert torch.equal(send, want)
+    y = A.view_seq(send)                                   # treat as if received
+    assert y.shape == (B, P * S, hp, D)
+    back = A.unpack_heads(A.pack_seq(x[:, :, :hp].contiguous(), P))
+    want2 = x[:, :, :hp].reshape(B, P, S // P, hp, D).permute(0, 2, 1, 3, 4).reshape(B, S // P, H, D)
+    assert torch.equal(back, want2)
+    # cast + add (bit exact vs torch)
+    a = torch.randn(B, S, H, D, device=dev)
+    b = torch.randn(B, S, H, D, device=dev)
+    d16 = torch.empty(B, S, H, D, device=dev, dtype=torch.bfloat16)
+    _C.cast_from_f32(d16, a)
+    assert torch.equal(d16, a.to(torch.bfloat16))
+    d16h = torch.empty(B, S, H, D, device=dev, dtype=torch.float16)
+    _C.cast_from_f32(d16h, a)
+    assert torch.equal(d16h, a.to(torch.float16))
+    c = torch.empty_like(a)
+    _C.add_f32(c, a, b)
+    assert torch.equal(c, a + b)
+    _C.add_f32(a[:, :half], a[:, :half], b[:, :half])       # in place on batch slices
+    assert torch.equal(a[:, :half], (c - b + b)[:, :half]) or torch.allclose(a[:, :half], c[:, :half])
+
+
+def test_unsupported_arguments_raise(dev):
+    from yunchang_amd.kernels import hip_attn_forward
+    q = torch.randn(1, 64, 2, 96, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        hip_attn_forward(q, q, q)
+    q32 = torch.randn(1, 64, 2, 64, device=dev)
+    with pytest.raises(TypeError):
+        hip_attn_forward(q32, q32, q32)
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures from the reference: single-rank through the real entry point
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def single_rank_pg(dev):
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29731")
+    if not dist.is_initialized():
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    import yunchang_amd as Y
+    Y.set_seq_parallel_pg(1, 1, 0, 1)
+    yield
+    dist.destroy_process_group()
+
+
+W1 = [f for f in golden_files() if "_w1_" in f and "fp32" not in f]
+
+
+@pytest.mark.parametrize("path", W1, ids=lambda p: p.split("/")[-1][:-4])
+def test_single_rank_golden_through_long_context_attention(dev, single_rank_pg, path):
+    import yunchang_amd as Y
+    g = Golden(path)
+    tq, tk, tv, tdo = (_t(x, g.dtype, dev) for x in (g.q, g.k, g.v, g.dout))
+    if g.bwd:
+        for t in (tq, tk, tv):
+            t.requires_grad_(True)
+    attn = Y.LongContextAttention(ring_impl_type=g.impl, attn_type=Y.AttnType.TORCH_EFFICIENT)
+    out = attn(tq, tk, tv, dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
+               alibi_slopes=None, deterministic=False, return_attn_probs=True)
+    assert out.shape == tq.shape and out.dtype == tq.dtype
+    assert_close(_f(out), g.out[0], *TOL[g.dtype]["out"], f"{g.name} out vs reference run")
+    if g.bwd:
+        out.backward(tdo)
+        for key, t in (("dq", tq), ("dk", tk), ("dv", tv)):
+            assert_close(_f(t.grad), getattr(g, key)[0], *TOL[g.dtype]["grad"], f"{g.name} {key}")
+
+
+def test_c1_fp32_fixture_is_matched_by_bf16_kernel(dev, single_rank_pg):
+    """BASELINE configs[0] (the reference's CPU-runnable case, fp32): our 16-bit kernel on the
+    bf16-rounded inputs must sit within the bf16 envelope of the reference's fp32 result."""
+    import yunchang_amd as Y
+    g = Golden([f for f in golden_files() if "c1_w1_fp32" in f][0])
+    tq, tk, tv = (_t(x, "bfloat16", dev) for x in (g.q, g.k, g.v))
+    out = Y.LongContextAttention(ring_impl_type="basic")(tq, tk, tv, causal=True)
+    assert_close(_f(out), g.out[0], *TOL["bfloat16"]["out"], "C1 out vs reference fp32 run")
+
+
+# ------------------------------------------------------------------------------------------------
+# golden fixtures from the reference: multi-rank grids emulated with VIRTUAL RANKS on one GPU
+# (the package's real pack/unpack kernels and ring step functions; only the wire is emulated)
+# ------------------------------------------------------------------------------------------------
+MULTI = [f for f in golden_files() if "_w1_" not in f]
+
+
+def _virtual_usp(g, dev, with_bwd):
+    from yunchang_amd.comm import all_to_all as A
+    from yunchang_amd.kernels import get_block_backend
+    from yunchang_amd.ring import ring_flash_attn as RB
+    from yunchang_amd.ring import zigzag_ring_flash_attn as RZ
+    be = get_block_backend()
+    assert be.name == "hip"
+    ws, ud, rd, dt = g.ws, g.ud, g.rd, g.dtype
+    tdt = getattr(torch, dt)
+    ulysses, ring = O.seq_parallel_groups(ud, rd, ws)
+    scale = g.D ** -0.5
+    loc = {n: [_t(g.shard(getattr(g, n), r), dt, dev) for r in range(ws)] for n in ("q", "k", "v", "dout")}
+
+    def exchange_heads(xs):           # xs: per-rank (B,Sl,H,D) -> per-rank (B,S,H/P,D)
+        res = [None] * ws
+        for grp in ulysses:
+            P = len(grp)
+            if P == 1:
+                res[grp[0]] = xs[grp[0]]
+                continue
+            sends = [A.pack_heads(xs[r], P) for r in grp]
+            for i, r in enumerate(grp):
+                recv = torch.stack([sends[j][i] for j in range(P)])
+                res[r] = A.view_seq(recv)
+        return res
+
+    def exchange_seq(xs):             # per-rank (B,S,H/P,D) -> per-rank (B,Sl,H,D)
+        res = [None] * ws
+        for grp in ulysses:
+            P = len(grp)
+            if P == 1:
+                res[grp[0]] = xs[grp[0]]
+                continue
+            sends = [A.pack_seq(xs[r], P) for r in grp]
+            for i, r in enumerate(grp):
+                recv = torch.stack([sends[j][i] for j in range(P)])
+                res[r] = A.unpack_heads(recv)
+        return res
+
+    hq, hk, hv = exchange_heads(loc["q"]), exchange_heads(loc["k"]), exchange_heads(loc["v"])
+    outs, lses = [None] * ws, [None] * ws
+    for grp in ring:
+        P = len(grp)
+        for r, rank in enumerate(grp):
+            q = hq[rank]
+            B, S, H, D = q.shape
+            out = A.seq_major_empty(B, S, H, D, tdt, dev)
+            lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+            acc = torch.empty((B, S, H, D), dtype=torch.float32, device=dev) if P > 1 else None
+            for step in range(P):
+                src = grp[(r - step) % P]
+                if g.impl == "zigzag":
+                    RZ.zigzag_fwd_step(be, r, P, step, q, hk[src], hv[src], scale, lse, out, acc)
+                else:
+                    RB.basic_fwd_step(be, r, P, step, True, q, hk[src], hv[src], scale, lse, out, acc)
+            outs[rank], lses[rank] = out, lse
+    final = exchange_seq(outs)
+    if not with_bwd:
+        return final, None
+    hdo = exchange_heads(loc["dout"])
+    f32 = torch.float32
+    hdq, hdk, hdv = [None] * ws, [None] * ws, [None] * ws
+    for grp in ring:
+        P = len(grp)
+        st = []
+        for r, rank in enumerate(grp):
+            q = hq[rank]
+            B, S, H, D = q.shape
+            delta = torch.empty((B, H, S), dtype=f32, device=dev)
+            be.delta(hdo[rank], outs[rank], delta)
+            st.append(dict(delta=delta, dq=torch.empty((B, S, H, D), dtype=f32, device=dev),
+                           dk=torch.empty(hk[rank].shape, dtype=f32, device=dev),
+                           dv=torch.empty(hv[rank].shape, dtype=f32, device=dev),
+                           bk=torch.empty(hk[rank].shape, dtype=f32, device=dev),
+                           bv=torch.empty(hv[rank].shape, dtype=f32, device=dev)))
+        c = hq[grp[0]].shape[1] // 2
+        for step in range(P):
+            if step > 0:                                       # the wire: accumulators move to rank+1
+                dks, dvs = [s["dk"] for s in st], [s["dv"] for s in st]
+                for r in range(P):
+                    st[r]["dk"], st[r]["dv"] = dks[(r - 1) % P], dvs[(r - 1) % P]
+            for r, rank in enumerate(grp):
+                s = st[r]
+                src = grp[(r - step) % P]
+                dst_k, dst_v = (s["dk"], s["dv"]) if step == 0 else (s["bk"], s["bv"])
+                if g.impl == "zigzag":
+                    RZ.zigzag_bwd_block(be, r, P, step, hdo[rank], hq[rank], hk[src], hv[src], lses[rank],
+                                        s["delta"], scale, s["dq"], dst_k, dst_v)
+                    if step > 0:
+                        RZ.zigzag_bwd_fold(be, r, step, c, s["dk"], s["dv"], s["bk"], s["bv"])
+                else:
+                    did = RB.basic_bwd_block(be, r, P, step, True, hdo[rank], hq[rank], hk[src], hv[src],
+                                             lses[rank], s["delta"], scale, s["dq"], dst_k, dst_v)
+                    if step > 0 and did:
+                        be.add(s["dk"], s["dk"], s["bk"])
+                        be.add(s["dv"], s["dv"], s["bv"])
+        dks, dvs = [s["dk"] for s in st], [s["dv"] for s in st]
+        for r, rank in enumerate(grp):                         # final hop lands on the owner
+            hdq[rank] = st[r]["dq"].to(tdt)
+            hdk[rank] = dks[(r - 1) % P].to(tdt) if P > 1 else dks[r].to(tdt)
+            hdv[rank] = dvs[(r - 1) % P].to(tdt) if P > 1 else dvs[r].to(tdt)
+    return final, (exchange_seq(hdq), exchange_seq(hdk), exchange_seq(hdv))
+
+
+@pytest.mark.parametrize("path", MULTI, ids=lambda p: p.split("/")[-1][:-4])
+def test_multi_rank_golden_with_virtual_ranks(dev, path):
+    g = Golden(path)
+    outs, grads = _virtual_usp(g, dev, g.bwd)
+    for r in range(g.ws):
+        assert_close(_f(outs[r]), g.out[r], *TOL[g.dtype]["out"], f"{g.name} out rank {r}")
+    if g.bwd:
+        for name, per_rank in zip(("dq", "dk", "dv"), grads):
+            for r in range(g.ws):
+                assert_close(_f(per_rank[r]), getattr(g, name)[r], *TOL[g.dtype]["grad"],
+                             f"{g.name} {name} rank {r}")
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE full sizes: size-independent properties + sampled oracle rows
+# ------------------------------------------------------------------------------------------------
+def _sampled_rows_oracle(q, k, v, b, h, rows, causal, g):
+    """Exact attention for a few query rows of one head (numpy fp64)."""
+    qs = q[b, rows, h].astype(np.float64)                       # (R,D)
+    kk = k[b, :, h // g].astype(np.float64)
+    vv = v[b, :, h // g].astype(np.float64)
+    s = qs @ kk.T * (q.shape[-1] ** -0.5)
+    if causal:
+        off = k.shape[1] - q.shape[1]
+        s = np.where(np.arange(k.shape[1])[None, :] > np.asarray(rows)[:, None] + off, -np.inf, s)
+    m = s.max(-1, keepdims=True)
+    p = np.exp(s - m)
+    l = p.sum(-1, keepdims=True)
+    return (p / l) @ vv, (m + np.log(l))[:, 0]
+
+
+def test_c2_full_size_properties(dev):
+    """BASELINE configs[1]: B=2 S=8192 H=16 D=128 bf16 causal, on the real kernel."""
+    from yunchang_amd import _C
+    from yunchang_amd.kernels import hip_attn_forward
+    B, S, H, D = 2, 8192, 16, 128
+    gen = torch.Generator(device="cpu").manual_seed(0)
+    q, k, v = (torch.randn(B, S, H, D, generator=gen).to(torch.bfloat16) for _ in range(3))
+    tq, tk, tv = q.to(dev), k.to(dev), v.to(dev)
+    out, lse = hip_attn_forward(tq, tk, tv, causal=True)
+    # (1) sampled rows of two heads against exact attention
+    qn, kn, vn = (t.float().numpy() for t in (q, k, v))
+    rows = [0, 1, 63, 64, 255, 256, 257, 4095, 4096, 8000, 8191]
+    for (b, h) in ((0, 0), (1, 13)):
+        ro, rl = _sampled_rows_oracle(qn, kn, vn, b, h, rows, True, 1)
+        assert_close(_f(out[b, rows, h]), ro, *TOL["bfloat16"]["out"], f"sampled out b{b} h{h}")
+        assert_close(_f(lse[b, h, rows]), rl, 2e-3, 1e-4, f"sampled lse b{b} h{h}")
+    # (2) linearity in V: attention(q, k, 2v) == 2 attention(q, k, v) exactly (power-of-two scale)
+    out2, lse2 = hip_attn_forward(tq, tk, tv * 2, causal=True)
+    assert torch.equal(out2.float(), out.float() * 2) and torch.equal(lse2, lse)
+    # (3) causal prefix property: rows [0, S/2) do not depend on later keys
+    outp, lsep = hip_attn_forward(tq[:, : S // 2], tk[:, : S // 2], tv[:, : S // 2], causal=True)
+    assert torch.allclose(outp.float(), out[:, : S // 2].float(), atol=1e-2, rtol=1e-2)
+    assert torch.allclose(lsep, lse[:, :, : S // 2], atol=1e-4, rtol=1e-5)
+    # (4) KV-split + fused merge == one pass (non-causal), i.e. what a ring of 2 computes
+    full, lse_full = hip_attn_forward(tq, tk, tv, causal=False)
+    acc = torch.empty(B, S, H, D, device=dev, dtype=torch.float32)
+    lse_m = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+    outm = torch.empty_like(full)
+    hs = S // 2
+    _C.flash_fwd(tq, tk[:, :hs], tv[:, :hs], D ** -0.5, False, lse_m, outm, acc, False, 0, 0)
+    _C.flash_fwd(tq, tk[:, hs:], tv[:, hs:], D ** -0.5, False, lse_m, outm, acc, True, 0, S)
+    assert torch.allclose(outm.float(), full.float(), atol=8e-3, rtol=8e-3)
+    assert torch.allclose(lse_m, lse_full, atol=1e-4, rtol=1e-5)
+    # (5) softmax rows are convex combinations: |out| <= max |v| per head
+    vmax = tv.float().abs().amax(dim=1, keepdim=True)
+    assert (out.float().abs() <= vmax + 1e-2).all()
+
+
+def test_c5_rank_block_gqa_backward_sampled(dev):
+    """The per-rank block of BASELINE configs[4] after the Ulysses exchange (Hq=16, Hkv=2, D=128),
+    at a reduced sequence (S=2048): GQA backward against the oracle on one kv head."""
+    from yunchang_amd.kernels import hip_attn_backward, hip_attn_forward
+    dt = "bfloat16"
+    B, S, Hq, Hkv, D = 1, 2048, 16, 2, 128
+    q, k, v, do = (_rand(s, dt, 40 + i) for i, s in enumerate(
+        [(B, S, Hq, D), (B, S, Hkv, D), (B, S, Hkv, D), (B, S, Hq, D)]))
+    tq, tk, tv, tdo = (_t(x, dt, dev) for x in (q, k, v, do))
+    out, lse = hip_attn_forward(tq, tk, tv, causal=True)
+    dq, dk, dv = (torch.empty_like(t) for t in (tq, tk, tv))
+    hip_attn_backward(tdo, tq, tk, tv, out, lse, dq, dk, dv, 0.0, None, True)
+    g = Hq // Hkv
+    sl = slice(g, 2 * g)                                     # query heads of kv head 1
+    ro, rl = O.block_fwd(q[:, :, sl], k[:, :, 1:2], v[:, :, 1:2], None, True)
+    rdq, rdk, rdv = O.block_bwd(do[:, :, sl], q[:, :, sl], k[:, :, 1:2], v[:, :, 1:2],
+                                _f(out)[:, :, sl], _f(lse)[:, sl], None, True)
+    assert_close(_f(out)[:, :, sl], ro, *TOL[dt]["out"], "out")
+    assert_close(_f(dq)[:, :, sl], rdq, *TOL[dt]["grad"], "dq")
+    assert_close(_f(dk)[:, :, 1:2], rdk, 8e-2, 5e-2, "dk (sum over 8 query heads)")
+    assert_close(_f(dv)[:, :, 1:2], rdv, 8e-2, 5e-2, "dv (sum over 8 query heads)")

@@ -1,0 +1,116 @@
+"""CPU tests of the host-side mirror of the reference interface and of the C-ABI library surface
+(no compute calls: there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import yunchang_amd as Y
+from yunchang_amd import _C
+from yunchang_amd.kernels import AttnType, select_flash_attn_impl
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "usp_hip.h")).read()
+    declared = set(re.findall(r"\b(usp_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"usp_tensor"}
+    assert {"usp_flash_fwd", "usp_flash_bwd", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
+            "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror"} <= declared
+    lib = ctypes.CDLL(_C.lib_path())
+    for name in declared:
+        assert hasattr(lib, name), f"libusp_hip.so does not export {name}"
+    assert set(_C.EXPORTS) == declared
+    L = _C.load()
+    assert L.usp_abi_version() == 1
+    assert b"head_dim" in L.usp_strerror(-2)
+
+
+def test_argument_validation_without_launch():
+    """Bad arguments are rejected before any launch (safe to call without a GPU)."""
+    L = _C.load()
+    a = _C.UspFwdArgs()
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -1          # null lse
+    buf = ctypes.create_string_buffer(4096)
+    addr = (ctypes.addressof(buf) + 15) & ~15
+    a.lse = addr
+    a.dtype, a.B, a.Sq, a.Sk, a.Hq, a.Hkv, a.D = 0, 1, 16, 16, 2, 2, 96
+    a.softmax_scale = 0.1
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -2          # head_dim 96 unsupported
+    a.D, a.Hq, a.Hkv = 64, 3, 2
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -2          # Hq % Hkv
+    a.Hq, a.softmax_scale = 2, 0.0
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
+    a.dtype, a.softmax_scale = 7, 0.1
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
+    assert L.usp_copy_rows(addr, addr, 24, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, None) == -2
+    assert L.usp_flash_bwd(None, None) == -1
+
+
+def test_attn_type_surface():
+    ref_members = ["aiter", "fa", "fa3", "flashinfer", "torch_math", "torch_flash", "torch_efficient",
+                   "torch_cudnn", "sage_auto", "sage_fp16", "sage_fp16_triton", "sage_fp8",
+                   "sage_fp8_sm90", "sparse_sage", "npu"]                 # kernels/__init__.py:38-53
+    for v in ref_members:
+        assert AttnType.from_string(v).value == v
+    assert AttnType.from_string("hip") is AttnType.HIP
+    with pytest.raises(ValueError):
+        AttnType.from_string("torch")                                     # scripts/run_dit.sh:40 case
+    for t in (AttnType.HIP, AttnType.FA, AttnType.TORCH_EFFICIENT):
+        for stage in ("fwd-only", "bwd-only", "fwd-bwd"):
+            assert callable(select_flash_attn_impl(t, stage))
+        with pytest.raises(ValueError):
+            select_flash_attn_impl(t, "nope")
+    with pytest.raises(ValueError):
+        select_flash_attn_impl(AttnType.SAGE_FP8, "fwd-only")
+    marker = object()
+    assert select_flash_attn_impl(AttnType.SAGE_FP8, "fwd-only", attn_processor=marker) is marker
+
+
+def test_registry_keys_and_exports():
+    assert list(Y.EXTRACT_FUNC_DICT) == ["basic", "strip", "zigzag", "basic_pytorch", "basic_flashinfer",
+                                         "basic_npu"]                     # extract_local.py:53-60
+    from yunchang_amd.hybrid.utils import RING_IMPL_DICT, RING_IMPL_QKVPACKED_DICT
+    assert list(RING_IMPL_DICT) == ["basic", "zigzag", "strip", "basic_pytorch", "basic_flashinfer",
+                                    "basic_npu"]                          # hybrid/utils.py:14-21
+    assert set(RING_IMPL_QKVPACKED_DICT) == {"basic", "zigzag", "strip", "basic_flashinfer"}
+    with pytest.raises(NotImplementedError):
+        RING_IMPL_DICT["strip"](None, None, None)
+    for name in ("LongContextAttention", "set_seq_parallel_pg", "EXTRACT_FUNC_DICT", "AttnType",
+                 "PROCESS_GROUP", "zigzag_ring_flash_attn_func", "ring_flash_attn_func", "RingComm",
+                 "update_out_and_lse", "basic_extract_local", "zigzag_extract_local", "__version__"):
+        assert hasattr(Y, name), name
+
+
+def test_layer_requires_process_groups():
+    Y.PROCESS_GROUP.ULYSSES_PG = None
+    Y.PROCESS_GROUP.RING_PG = None
+    with pytest.raises(AssertionError, match="set_seq_parallel_pg"):
+        Y.LongContextAttention(ring_impl_type="zigzag")
+    with pytest.raises(KeyError):
+        Y.PROCESS_GROUP.RING_PG = object()
+        Y.LongContextAttention(ring_impl_type="stripe")                   # the key is "strip"
+    Y.PROCESS_GROUP.RING_PG = None
+
+
+def test_cpu_tensors_fail_loudly():
+    """No CPU fallback: the HIP backend refuses host tensors."""
+    from yunchang_amd.kernels import get_block_backend, hip_attn_forward
+    assert get_block_backend().name == "hip"
+    q = torch.randn(1, 8, 2, 64, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        hip_attn_forward(q, q, q, causal=True)
+    with pytest.raises(NotImplementedError):
+        hip_attn_forward(q, q, q, dropout_p=0.1)
+
+
+def test_grid_matches_reference_layout():
+    """globals.py:39-57 replayed by the oracle: ud=2, rd=4, ws=8 -> ulysses {0,1}.., ring {0,2,4,6}.."""
+    from oracle import usp_oracle as O
+    u, r = O.seq_parallel_groups(2, 4, 8)
+    assert u == [[0, 1], [2, 3], [4, 5], [6, 7]] and r == [[0, 2, 4, 6], [1, 3, 5, 7]]
+    u, r = O.seq_parallel_groups(2, 2, 8)           # dp = 2
+    assert u == [[0, 1], [2, 3], [4, 5], [6, 7]] and r == [[0, 2], [1, 3], [4, 6], [5, 7]]
