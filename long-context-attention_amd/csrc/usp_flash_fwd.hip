@@ -52,11 +52,12 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
   using E = Elem<DT>;
   constexpr int ROWB = D * 2;                 // bytes per K row
   constexpr int KBYTES = kBN * ROWB;          // one K (or V) tile
-  constexpr int BUFB = 2 * KBYTES;            // K + V
   constexpr int NKT = D / 16;                 // k-steps of K Q^T
   constexpr int NDJ = D / 32;                 // 32-wide dim tiles of O^T
   constexpr int NCH = kBN * D / 8;            // 16-byte chunks per tile
   constexpr int NP = (NCH + kThreads - 1) / kThreads;
+  // LDS: Kbuf[0], Kbuf[1], Vbuf[0], Vbuf[1]
+  constexpr int VOFF = 2 * KBYTES;
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   USP_LDS char* smem = (USP_LDS char*)smem_raw;
@@ -94,6 +95,15 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
   }
   if (qw >= p.Sq) wave_kv_end = 0;
   const int nt = blk_kv_end > 0 ? (blk_kv_end + kBN - 1) / kBN : 0;
+  // leading tiles that need neither a causal nor a ragged mask for this wave
+  int n_full = p.Sk / kBN;
+  if (CAUSAL) {
+    const int lim = qw + off + 1;                         // keys < lim are visible to EVERY row of the wave
+    const int nf = lim > 0 ? lim / kBN : 0;
+    n_full = nf < n_full ? nf : n_full;
+  }
+  if (qw + 32 > p.Sq) n_full = 0;                         // ragged / inactive waves take the generic loop
+  if (n_full > nt) n_full = nt;
 
   // ---- Q fragments (B operand: lane holds Q[row][16t + 8hi .. +7]) ---------------------------
   u32x4 qf[NKT];
@@ -121,40 +131,47 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
       const int dj = r2 % NDJ, kb = r2 / NDJ;
       v_row[i] = 4 * kb + kr;
       v_goff[i] = (32 * dj + 8 * q4) * 2;
-      v_loff[i] = KBYTES + (kb * NDJ + dj) * 256 + kr * 64 + q4 * 16;
+      v_loff[i] = VOFF + (kb * NDJ + dj) * 256 + kr * 64 + q4 * 16;
     }
   }
   u32x4 kst[NP], vst[NP];
-  auto stage_load = [&](int tile) {
+  auto load_k = [&](int tile) {
     const int k0 = tile * kBN;
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
+    for (int i = 0; i < NP; ++i)
       if (NCH % kThreads == 0 || i * kThreads + tid < NCH) {
         int kr = k0 + k_row[i];
         kr = kr < p.Sk ? kr : p.Sk - 1;
         kst[i] = *(const u32x4*)(kbase + 2 * (int64_t)kr * p.k_ss + k_goff[i]);
+      }
+  };
+  auto load_v = [&](int tile) {
+    const int k0 = tile * kBN;
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      if (NCH % kThreads == 0 || i * kThreads + tid < NCH) {
         int vr = k0 + v_row[i];
         vr = vr < p.Sk ? vr : p.Sk - 1;
         vst[i] = *(const u32x4*)(vbase + 2 * (int64_t)vr * p.v_ss + v_goff[i]);
       }
-    }
   };
-  auto stage_store = [&](int buf) {
+  auto store_k = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      if (NCH % kThreads == 0 || i * kThreads + tid < NCH) {
-        *(USP_LDS u32x4*)(smem + buf * BUFB + k_loff[i]) = kst[i];
-        *(USP_LDS u32x4*)(smem + buf * BUFB + v_loff[i]) = vst[i];
-      }
-    }
+    for (int i = 0; i < NP; ++i)
+      if (NCH % kThreads == 0 || i * kThreads + tid < NCH)
+        *(USP_LDS u32x4*)(smem + buf * KBYTES + k_loff[i]) = kst[i];
+  };
+  auto store_v = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      if (NCH % kThreads == 0 || i * kThreads + tid < NCH)
+        *(USP_LDS u32x4*)(smem + buf * KBYTES + v_loff[i]) = vst[i];
   };
 
   // ---- per-lane LDS read bases -----------------------------------------------------------------
-  // K fragment (A operand) for key half n32, k-step t: row 32*n32 + l31, slot (2t + hi) ^ swz.
   const int k_rd_row = l31 * ROWB;
   const int k_rd_x = hi ^ KSwz<D>::of(l31);          // (2t + hi) ^ s == (2t) ^ (hi ^ s)
-  // V fragment for (dj, ks, e): block (4ks + hi + 2e) * NDJ + dj; chunk of lane i in its 16-group.
-  const int v_rd = KBYTES + hi * NDJ * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 +
+  const int v_rd = VOFF + hi * NDJ * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 +
                    (lane & 3) * 8;
 
   // ---- accumulators ----------------------------------------------------------------------------
@@ -167,92 +184,290 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
   float l_run = 0.f;           // this lane's share of the row sum
   const float c = p.scale_log2;
 
+  // S^T = K Q^T for the K tile in Kbuf[kbuf]
+  auto qk = [&](int kbuf, f32x16& s0, f32x16& s1) {
+    USP_LDS const char* kb = smem + kbuf * KBYTES;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int slot = ((2 * kt) ^ k_rd_x) * 16;
+      u32x4 ka = *(USP_LDS const u32x4*)(kb + k_rd_row + slot);
+      u32x4 kc = *(USP_LDS const u32x4*)(kb + 32 * ROWB + k_rd_row + slot);
+      s0 = E::mfma(ka, qf[kt], s0);
+      s1 = E::mfma(kc, qf[kt], s1);
+    }
+  };
+  // online softmax of one 64-key tile held in (s0, s1); rescales o, returns P packed for the PV MFMAs
+  auto softmax = [&](f32x16& s0, f32x16& s1, u32x4 (&pf)[4]) {
+    float mt = s0[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s0[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s1[r]);
+    mt = xhalf_max(mt);
+    const float m_new = fmaxf(m_run, mt);
+    const float m_use = (m_new == USP_NEG_INF) ? 0.f : m_new;
+    const float mc = m_use * c;
+    const float alpha = fast_exp2(m_run * c - mc);
+    m_run = m_new;
+    float rs = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = fast_exp2(__builtin_fmaf(s0[r], c, -mc));
+      s1[r] = fast_exp2(__builtin_fmaf(s1[r], c, -mc));
+      rs += s0[r] + s1[r];
+    }
+    l_run = l_run * alpha + rs;
+#pragma unroll
+    for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
+    // P (B operand of V^T P^T): k-step ks = 2*n32 + (r>>3), element e = r & 7
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pf[0][j] = E::pack2(s0[2 * j], s0[2 * j + 1]);
+      pf[1][j] = E::pack2(s0[8 + 2 * j], s0[8 + 2 * j + 1]);
+      pf[2][j] = E::pack2(s1[2 * j], s1[2 * j + 1]);
+      pf[3][j] = E::pack2(s1[8 + 2 * j], s1[8 + 2 * j + 1]);
+    }
+  };
+  // O^T += V^T P^T for the V tile in Vbuf[vbuf]
+  auto pv = [&](int vbuf, const u32x4 (&pf)[4]) {
+    USP_LDS const char* vb = smem + vbuf * KBYTES + v_rd;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int dj = 0; dj < NDJ; ++dj) {
+        USP_LDS const char* vp = vb + (4 * ks * NDJ + dj) * 256;
+        u32x2 v0 = lds_read_tr16(vp);
+        u32x2 v1 = lds_read_tr16(vp + 2 * NDJ * 256);
+        u32x4 va = {v0[0], v0[1], v1[0], v1[1]};
+        o[dj] = E::mfma(va, pf[ks], o[dj]);
+      }
+    }
+  };
+  auto mask = [&](int kt0, f32x16& s0, f32x16& s1) {
+    int klim = p.Sk - 1;
+    if (CAUSAL) klim = row + off < klim ? row + off : klim;
+    const int kb0 = kt0 + 4 * hi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kb0 + (r & 3) + 8 * (r >> 2);
+      if (key > klim) s0[r] = USP_NEG_INF;
+      if (key + 32 > klim) s1[r] = USP_NEG_INF;
+    }
+  };
+
+  // ---- prologue: K(0), V(0), K(1) resident; S(0) computed ------------------------------------------
+  f32x16 sa, sb;          // S^T of the tile the softmax works on next
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
   if (nt > 0) {
-    stage_load(0);
-    stage_store(0);
+    load_k(0); load_v(0);
+    store_k(0); store_v(0);
+    if (nt > 1) { load_k(1); store_k(1); }
   }
   __syncthreads();
+  if (nt > 0 && wave_kv_end > 0) qk(0, sa, sb);
 
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    const int kt0 = t * kBN;
-    if (t + 1 < nt) stage_load(t + 1);
-
-    if (kt0 < wave_kv_end) {
-      USP_LDS const char* kb = smem + buf * BUFB;
-      // ---- S^T = K Q^T --------------------------------------------------------------------
-      f32x16 s0, s1;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
-        const int slot = ((2 * kt) ^ k_rd_x) * 16;
-        u32x4 ka = *(USP_LDS const u32x4*)(kb + k_rd_row + slot);
-        u32x4 kc = *(USP_LDS const u32x4*)(kb + 32 * ROWB + k_rd_row + slot);
-        s0 = E::mfma(ka, qf[kt], s0);
-        s1 = E::mfma(kc, qf[kt], s1);
-      }
-      // ---- mask ---------------------------------------------------------------------------
-      const bool need_mask = (kt0 + kBN > p.Sk) || (CAUSAL && kt0 + kBN - 1 > qw + off);
-      if (need_mask) {
-        int klim = p.Sk - 1;
-        if (CAUSAL) klim = row + off < klim ? row + off : klim;
-        const int kb0 = kt0 + 4 * hi;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kb0 + (r & 3) + 8 * (r >> 2);
-          if (key > klim) s0[r] = USP_NEG_INF;
-          if (key + 32 > klim) s1[r] = USP_NEG_INF;
-        }
-      }
-      // ---- online softmax (lane-local row) --------------------------------------------------
-      float mt = s0[0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s0[r]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s1[r]);
-      mt = xhalf_max(mt);
+  // ---- main loop over unmasked tiles, hand-pinned software pipeline --------------------------------
+  // Per iteration j (reference max m_run already decided for tile j):
+  //   phase A: 2*NKT MFMAs of S(j+1) = K(j+1) Q^T, each followed by a slice of the exp2 / row-sum /
+  //            pack work of tile j (24 of its 32 elements), K fragments prefetched two k-steps ahead;
+  //   phase B: 4*NDJ MFMAs of O^T += V(j)^T P(j)^T, the first half each followed by one of the 8
+  //            remaining exp2 elements, all of them by a slice of the row-max chain of S(j+1),
+  //            V fragments prefetched two MFMAs ahead;
+  //   decision: defer-max -- O and l are rescaled only when some row's max grew by more than 2^kThr
+  //            (wave-uniform, rare); otherwise the old reference max is kept (P <= 2^kThr).
+  // sched_barrier(0) pins the order: hipcc otherwise emits all MFMAs, then all VALU (measured).
+  // The two S register sets ping-pong (no copies); the first MFMA of each chain takes C = 0.
+  // K/V tiles are fetched with buffer loads: per-thread offsets are loop invariant, the tile offset
+  // is a scalar (no 64-bit VALU address math in the loop).
+  constexpr float kThr = 8.f;
+  constexpr int NA = 2 * NKT, NB = 4 * NDJ;
+  int j = 0;
+  const int n_main = n_full < nt - 1 ? n_full : nt - 1;    // j + 1 < nt holds inside: no branches
+  auto decide = [&](float mt) {
+    // mt: row max of the upcoming tile (both half-waves).  Wave-uniform branch.
+    if (!__all((mt - m_run) * c <= kThr)) {
+      asm volatile("; rescale (rare)" ::: "memory");          // keeps hipcc from if-converting the branch
       const float m_new = fmaxf(m_run, mt);
       const float m_use = (m_new == USP_NEG_INF) ? 0.f : m_new;
-      const float mc = m_use * c;
-      const float alpha = fast_exp2(m_run * c - mc);
+      const float alpha = fast_exp2(m_run * c - m_use * c);
       m_run = m_new;
-      float rs = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = fast_exp2(__builtin_fmaf(s0[r], c, -mc));
-        s1[r] = fast_exp2(__builtin_fmaf(s1[r], c, -mc));
-        rs += s0[r] + s1[r];
-      }
-      l_run = l_run * alpha + rs;
+      l_run *= alpha;
 #pragma unroll
       for (int dj = 0; dj < NDJ; ++dj)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
-      // ---- P (B operand of V^T P^T): k-step ks = 2*n32 + (r>>3), element e = r & 7 ---------
-      u32x4 pf[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        pf[0][j] = E::pack2(s0[2 * j], s0[2 * j + 1]);
-        pf[1][j] = E::pack2(s0[8 + 2 * j], s0[8 + 2 * j + 1]);
-        pf[2][j] = E::pack2(s1[2 * j], s1[2 * j + 1]);
-        pf[3][j] = E::pack2(s1[8 + 2 * j], s1[8 + 2 * j + 1]);
-      }
-      // ---- O^T += V^T P^T ------------------------------------------------------------------
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-        for (int dj = 0; dj < NDJ; ++dj) {
-          USP_LDS const char* vp = kb + v_rd + (4 * ks * NDJ + dj) * 256;
-          u32x2 v0 = lds_read_tr16(vp);
-          u32x2 v1 = lds_read_tr16(vp + 2 * NDJ * 256);
-          u32x4 va = {v0[0], v0[1], v1[0], v1[1]};
-          o[dj] = E::mfma(va, pf[ks], o[dj]);
-        }
-      }
     }
+  };
+  // Buffer loads: the tile offset is folded into the (64-bit, scalar) descriptor base so that no
+  // 32-bit offset can overflow at any sequence length; num_records makes rows >= Sk read as 0.
+  int k_voff[NP], v_voff[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    k_voff[i] = k_row[i] * (int)p.k_ss * 2 + k_goff[i];
+    v_voff[i] = v_row[i] * (int)p.v_ss * 2 + v_goff[i];
+  }
+  auto tile_rsrc = [&](const char* base, int64_t ss, int tile) {
+    const int64_t toff = (int64_t)tile * kBN * ss * 2;
+    int64_t rem = ((int64_t)(p.Sk - 1 - tile * kBN) * ss + D) * 2;
+    rem = rem < 0 ? 0 : (rem > 0xffffffffLL ? 0xffffffffLL : rem);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + toff), 0, (int)(uint32_t)rem, 0x00020000);
+  };
+  auto bload_k = [&](int tile) {
+    const auto rs_ = tile_rsrc(kbase, p.k_ss, tile);
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      if (NCH % kThreads == 0 || i * kThreads + tid < NCH)
+        kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, k_voff[i], 0, 0);
+  };
+  auto bload_v = [&](int tile) {
+    const auto rs_ = tile_rsrc(vbase, p.v_ss, tile);
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+      if (NCH % kThreads == 0 || i * kThreads + tid < NCH)
+        vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, v_voff[i], 0, 0);
+  };
 
-    if (t + 1 < nt) stage_store(buf ^ 1);
+  // one pipelined iteration: softmax + PV of tile jj (scores in ca/cb), scores of tile jj+1 into na/nb
+  auto iter = [&](int jj, f32x16& ca, f32x16& cb, f32x16& na, f32x16& nb) {
+    const int jk = jj + 2 < nt ? jj + 2 : nt - 1;           // clamped prefetch (redundant load at the end)
+#ifndef USP_ABLATE_NOSTAGE
+    bload_k(jk);
+    bload_v(jj + 1);
+#endif
+    // ---------------- phase A ----------------
+    USP_LDS const char* kb = smem + ((jj + 1) & 1) * KBYTES + k_rd_row;
+    u32x4 ka[NKT], kc[NKT];
+    auto rd_k = [&](int kt) {
+      const int slot = ((2 * kt) ^ k_rd_x) * 16;
+#ifdef USP_ABLATE_NOLDS
+      ka[kt] = qf[kt]; kc[kt] = qf[(kt + 1) % NKT]; (void)slot;
+#else
+      ka[kt] = *(USP_LDS const u32x4*)(kb + slot);
+      kc[kt] = *(USP_LDS const u32x4*)(kb + 32 * ROWB + slot);
+#endif
+    };
+    rd_k(0);
+    if (NKT > 1) rd_k(1);
+    const float mc = ((m_run == USP_NEG_INF) ? 0.f : m_run) * c;
+    float rs = 0.f;
+    u32x4 pf[4];
+    // element e of the tile's 32 scores: e < 16 -> ca[e], else cb[e - 16]
+    auto exp_elem = [&](int e) {
+#ifdef USP_ABLATE_NOEXP
+      if (e & 1) {
+        const int r = (e & 15) - 1;
+        if (e < 16) pf[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(uint32_t, ca[r]);
+        else pf[2 + (r >> 3)][(r & 7) >> 1] = __builtin_bit_cast(uint32_t, cb[r]);
+      }
+      return;
+#endif
+      if (e < 16) { ca[e] = fast_exp2(__builtin_fmaf(ca[e], c, -mc)); rs += ca[e]; }
+      else { cb[e - 16] = fast_exp2(__builtin_fmaf(cb[e - 16], c, -mc)); rs += cb[e - 16]; }
+      if (e & 1) {                                          // pair (e-1, e) complete -> pack
+        const int r = (e & 15) - 1;
+        if (e < 16) pf[r >> 3][(r & 7) >> 1] = E::pack2(ca[r], ca[r + 1]);
+        else pf[2 + (r >> 3)][(r & 7) >> 1] = E::pack2(cb[r], cb[r + 1]);
+      }
+    };
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sl = 0; sl < NA; ++sl) {
+      const int kt = sl >> 1;
+      if ((sl & 1) == 0) {
+        if (kt + 2 < NKT) rd_k(kt + 2);
+        na = E::mfma(ka[kt], qf[kt], kt == 0 ? zero : na);
+      } else {
+        nb = E::mfma(kc[kt], qf[kt], kt == 0 ? zero : nb);
+      }
+#pragma unroll
+      for (int e = sl * 24 / NA; e < (sl + 1) * 24 / NA; ++e) exp_elem(e);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---------------- phase B ----------------
+    USP_LDS const char* vb = smem + (jj & 1) * KBYTES + v_rd;
+    u32x4 va[NB];
+    auto rd_v = [&](int i) {                                  // i = ks * NDJ + dj
+      const int ks = i / NDJ, dj = i % NDJ;
+      USP_LDS const char* vp = vb + (4 * ks * NDJ + dj) * 256;
+#ifdef USP_ABLATE_NOLDS
+      va[i] = qf[i % NKT]; (void)vp;
+#else
+      const u32x2 v0 = lds_read_tr16(vp);
+      const u32x2 v1 = lds_read_tr16(vp + 2 * NDJ * 256);
+      va[i] = u32x4{v0[0], v0[1], v1[0], v1[1]};
+#endif
+    };
+    rd_v(0);
+    if (NB > 1) rd_v(1);
+    float mt = USP_NEG_INF;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (i + 2 < NB) rd_v(i + 2);
+      o[i % NDJ] = E::mfma(va[i], pf[i / NDJ], o[i % NDJ]);
+      if (i < NB / 2) {
+#pragma unroll
+        for (int e = 24 + i * 16 / NB; e < 24 + (i + 1) * 16 / NB; ++e) exp_elem(e);
+      }
+#pragma unroll
+      for (int e = i * 32 / NB; e < (i + 1) * 32 / NB; ++e)   // row-max chain of S(jj+1)
+        mt = fmaxf(mt, e < 16 ? na[e] : nb[e - 16]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    l_run += rs;
+#ifndef USP_ABLATE_NOSTAGE
+    store_k(jj & 1);
+    store_v((jj + 1) & 1);
+#endif
+    decide(xhalf_max(mt));
+#ifndef USP_ABLATE_NOBARRIER
+    __syncthreads();
+#endif
+  };
+
+  if (n_main > 0) {
+    float mt = sa[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sa[r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sb[r]);
+    decide(xhalf_max(mt));
+    f32x16 ta, tb;
+    for (; j + 1 < n_main; j += 2) {
+      iter(j, sa, sb, ta, tb);
+      iter(j + 1, ta, tb, sa, sb);
+    }
+    if (j < n_main) {
+      iter(j, sa, sb, ta, tb);
+      sa = ta; sb = tb;
+      ++j;
+    }
+  }
+  // ---- generic tail: masked and/or inactive tiles ---------------------------------------------------
+  for (; j < nt; ++j) {
+    const int kt0 = j * kBN;
+    if (j + 2 < nt) load_k(j + 2);
+    if (j + 1 < nt) load_v(j + 1);
+    f32x16 na, nb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { na[r] = 0.f; nb[r] = 0.f; }
+    if (j + 1 < nt && kt0 + kBN < wave_kv_end) qk((j + 1) & 1, na, nb);
+    if (kt0 < wave_kv_end) {
+      const bool need_mask = (kt0 + kBN > p.Sk) || (CAUSAL && kt0 + kBN - 1 > qw + off);
+      if (need_mask) mask(kt0, sa, sb);
+      u32x4 pf[4];
+      softmax(sa, sb, pf);
+      pv(j & 1, pf);
+    }
+    sa = na; sb = nb;
+    if (j + 2 < nt) store_k(j & 1);
+    if (j + 1 < nt) store_v((j + 1) & 1);
     __syncthreads();
   }
 
