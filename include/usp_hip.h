@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USP_ABI_VERSION 1
+#define USP_ABI_VERSION 2
 
 enum { USP_BF16 = 0, USP_FP16 = 1 };
 
@@ -94,6 +94,7 @@ int usp_flash_fwd(const usp_fwd_args* args, void* stream);
  *     dQ = dS K ; dK = dS^T Q                  (GQA: dK,dV summed over the Hq/Hkv query heads)
  * Outputs are fp32 (B,S,H,D) tensors: dq (+)= dQ, dk (+)= dK, dv (+)= dV, where "+=" is used when
  * the matching accum_* flag is non-zero and "=" otherwise.  Deterministic (no atomics).
+ * `workspace` (optional) enables the GQA head split described at usp_flash_bwd_workspace_bytes().
  * -------------------------------------------------------------------------------------------- */
 typedef struct usp_bwd_args {
   int32_t dtype;
@@ -107,9 +108,18 @@ typedef struct usp_bwd_args {
   int64_t delta_stride_b, delta_stride_h;
   usp_tensor dq, dk, dv;         /* fp32 outputs */
   int32_t accum_dq, accum_dk, accum_dv;
+  void* workspace;               /* optional scratch (device, 16-byte aligned), see below; may be NULL */
+  int64_t workspace_bytes;
 } usp_bwd_args;
 
 int usp_flash_bwd(const usp_bwd_args* args, void* stream);
+
+/* GQA (Hq > Hkv) only: bytes of scratch with which the dK/dV launch gives every query head of a KV
+ * group its own workgroups (per-head fp32 partials + one deterministic reduce) instead of looping the
+ * group inside one workgroup -- Hq/Hkv times more parallelism, which is what balances the causal
+ * triangle when B*Hkv*ceil(Sk/128) is small.  Returns 0 when Hq == Hkv.  Passing less (or NULL) is
+ * valid and selects the in-workgroup loop; results are identical up to fp32 summation order. */
+int64_t usp_flash_bwd_workspace_bytes(const usp_bwd_args* args);
 
 /* delta[b,h,s] = sum_d dout[b,s,h,d] * out[b,s,h,d]   (fp32; delta is (B,H,S), seq stride 1).
  * The "softmax_d" term flash-attn's backward derives from `out` (its 5th positional argument,

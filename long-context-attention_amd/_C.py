@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libusp_hip.so")
 _lib = None
 
 USP_BF16, USP_FP16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class UspTensor(ctypes.Structure):
@@ -49,10 +49,11 @@ class UspBwdArgs(ctypes.Structure):
                 ("delta_stride_b", ctypes.c_int64), ("delta_stride_h", ctypes.c_int64),
                 ("dq", UspTensor), ("dk", UspTensor), ("dv", UspTensor),
                 ("accum_dq", ctypes.c_int32), ("accum_dk", ctypes.c_int32),
-                ("accum_dv", ctypes.c_int32)]
+                ("accum_dv", ctypes.c_int32),
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64)]
 
 
-EXPORTS = ("usp_flash_fwd", "usp_flash_bwd", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
+EXPORTS = ("usp_flash_fwd", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
            "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror")
 
 
@@ -81,6 +82,8 @@ def load():
     i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
     L.usp_flash_fwd.argtypes = [ctypes.POINTER(UspFwdArgs), vp]
     L.usp_flash_bwd.argtypes = [ctypes.POINTER(UspBwdArgs), vp]
+    L.usp_flash_bwd_workspace_bytes.argtypes = [ctypes.POINTER(UspBwdArgs)]
+    L.usp_flash_bwd_workspace_bytes.restype = ctypes.c_int64
     L.usp_bwd_delta.argtypes = [i32, i32, i32, i32, i32, ctypes.POINTER(UspTensor),
                                 ctypes.POINTER(UspTensor), vp, i64, i64, vp]
     L.usp_lse_merge.argtypes = [i32, i32, i32, i32, i32, ctypes.POINTER(UspTensor), vp, i64, i64,
@@ -88,7 +91,8 @@ def load():
     L.usp_copy_rows.argtypes = [vp, vp] + [i64] * 13 + [vp]
     L.usp_cast_from_f32.argtypes = [i32, vp, i64, vp, i64, i64, i64, vp]
     L.usp_add_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, vp]
-    for name in EXPORTS[:7]:
+    for name in ("usp_flash_fwd", "usp_flash_bwd", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
+                 "usp_cast_from_f32", "usp_add_f32"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L
@@ -185,7 +189,13 @@ def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causa
             raise TypeError("dq/dk/dv buffers of usp_flash_bwd are fp32")
     a.dq, a.dk, a.dv = _t4(dq), _t4(dk), _t4(dv)
     a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
-    _check(load().usp_flash_bwd(ctypes.byref(a), _stream()), "usp_flash_bwd")
+    L = load()
+    need = L.usp_flash_bwd_workspace_bytes(ctypes.byref(a))     # > 0 only for GQA (head split)
+    ws = None
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)   # caching allocator; stream-ordered
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
+    _check(L.usp_flash_bwd(ctypes.byref(a), _stream()), "usp_flash_bwd")
 
 
 def lse_merge(acc, lse, blk_out, blk_lse, first: bool):

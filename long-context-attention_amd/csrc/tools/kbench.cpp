@@ -330,6 +330,8 @@ static int run_bwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, in
   a.lse = dlse; a.delta = ddelta;
   a.lse_stride_b = a.delta_stride_b = (int64_t)Hq * Sq; a.lse_stride_h = a.delta_stride_h = Sq;
   a.dq = bshd(gdq, Sq, Hq, D); a.dk = bshd(gdk, Sk, Hkv, D); a.dv = bshd(gdv, Sk, Hkv, D);
+  const int64_t wsb = getenv("USP_NO_WORKSPACE") ? 0 : usp_flash_bwd_workspace_bytes(&a);
+  if (wsb > 0) { a.workspace = dev_alloc<char>((size_t)wsb); a.workspace_bytes = wsb; }
   rc |= usp_flash_bwd(&a, nullptr);
   if (rc) { printf("BWD launch failed: %s\n", usp_strerror(rc)); return 1; }
   HIP_OK(hipDeviceSynchronize());

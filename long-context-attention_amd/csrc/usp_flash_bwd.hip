@@ -34,6 +34,8 @@ struct BwdParams {
   int causal_off;
   float scale, scale_log2;
   int accum_dq, accum_dk, accum_dv;
+  float* ws_dk; float* ws_dv;        // head-split partials [G][B][Sk][Hkv][D] fp32 (MODE 1, G > 1)
+  int split;                          // 1: one workgroup per (query head, key block)
 };
 
 constexpr int kTile = 64;           // streamed rows per LDS tile
@@ -57,8 +59,6 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   constexpr int BUFB = 2 * TILEB + STATB;
   constexpr int NKT = D / 16;
   constexpr int NDJ = D / 32;
-  constexpr int NCH = kTile * D / 8;
-  constexpr int NP = (NCH + NT - 1) / NT;
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   USP_LDS char* smem = (USP_LDS char*)smem_raw;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   int w = xcd_remap(blockIdx.x, gridDim.x);
   const int blk_r = w % p.nblk;
   int rest = w / p.nblk;
-  int b, hkv, h0, blk;
+  int b, hkv, h0, blk, split_g = 0;
   if (MODE == 0) {
     blk = CAUSAL ? (p.nblk - 1 - blk_r) : blk_r;          // late query blocks see most keys
     const int g = rest % p.G; rest /= p.G;
@@ -82,8 +82,11 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
     h0 = hkv * p.G + g;
   } else {
     blk = blk_r;                                           // early key blocks are seen by most rows
+    int g = 0;
+    if (p.split) { g = rest % p.G; rest /= p.G; }          // one query head of the GQA group per workgroup
     hkv = rest % p.Hkv; b = rest / p.Hkv;
-    h0 = hkv * p.G;
+    h0 = hkv * p.G + g;
+    split_g = g;
   }
   const int own0 = blk * OWN;                  // first owned row (query row / key)
   const int ow = own0 + wave * 32;             // first row owned by this wave
@@ -132,63 +135,96 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
     }
   }
   const int per_head = t_end - t_begin;
-  const int n_iter = MODE == 0 ? per_head : per_head * p.G;
+  const int n_iter = (MODE == 0 || p.split) ? per_head : per_head * p.G;
 
-  // ---- staging maps -----------------------------------------------------------------------------
-  int st_row[NP], st_goff[NP], st_loff[NP];
+  // ---- staging: LDS-DMA (buffer_load ... lds), no staging registers, no ds_write ---------------------
+  // One wave-instruction fills 1 KiB of LDS linearly (wave-uniform base + lane*16), i.e. 1024/ROWB
+  // whole tile rows.  The slot swizzle is therefore applied on the SOURCE: the lane that lands on
+  // physical slot p of row r fetches logical slot p ^ swz(r) of that row (same 16-byte chunks of the
+  // same row: coalescing is unaffected).  Rows past the end of the tensor read as 0 (descriptor
+  // bounds); hipcc drains the DMA (vmcnt(0)) in front of the s_barrier that ends the iteration.
+  constexpr int NW = NT / 64;                     // waves
+  constexpr int CHUNKS = TILEB / 1024;            // 1 KiB pieces per matrix tile
+  constexpr int CPW = (CHUNKS + NW - 1) / NW;     // pieces per wave per matrix
+  constexpr int RPC = 1024 / ROWB;                // tile rows per piece
+  int dma_voff1[CPW], dma_voff2[CPW];
+  const int64_t ss1 = MODE == 0 ? p.k_ss : p.q_ss;
+  const int64_t ss2 = MODE == 0 ? p.v_ss : p.do_ss;
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int c = i * NT + tid;
-    const int r = c / (D / 8), c8 = c % (D / 8);
-    st_row[i] = r;
-    st_goff[i] = c8 * 16;
-    st_loff[i] = r * ROWB + ((c8 ^ tile_swz<D>(r)) * 16);
+  for (int i = 0; i < CPW; ++i) {
+    const int cidx = wave + NW * i;
+    const int r = cidx * RPC + lane / (D / 8);
+    const int c8 = (lane % (D / 8)) ^ tile_swz<D>(r);
+    dma_voff1[i] = r * (int)ss1 * 2 + c8 * 16;
+    dma_voff2[i] = r * (int)ss2 * 2 + c8 * 16;
   }
-  u32x4 st1[NP], st2[NP];
   float st_lse = 0.f, st_delta = 0.f;
-  auto stage_load = [&](int it) {
-    int tile, hh;
-    if (MODE == 0) { tile = t_begin + it; hh = 0; }
-    else { hh = it / per_head; tile = t_begin + it % per_head; }
-    const int s0 = tile * kTile;
+  // Prefetch cursor: running 64-bit tile pointers / remaining-bytes counters / (tile, head) counters,
+  // advanced by additions only.  (Per-iteration 64-bit multiplies and the it/per_head division cost
+  // ~150 SALU instructions per tile, which nothing hides at one wave per SIMD.)
+  decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0)) rs1, rs2;
+  int dma_buf = 0;
+  const int64_t tb1 = (int64_t)kTile * ss1 * 2, tb2 = (int64_t)kTile * ss2 * 2;   // bytes per tile step
+  const int heads_here = (MODE == 0 || p.split) ? 1 : p.G;
+  int pf_tile = t_begin, pf_hh = 0;              // next tile to prefetch
+  const char *pf_p1 = nullptr, *pf_p2 = nullptr;
+  int64_t pf_rem1 = 0, pf_rem2 = 0;
+  auto pf_head = [&]() {                         // (re)base the cursor on head pf_hh, tile t_begin
     const char *b1, *b2;
-    int64_t ss1, ss2;
     if (MODE == 0) {
-      b1 = p.k + 2 * (b * p.k_sb + hkv * p.k_sh); ss1 = p.k_ss;
-      b2 = p.v + 2 * (b * p.v_sb + hkv * p.v_sh); ss2 = p.v_ss;
+      b1 = p.k + 2 * (b * p.k_sb + hkv * p.k_sh);
+      b2 = p.v + 2 * (b * p.v_sb + hkv * p.v_sh);
     } else {
-      b1 = p.q + 2 * (b * p.q_sb + (h0 + hh) * p.q_sh); ss1 = p.q_ss;
-      b2 = p.dout + 2 * (b * p.do_sb + (h0 + hh) * p.do_sh); ss2 = p.do_ss;
+      b1 = p.q + 2 * (b * p.q_sb + (h0 + pf_hh) * p.q_sh);
+      b2 = p.dout + 2 * (b * p.do_sb + (h0 + pf_hh) * p.do_sh);
     }
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      if (NCH % NT == 0 || i * NT + tid < NCH) {
-        int r = s0 + st_row[i];
-        r = r < str_len ? r : str_len - 1;
-        st1[i] = *(const u32x4*)(b1 + 2 * (int64_t)r * ss1 + st_goff[i]);
-        st2[i] = *(const u32x4*)(b2 + 2 * (int64_t)r * ss2 + st_goff[i]);
-      }
-    }
+    pf_tile = t_begin;
+    pf_p1 = b1 + t_begin * tb1;
+    pf_p2 = b2 + t_begin * tb2;
+    pf_rem1 = ((int64_t)(str_len - 1 - t_begin * kTile) * ss1 + D) * 2;
+    pf_rem2 = ((int64_t)(str_len - 1 - t_begin * kTile) * ss2 + D) * 2;
+  };
+  pf_head();
+  // build the descriptors for the cursor's tile, fetch its row statistics, then advance the cursor
+  auto stage_setup = [&](int buf) {
+    auto clampu = [](int64_t r) { return (int)(uint32_t)(r < 0 ? 0 : (r > 0xffffffffLL ? 0xffffffffLL : r)); };
+    rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)pf_p1, 0, clampu(pf_rem1), 0x00020000);
+    rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)pf_p2, 0, clampu(pf_rem2), 0x00020000);
+    dma_buf = buf;
     if (MODE == 1 && tid < kTile) {
-      const int r = s0 + tid;
+      const int r = pf_tile * kTile + tid;
       if (r < p.Sq) {
-        const float l_ = p.lse[b * p.lse_sb + (h0 + hh) * p.lse_sh + r];
+        const float l_ = p.lse[b * p.lse_sb + (h0 + pf_hh) * p.lse_sh + r];
         st_lse = (l_ == USP_NEG_INF) ? __builtin_inff() : l_ * kLog2e;
-        st_delta = p.delta[b * p.dl_sb + (h0 + hh) * p.dl_sh + r];
+        st_delta = p.delta[b * p.dl_sb + (h0 + pf_hh) * p.dl_sh + r];
       } else {
         st_lse = __builtin_inff();    // rows past the end contribute P = 0
         st_delta = 0.f;
       }
     }
+    ++pf_tile;
+    pf_p1 += tb1; pf_p2 += tb2; pf_rem1 -= tb1; pf_rem2 -= tb2;
+    if (heads_here > 1 && pf_tile == t_end) { ++pf_hh; pf_head(); }
   };
-  auto stage_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      if (NCH % NT == 0 || i * NT + tid < NCH) {
-        *(USP_LDS u32x4*)(smem + buf * BUFB + st_loff[i]) = st1[i];
-        *(USP_LDS u32x4*)(smem + buf * BUFB + TILEB + st_loff[i]) = st2[i];
-      }
+  // piece pi in [0, 2*CPW): matrix pi & 1, chunk wave + NW * (pi >> 1)
+  auto stage_piece = [&](int pi) {
+    const int i = pi >> 1;
+    const int cidx = wave + NW * i;
+    if (CHUNKS % NW == 0 || cidx < CHUNKS) {
+      USP_LDS char* d1 = smem + dma_buf * BUFB + cidx * 1024;
+#ifndef USP_ABLATE_NOSTAGE
+      if ((pi & 1) == 0) lds_dma16(rs1, d1, dma_voff1[i]);
+      else lds_dma16(rs2, d1 + TILEB, dma_voff2[i]);
+#else
+      (void)d1;
+#endif
     }
+  };
+  auto stage_all = [&]() {
+#pragma unroll
+    for (int pi = 0; pi < 2 * CPW; ++pi) stage_piece(pi);
+  };
+  auto stage_stats = [&](int buf) {
     if (MODE == 1 && tid < kTile) {
       *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * tid) = st_lse;
       *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * kTile + 4 * tid) = st_delta;
@@ -222,16 +258,31 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   for (int dj = 0; dj < NDJ; ++dj)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc1[dj][r] = 0.f; if (MODE == 1) acc2[dj][r] = 0.f; }
+  if (MODE == 1) {
+    // give the loop-carried accumulators an AGPR home from the start (see Elem::mfma_agpr)
+#pragma unroll
+    for (int dj = 0; dj < NDJ; ++dj) {
+      pin_agpr(acc1[dj]);
+      pin_agpr(acc2[dj]);
+    }
+  }
   const float c = p.scale_log2;
 
-  if (n_iter > 0) { stage_load(0); stage_store(0); }
+  if (n_iter > 0) { stage_setup(0); stage_all(); stage_stats(0); }
   __syncthreads();
 
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr int NST = 2 * NKT;                          // MFMAs of one S/T phase
+  constexpr int NGR = 2 * NDJ * (MODE == 1 ? 2 : 1);    // MFMAs of one gradient phase
+
+  int cur_tile = t_begin;                              // streamed tile of the current iteration
   for (int it = 0; it < n_iter; ++it) {
     const int buf = it & 1;
-    const int tile = t_begin + (MODE == 0 ? it : it % per_head);
+    const int tile = cur_tile;
+    cur_tile = (cur_tile + 1 == t_end) ? t_begin : cur_tile + 1;
     const int s0 = tile * kTile;                       // first streamed row of this tile
-    if (it + 1 < n_iter) stage_load(it + 1);
+    const bool prefetch = it + 1 < n_iter;
+    if (prefetch) stage_setup(buf ^ 1);
 
     bool active = true, need_mask = false;
     if (MODE == 0) {
@@ -250,91 +301,153 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
     }
 
     if (active) {
+      // Hand-pinned pipeline over the two 32-row halves h0, h1 of the tile (sched_barrier(0) fences;
+      // hipcc otherwise emits MFMA clusters and VALU clusters):
+      //   ST(h0) | ST(h1) || P,dS(h0) | GRAD(h0) || P,dS(h1) | GRAD(h1)
+      // LDS operands are prefetched two MFMAs ahead; the first MFMA of a chain takes C = 0.
       USP_LDS const char* x1 = smem + buf * BUFB;
       USP_LDS const char* x2 = x1 + TILEB;
-      u32x4 pk_ds[4], pk_p[MODE == 1 ? 4 : 1];
-#pragma unroll
-      for (int n32 = 0; n32 < 2; ++n32) {
-        f32x16 s, tt;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; tt[r] = 0.f; }
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-          const int a = n32 * 32 * ROWB + rd_row + (((2 * kt) ^ rd_x) * 16);
-          const u32x4 f1 = *(USP_LDS const u32x4*)(x1 + a);
-          const u32x4 f2 = *(USP_LDS const u32x4*)(x2 + a);
-          s = E::mfma(f1, r1[kt], s);
-          tt = E::mfma(f2, r2[kt], tt);
+      f32x16 sS[2], sT[2];
+      u32x4 pk_ds[2][2], pk_p[MODE == 1 ? 2 : 1][2];
+      f32x4 stl, std_;                                  // MODE 1: lse2 / delta of 4 consecutive rows
+
+      // stats of rows 4*g4 .. 4*g4+3 of half h (broadcast ds_read_b128, loaded just in time)
+      auto load_stats = [&](int h, int g4) {
+        if (MODE == 1) {
+          USP_LDS const char* stat = x1 + 2 * TILEB + (32 * h + 4 * hi) * 4 + 32 * g4;
+          stl = *(USP_LDS const f32x4*)stat;
+          std_ = *(USP_LDS const f32x4*)(stat + 4 * kTile);
         }
-        // streamed row of register r: s0 + 32 n32 + 8 (r>>2) + 4 hi + (r&3)
-        const int sr0 = s0 + 32 * n32 + 4 * hi;
-        if (need_mask) {
-          if (MODE == 0) {
-            int klim = p.Sk - 1;
-            if (CAUSAL) klim = orow + off < klim ? orow + off : klim;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (sr0 + (r & 3) + 8 * (r >> 2) > klim) s[r] = USP_NEG_INF;
-          } else {
-            // query row i sees key j iff j <= i + off
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (orow > sr0 + (r & 3) + 8 * (r >> 2) + off) s[r] = USP_NEG_INF;
-          }
-        }
-        float pr[16], dsr[16];
+      };
+      auto apply_mask = [&](int h) {
+        const int sr0 = s0 + 32 * h + 4 * hi;           // streamed row of register r: sr0 + 8(r>>2) + (r&3)
         if (MODE == 0) {
+          int klim = p.Sk - 1;
+          if (CAUSAL) klim = orow + off < klim ? orow + off : klim;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            pr[r] = fast_exp2(__builtin_fmaf(s[r], c, -lse2_l));
-            dsr[r] = pr[r] * (tt[r] - delta_l);
-          }
+          for (int r = 0; r < 16; ++r)
+            if (sr0 + (r & 3) + 8 * (r >> 2) > klim) sS[h][r] = USP_NEG_INF;
         } else {
-          USP_LDS const char* stat = x1 + 2 * TILEB + (32 * n32 + 4 * hi) * 4;
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const f32x4 l4 = *(USP_LDS const f32x4*)(stat + 32 * g4);
-            const f32x4 d4 = *(USP_LDS const f32x4*)(stat + 4 * kTile + 32 * g4);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int r = 4 * g4 + j;
-              pr[r] = fast_exp2(__builtin_fmaf(s[r], c, -l4[j]));
-              dsr[r] = pr[r] * (tt[r] - d4[j]);
-            }
-          }
+          for (int r = 0; r < 16; ++r)                   // query row i sees key j iff j <= i + off
+            if (orow > sr0 + (r & 3) + 8 * (r >> 2) + off) sS[h][r] = USP_NEG_INF;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          pk_ds[2 * n32][j] = E::pack2(dsr[2 * j], dsr[2 * j + 1]);
-          pk_ds[2 * n32 + 1][j] = E::pack2(dsr[8 + 2 * j], dsr[8 + 2 * j + 1]);
-          if (MODE == 1) {
-            pk_p[2 * n32][j] = E::pack2(pr[2 * j], pr[2 * j + 1]);
-            pk_p[2 * n32 + 1][j] = E::pack2(pr[8 + 2 * j], pr[8 + 2 * j + 1]);
-          }
+      };
+      // P and dS of element r of half h (+ pack when a pair completes)
+      auto elem = [&](int h, int r) {
+#ifdef USP_ABLATE_NOEXP
+        if (r & 1) {
+          pk_ds[h][r >> 3][(r & 7) >> 1] = __builtin_bit_cast(uint32_t, sT[h][r]);
+          if (MODE == 1) pk_p[h][r >> 3][(r & 7) >> 1] = __builtin_bit_cast(uint32_t, sS[h][r]);
         }
-      }
-      // gradient MFMAs: acc1^T += X1^T dS ; (MODE 1) acc2^T += X2^T P
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-        for (int dj = 0; dj < NDJ; ++dj) {
-          const int base = ks * 16 * ROWB;
-          const u32x2 a0 = lds_read_tr16(x1 + base + tr_addr[dj][0]);
-          const u32x2 a1 = lds_read_tr16(x1 + base + tr_addr[dj][1]);
-          const u32x4 xa = {a0[0], a0[1], a1[0], a1[1]};
-          acc1[dj] = E::mfma(xa, pk_ds[ks], acc1[dj]);
-          if (MODE == 1) {
-            const u32x2 b0 = lds_read_tr16(x2 + base + tr_addr[dj][0]);
-            const u32x2 b1 = lds_read_tr16(x2 + base + tr_addr[dj][1]);
-            const u32x4 xb = {b0[0], b0[1], b1[0], b1[1]};
-            acc2[dj] = E::mfma(xb, pk_p[ks], acc2[dj]);
-          }
+        return;
+#endif
+        float pr, ds;
+        if (MODE == 0) {
+          pr = fast_exp2(__builtin_fmaf(sS[h][r], c, -lse2_l));
+          ds = pr * (sT[h][r] - delta_l);
+        } else {
+          if ((r & 3) == 0) load_stats(h, r >> 2);
+          pr = fast_exp2(__builtin_fmaf(sS[h][r], c, -stl[r & 3]));
+          ds = pr * (sT[h][r] - std_[r & 3]);
         }
-      }
+        sS[h][r] = pr;
+        sT[h][r] = ds;
+        if (r & 1) {
+          pk_ds[h][r >> 3][(r & 7) >> 1] = E::pack2(sT[h][r - 1], sT[h][r]);
+          if (MODE == 1) pk_p[h][r >> 3][(r & 7) >> 1] = E::pack2(sS[h][r - 1], sS[h][r]);
+        }
+      };
+      // S/T phase of half h; `vh` >= 0: interleave the element work of half vh
+      // `dma`: also issue this wave's LDS-DMA pieces of the next tile, spread over the MFMA slots
+      // (a piece costs 60-185 issue cycles; eight back-to-back would idle the matrix pipe)
+      auto st_phase = [&](int h, int vh, bool dma) {
+        u32x4 f1[NKT], f2[NKT];
+        auto rd = [&](int kt) {
+          const int a = h * 32 * ROWB + rd_row + (((2 * kt) ^ rd_x) * 16);
+#ifdef USP_ABLATE_NOLDS
+          f1[kt] = r1[(kt + 1) % NKT]; f2[kt] = r2[(kt + 1) % NKT]; (void)a;
+#else
+          f1[kt] = *(USP_LDS const u32x4*)(x1 + a);
+          f2[kt] = *(USP_LDS const u32x4*)(x2 + a);
+#endif
+        };
+        rd(0);
+        if (NKT > 1) rd(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int sl = 0; sl < NST; ++sl) {
+          const int kt = sl >> 1;
+          if ((sl & 1) == 0) {
+            if (kt + 2 < NKT) rd(kt + 2);
+            sS[h] = E::mfma(f1[kt], r1[kt], kt == 0 ? zero16 : sS[h]);
+          } else {
+            sT[h] = E::mfma(f2[kt], r2[kt], kt == 0 ? zero16 : sT[h]);
+          }
+          if (vh >= 0) {
+#pragma unroll
+            for (int e = sl * 16 / NST; e < (sl + 1) * 16 / NST; ++e) elem(vh, e);
+          }
+          if (dma) {
+#pragma unroll
+            for (int pi = sl * 2 * CPW / NST; pi < (sl + 1) * 2 * CPW / NST; ++pi) stage_piece(pi);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      // gradient phase of half h; `vh` >= 0: interleave the element work of half vh
+      auto grad_phase = [&](int h, int vh) {
+        u32x4 xa[NGR];
+        auto rd = [&](int i) {                           // i -> (k2, dj, which matrix)
+          const int m = MODE == 1 ? (i & 1) : 0;
+          const int j = MODE == 1 ? (i >> 1) : i;
+          const int k2 = j / NDJ, dj = j % NDJ;
+          USP_LDS const char* xb = (m ? x2 : x1) + (2 * h + k2) * 16 * ROWB;
+#ifdef USP_ABLATE_NOLDS
+          xa[i] = r1[(i + dj) % NKT]; (void)xb;
+#else
+          const u32x2 a0 = lds_read_tr16(xb + tr_addr[dj][0]);
+          const u32x2 a1 = lds_read_tr16(xb + tr_addr[dj][1]);
+          xa[i] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+#endif
+        };
+        rd(0);
+        if (NGR > 1) rd(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NGR; ++i) {
+          if (i + 2 < NGR) rd(i + 2);
+          const int m = MODE == 1 ? (i & 1) : 0;
+          const int j = MODE == 1 ? (i >> 1) : i;
+          const int k2 = j / NDJ, dj = j % NDJ;
+          if (MODE == 1) {                                 // 512-register kernel: accumulators pinned to AGPRs
+            if (m == 0) E::mfma_agpr(acc1[dj], xa[i], pk_ds[h][k2]);
+            else E::mfma_agpr(acc2[dj], xa[i], pk_p[h][k2]);
+          } else {
+            acc1[dj] = E::mfma(xa[i], pk_ds[h][k2], acc1[dj]);
+          }
+          if (vh >= 0) {
+#pragma unroll
+            for (int e = i * 16 / NGR; e < (i + 1) * 16 / NGR; ++e) elem(vh, e);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+
+      st_phase(0, -1, prefetch);
+      if (need_mask) apply_mask(0);
+      st_phase(1, 0, false);
+      if (need_mask) apply_mask(1);
+      grad_phase(0, 1);
+      grad_phase(1, -1);
+    } else if (prefetch) {
+      stage_all();
     }
 
-    if (it + 1 < n_iter) stage_store(buf ^ 1);
+    if (it + 1 < n_iter) stage_stats(buf ^ 1);
+#ifndef USP_ABLATE_NOBARRIER
     __syncthreads();
+#endif
   }
 
   // ---- epilogue: fp32 store / accumulate ------------------------------------------------------------
@@ -344,8 +457,14 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
     if (MODE == 0) {
       o1 = p.dq + b * p.dq_sb + (int64_t)orow * p.dq_ss + h0 * p.dq_sh; acc_f1 = p.accum_dq;
     } else {
-      o1 = p.dk + b * p.dk_sb + (int64_t)orow * p.dk_ss + hkv * p.dk_sh; acc_f1 = p.accum_dk;
-      o2 = p.dv + b * p.dv_sb + (int64_t)orow * p.dv_ss + hkv * p.dv_sh; acc_f2 = p.accum_dv;
+      if (p.split) {   // per-head partial, combined (deterministically) by reduce_heads_kernel
+        const int64_t wo = ((((int64_t)split_g * p.B + b) * p.Sk + orow) * p.Hkv + hkv) * D;
+        o1 = p.ws_dk + wo; acc_f1 = 0;
+        o2 = p.ws_dv + wo; acc_f2 = 0;
+      } else {
+        o1 = p.dk + b * p.dk_sb + (int64_t)orow * p.dk_ss + hkv * p.dk_sh; acc_f1 = p.accum_dk;
+        o2 = p.dv + b * p.dv_sb + (int64_t)orow * p.dv_ss + hkv * p.dv_sh; acc_f2 = p.accum_dv;
+      }
     }
 #pragma unroll
     for (int dj = 0; dj < NDJ; ++dj)
@@ -366,18 +485,59 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   }
 }
 
+// dst[b,s,h,:] (+)= sum_g ws[g][b][s][h][:]   -- combines the per-query-head dK / dV partials
+template <int D>
+__global__ __launch_bounds__(256) void reduce_heads_kernel(const float* ws_k, const float* ws_v,
+                                                           float* dk, float* dv, int64_t dk_sb,
+                                                           int64_t dk_ss, int64_t dk_sh, int64_t dv_sb,
+                                                           int64_t dv_ss, int64_t dv_sh, int B, int S, int H,
+                                                           int G, int acc_k, int acc_v) {
+  constexpr int C4 = D / 4;
+  const int64_t rows = (int64_t)B * S * H;
+  const int64_t total = rows * C4;
+  const int64_t gstride = rows * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    const int64_t r = i / C4;
+    const int h = (int)(r % H);
+    const int64_t bs = r / H;
+    const int sidx = (int)(bs % S);
+    const int b = (int)(bs / S);
+    float* pk = dk + b * dk_sb + (int64_t)sidx * dk_ss + h * dk_sh + 4 * c4;
+    float* pv = dv + b * dv_sb + (int64_t)sidx * dv_ss + h * dv_sh + 4 * c4;
+    f32x4 ak = acc_k ? *(const f32x4*)pk : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 av = acc_v ? *(const f32x4*)pv : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t o = r * D + 4 * c4;
+    for (int g = 0; g < G; ++g) {
+      ak += *(const f32x4*)(ws_k + g * gstride + o);
+      av += *(const f32x4*)(ws_v + g * gstride + o);
+    }
+    *(f32x4*)pk = ak;
+    *(f32x4*)pv = av;
+  }
+}
+
 template <int D, int DT>
 static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   constexpr size_t lds0 = 2 * (2 * kTile * D * 2);
   constexpr size_t lds1 = 2 * (2 * kTile * D * 2 + 2 * kTile * 4);
   // dK,dV
   p.nblk = (p.Sk + 127) / 128;
-  int grid = p.B * p.Hkv * p.nblk;
+  int grid = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1);
   if (causal)
     hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 1>), dim3(grid), dim3(256), lds1, st, p);
   else
     hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 1>), dim3(grid), dim3(256), lds1, st, p);
   if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
+  if (p.split) {
+    const int64_t items = (int64_t)p.B * p.Sk * p.Hkv * (D / 4);
+    int64_t rg = (items + 255) / 256;
+    rg = rg > 2048 ? 2048 : rg;
+    hipLaunchKernelGGL((reduce_heads_kernel<D>), dim3((int)rg), dim3(256), 0, st, p.ws_dk, p.ws_dv, p.dk,
+                       p.dv, p.dk_sb, p.dk_ss, p.dk_sh, p.dv_sb, p.dv_ss, p.dv_sh, p.B, p.Sk, p.Hkv, p.G,
+                       p.accum_dk, p.accum_dv);
+    if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
+  }
   // dQ
   p.nblk = (p.Sq + 255) / 256;
   grid = p.B * p.Hq * p.nblk;
@@ -395,6 +555,11 @@ static bool ok16(const usp_tensor& t, int esize) {
 }
 
 }  // namespace usp
+
+extern "C" int64_t usp_flash_bwd_workspace_bytes(const usp_bwd_args* a) {
+  if (!a || a->Hkv <= 0 || a->Hq <= a->Hkv || a->Hq % a->Hkv != 0) return 0;
+  return 2LL * a->Hq / a->Hkv * a->B * a->Sk * a->Hkv * a->D * 4;   // dK and dV partials, fp32
+}
 
 extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   using namespace usp;
@@ -429,6 +594,16 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   p.scale = a->softmax_scale;
   p.scale_log2 = a->softmax_scale * kLog2e;
   p.accum_dq = a->accum_dq ? 1 : 0; p.accum_dk = a->accum_dk ? 1 : 0; p.accum_dv = a->accum_dv ? 1 : 0;
+  // GQA head split: with a workspace, every query head of a KV group gets its own workgroups and the
+  // per-head partials are summed afterwards; without one the group's heads are looped inside a workgroup.
+  const int64_t need = usp_flash_bwd_workspace_bytes(a);
+  p.split = 0; p.ws_dk = nullptr; p.ws_dv = nullptr;
+  if (need > 0 && a->workspace && a->workspace_bytes >= need &&
+      (reinterpret_cast<uintptr_t>(a->workspace) & 15) == 0) {
+    p.split = 1;
+    p.ws_dk = (float*)a->workspace;
+    p.ws_dv = p.ws_dk + need / 8;
+  }
   hipStream_t st = (hipStream_t)stream;
   const bool causal = a->causal != 0;
   switch (a->D * 2 + a->dtype) {

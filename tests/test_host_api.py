@@ -18,14 +18,14 @@ def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "usp_hip.h")).read()
     declared = set(re.findall(r"\b(usp_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"usp_tensor"}
-    assert {"usp_flash_fwd", "usp_flash_bwd", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
+    assert {"usp_flash_fwd", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
             "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror"} <= declared
     lib = ctypes.CDLL(_C.lib_path())
     for name in declared:
         assert hasattr(lib, name), f"libusp_hip.so does not export {name}"
     assert set(_C.EXPORTS) == declared
     L = _C.load()
-    assert L.usp_abi_version() == 1
+    assert L.usp_abi_version() == 2
     assert b"head_dim" in L.usp_strerror(-2)
 
 
