@@ -118,21 +118,44 @@ def kernel_roofline(cfg, dev, iters=20):
     achieved = fwd_flops(B, Hq, S, D) / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "usp::flash_fwd_kernel<128,bf16,causal>", "achieved": round(achieved, 1),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4),
-            "kernel_ms": round(ms, 4), "traffic": None}
+            "kernel_ms": round(ms, 4), "traffic": pmc_traffic()}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the forward kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_rocprof_v1_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+    passes, C2 shape).  Counters cannot be collected inside this process; null if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_rocprof_v1_summary.txt")
+    try:
+        rd = wr = None
+        for ln in open(path):
+            if "HBM read bytes/launch" in ln and rd is None:
+                rd = float(ln.split("=")[1].split("MB")[0])
+            if "HBM write bytes/launch" in ln and wr is None:
+                wr = float(ln.split("=")[1].split("MB")[0])
+        if rd is None or wr is None:
+            return None
+        return {"read_MB": rd, "write_MB": wr, "algorithmic_MB": 268.4,
+                "source": "profiles/r01_rocprof_v1_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+    except OSError:
+        return None
 
 
 def cpu_baseline(cfg):
     """The CPU port (oracle/attn_oracle.c, OpenMP over (batch, head)) and the torch CPU op the
     reference's TORCH_EFFICIENT path falls back to, on a bounded sample of the N=1 workload."""
     cores = os.cpu_count() or 1
-    S, D = 2048, cfg["D"]
-    H = max(2, min(cores, 16))
+    D = cfg["D"]
+    # bounded sample: the workload's own sequence length, as many (batch, head) problems as there are
+    # cores to run them side by side, capped at the workload's 32 -- about 10-30 s of CPU work
+    S = cfg["S"]
+    H = max(1, min(cores, cfg["Hq"] * cfg["B"]))
     rs = np.random.RandomState(0)
     q, k, v = (rs.standard_normal((1, S, H, D)).astype(np.float32) for _ in range(3))
     fl = fwd_flops(1, H, S, D)
-    res = {"unit": "TFLOP/s", "cores": cores, "kind": "port",
-           "sample": f"causal fwd B1 S{S} H{H} D{D} fp32 (same per-head problem as the workload, "
-                     f"1/16 of its sequence); oracle/attn_oracle.c with OpenMP"}
+    res = {"unit": "TFLOP/s", "cores": cores, "threads_used": H, "kind": "port",
+           "sample": f"causal fwd, {H} of the workload's {cfg['Hq'] * cfg['B']} (batch, head) problems at its full "
+                     f"S={S}, D={D}, fp32 in / fp64 accumulate; oracle/attn_oracle.c, OpenMP over heads"}
     so = os.path.join(ROOT, "oracle", "libattn_oracle.so")
     try:
         L = ctypes.CDLL(so)
@@ -163,13 +186,87 @@ def cpu_baseline(cfg):
     return res
 
 
+def barrier(ws):
+    if ws > 1:            # a barrier over one rank is empty; NCCL would still launch an all-reduce for it
+        dist.barrier()
+
+
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def timed(step, steps, ws, dev):
+    """K steps bracketed by barrier + synchronize on both sides; max over ranks; seconds per step."""
+    _sync(dev)
+    barrier(ws)
+    _sync(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    _sync(dev)
+    barrier(ws)
+    _sync(dev)
+    dt = time.perf_counter() - t0
+    if ws > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    return dt / steps
+
+
+class _NoCompute:
+    """comm-only run: every kernel of the block backend is skipped (buffers stay uninitialised)."""
+    name = "none"
+
+    def __getattr__(self, _):
+        return lambda *a, **k: None
+
+
+def overlap_probe(step, steps, ws, dev, t_iter):
+    """overlap = 1 - (t_iter - t_compute_only) / t_comm_only   (SURVEY.md section 8d)."""
+    import yunchang_amd.comm.all_to_all as A
+    import yunchang_amd.ring.utils as U
+    from yunchang_amd.kernels import set_block_backend
+    # compute-only: same schedule, the wire replaced by local buffers
+    ex, commit, wait = A._exchange, U.RingComm.commit, U.RingComm.wait
+    A._exchange = lambda send, group, use_sync: send
+
+    def local_commit(self):
+        for snd, rcv in zip(self._ops[0::2], self._ops[1::2]):
+            rcv.tensor.copy_(snd.tensor)
+        self._reqs = []
+    U.RingComm.commit = local_commit
+    try:
+        for _ in range(2):
+            step()
+        t_comp = timed(step, steps, ws, dev)
+    finally:
+        A._exchange, U.RingComm.commit, U.RingComm.wait = ex, commit, wait
+    # comm-only: same schedule, every kernel skipped
+    prev = set_block_backend(_NoCompute())
+    try:
+        for _ in range(2):
+            step()
+        t_comm = timed(step, steps, ws, dev)
+    finally:
+        set_block_backend(prev)
+    ov = 1.0 - (t_iter - t_comp) / t_comm if t_comm > 0 else None
+    return {"definition": "1 - (t_iter - t_compute_only) / t_comm_only", "value": None if ov is None else round(ov, 4),
+            "ms_iter": round(t_iter * 1e3, 4), "ms_compute_only": round(t_comp * 1e3, 4),
+            "ms_comm_only": round(t_comm * 1e3, 4),
+            "note": "comm-only skips every kernel (incl. pack/unpack); compute-only replaces each transfer by a "
+                    "local copy of the same size"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="skip the compute-only / comm-only runs (N > 1)")
     ap.add_argument("--bwd", type=int, default=-1, help="override: 1 = fwd+bwd, 0 = fwd only")
     args = ap.parse_args()
 
@@ -212,31 +309,32 @@ def main():
     parity = None
     out = step()
     if not args.no_parity:
-        parity = parity_check(cfg, rank, ws, out.detach(), q, k, v)
-        pt = torch.tensor([parity], device=dev)
-        dist.all_reduce(pt, op=dist.ReduceOp.MAX)
-        parity = float(pt.item())
+        try:
+            parity = parity_check(cfg, rank, ws, out.detach(), q, k, v)
+        except Exception as e:                      # never let the optional check kill the measurement
+            print(f"[rank {rank}] parity check failed to run: {e!r}", file=sys.stderr)
+            parity = float("nan")
+        if ws > 1:
+            pt = torch.tensor([parity], device=dev)
+            dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+            parity = float(pt.item())
     del q, k, v, do, out
     for _ in range(args.warmup):
         step()
 
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = timed(step, args.steps, ws, dev) * args.steps
 
     ms = dt / args.steps * 1e3
     flops = fwd_flops(cfg["B"], cfg["Hq"], cfg["S"], cfg["D"]) * (3.5 if cfg["bwd"] else 1.0)
     value = flops / (ms * 1e-3) / 1e12
+
+    overlap = None
+    if ws > 1 and not args.no_overlap:
+        try:
+            overlap = overlap_probe(step, max(3, args.steps // 4), ws, dev, ms * 1e-3)
+        except Exception as e:
+            print(f"[rank {rank}] overlap probe failed to run: {e!r}", file=sys.stderr)
+            overlap = {"value": None, "error": repr(e)}
 
     if rank == 0:
         line = {
@@ -252,12 +350,14 @@ def main():
             "frac_of_mfma_roofline": round(value / (ws * PEAK_BF16_TFLOPS), 4),
             "parity_max_abs_err_vs_single_gpu_kernel": parity,
         }
+        if overlap is not None:
+            line["overlap"] = overlap
         if ws == 1:
             line["roofline"] = kernel_roofline(cfg, dev)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
-    dist.barrier()
+    barrier(ws)
     dist.destroy_process_group()
 
 

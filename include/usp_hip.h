@@ -106,8 +106,11 @@ typedef struct usp_bwd_args {
   const float* delta;            /* (B,Hq,Sq), seq stride 1 */
   int64_t lse_stride_b, lse_stride_h;
   int64_t delta_stride_b, delta_stride_h;
-  usp_tensor dq, dk, dv;         /* fp32 outputs */
+  usp_tensor dq, dk, dv;         /* fp32 outputs / accumulators */
   int32_t accum_dq, accum_dk, accum_dv;
+  usp_tensor dq16, dk16, dv16;   /* optional 16-bit FINAL outputs (ptr may be NULL): when set, the
+                                    result ((accum ? X : 0) + block) is rounded to `dtype` and stored
+                                    there instead of being written back to the fp32 tensor X */
   void* workspace;               /* optional scratch (device, 16-byte aligned), see below; may be NULL */
   int64_t workspace_bytes;
 } usp_bwd_args;

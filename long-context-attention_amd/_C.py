@@ -50,6 +50,7 @@ class UspBwdArgs(ctypes.Structure):
                 ("dq", UspTensor), ("dk", UspTensor), ("dv", UspTensor),
                 ("accum_dq", ctypes.c_int32), ("accum_dk", ctypes.c_int32),
                 ("accum_dv", ctypes.c_int32),
+                ("dq16", UspTensor), ("dk16", UspTensor), ("dv16", UspTensor),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64)]
 
 
@@ -171,9 +172,11 @@ def bwd_delta(dout, out, delta):
 
 
 def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causal: bool,
-              accum_dq=False, accum_dk=False, accum_dv=False):
-    """usp_flash_bwd.  dq/dk/dv are fp32 (B,S,H,D) views, written or accumulated."""
-    _require_cuda(dout, q, k, v, lse, delta, dq, dk, dv)
+              accum_dq=False, accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None):
+    """usp_flash_bwd.  dq/dk/dv are fp32 (B,S,H,D) views, written or accumulated; a 16-bit
+    dq16/dk16/dv16 receives the FINAL rounded result instead (the fp32 tensor may then be None
+    unless it is accumulated from)."""
+    _require_cuda(dout, q, k, v, lse, delta, dq, dk, dv, dq16, dk16, dv16)
     B, Sq, Hq, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
     a = UspBwdArgs()
@@ -185,9 +188,10 @@ def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causa
     a.lse, a.lse_stride_b, a.lse_stride_h = _lse3(lse)
     a.delta, a.delta_stride_b, a.delta_stride_h = _lse3(delta)
     for t in (dq, dk, dv):
-        if t.dtype != torch.float32:
+        if t is not None and t.dtype != torch.float32:
             raise TypeError("dq/dk/dv buffers of usp_flash_bwd are fp32")
     a.dq, a.dk, a.dv = _t4(dq), _t4(dk), _t4(dv)
+    a.dq16, a.dk16, a.dv16 = _t4(dq16), _t4(dk16), _t4(dv16)
     a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
     L = load()
     need = L.usp_flash_bwd_workspace_bytes(ctypes.byref(a))     # > 0 only for GQA (head split)

@@ -34,6 +34,8 @@ struct BwdParams {
   int causal_off;
   float scale, scale_log2;
   int accum_dq, accum_dk, accum_dv;
+  char* dq16; char* dk16; char* dv16;   // optional 16-bit final outputs
+  int64_t dq16_sb, dq16_ss, dq16_sh, dk16_sb, dk16_ss, dk16_sh, dv16_sb, dv16_ss, dv16_sh;
   float* ws_dk; float* ws_dv;        // head-split partials [G][B][Sk][Hkv][D] fp32 (MODE 1, G > 1)
   int split;                          // 1: one workgroup per (query head, key block)
 };
@@ -450,12 +452,14 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 #endif
   }
 
-  // ---- epilogue: fp32 store / accumulate ------------------------------------------------------------
+  // ---- epilogue: fp32 store / accumulate, or final 16-bit store ---------------------------------------
   if (orow < own_len) {
     float* o1; float* o2 = nullptr;
+    char* h1 = nullptr; char* h2 = nullptr;      // 16-bit final destinations (row base), if any
     int acc_f1, acc_f2 = 0;
     if (MODE == 0) {
       o1 = p.dq + b * p.dq_sb + (int64_t)orow * p.dq_ss + h0 * p.dq_sh; acc_f1 = p.accum_dq;
+      if (p.dq16) h1 = p.dq16 + 2 * (b * p.dq16_sb + (int64_t)orow * p.dq16_ss + h0 * p.dq16_sh);
     } else {
       if (p.split) {   // per-head partial, combined (deterministically) by reduce_heads_kernel
         const int64_t wo = ((((int64_t)split_g * p.B + b) * p.Sk + orow) * p.Hkv + hkv) * D;
@@ -464,6 +468,8 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
       } else {
         o1 = p.dk + b * p.dk_sb + (int64_t)orow * p.dk_ss + hkv * p.dk_sh; acc_f1 = p.accum_dk;
         o2 = p.dv + b * p.dv_sb + (int64_t)orow * p.dv_ss + hkv * p.dv_sh; acc_f2 = p.accum_dv;
+        if (p.dk16) h1 = p.dk16 + 2 * (b * p.dk16_sb + (int64_t)orow * p.dk16_ss + hkv * p.dk16_sh);
+        if (p.dv16) h2 = p.dv16 + 2 * (b * p.dv16_sb + (int64_t)orow * p.dv16_ss + hkv * p.dv16_sh);
       }
     }
 #pragma unroll
@@ -474,24 +480,27 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
         f32x4 v1 = {acc1[dj][4 * g4] * p.scale, acc1[dj][4 * g4 + 1] * p.scale,
                     acc1[dj][4 * g4 + 2] * p.scale, acc1[dj][4 * g4 + 3] * p.scale};
         if (acc_f1) v1 += *(const f32x4*)(o1 + d0);
-        *(f32x4*)(o1 + d0) = v1;
+        if (h1) *(u32x2*)(h1 + 2 * d0) = u32x2{E::pack2(v1[0], v1[1]), E::pack2(v1[2], v1[3])};
+        else *(f32x4*)(o1 + d0) = v1;
         if (MODE == 1) {
           f32x4 v2 = {acc2[dj][4 * g4], acc2[dj][4 * g4 + 1], acc2[dj][4 * g4 + 2],
                       acc2[dj][4 * g4 + 3]};
           if (acc_f2) v2 += *(const f32x4*)(o2 + d0);
-          *(f32x4*)(o2 + d0) = v2;
+          if (h2) *(u32x2*)(h2 + 2 * d0) = u32x2{E::pack2(v2[0], v2[1]), E::pack2(v2[2], v2[3])};
+          else *(f32x4*)(o2 + d0) = v2;
         }
       }
   }
 }
 
 // dst[b,s,h,:] (+)= sum_g ws[g][b][s][h][:]   -- combines the per-query-head dK / dV partials
-template <int D>
+template <int D, int DT>
 __global__ __launch_bounds__(256) void reduce_heads_kernel(const float* ws_k, const float* ws_v,
                                                            float* dk, float* dv, int64_t dk_sb,
                                                            int64_t dk_ss, int64_t dk_sh, int64_t dv_sb,
                                                            int64_t dv_ss, int64_t dv_sh, int B, int S, int H,
-                                                           int G, int acc_k, int acc_v) {
+                                                           int G, int acc_k, int acc_v, BwdParams p) {
+  using E = Elem<DT>;
   constexpr int C4 = D / 4;
   const int64_t rows = (int64_t)B * S * H;
   const int64_t total = rows * C4;
@@ -512,8 +521,18 @@ __global__ __launch_bounds__(256) void reduce_heads_kernel(const float* ws_k, co
       ak += *(const f32x4*)(ws_k + g * gstride + o);
       av += *(const f32x4*)(ws_v + g * gstride + o);
     }
-    *(f32x4*)pk = ak;
-    *(f32x4*)pv = av;
+    if (p.dk16) {
+      char* hk = p.dk16 + 2 * (b * p.dk16_sb + (int64_t)sidx * p.dk16_ss + h * p.dk16_sh + 4 * c4);
+      *(u32x2*)hk = u32x2{E::pack2(ak[0], ak[1]), E::pack2(ak[2], ak[3])};
+    } else {
+      *(f32x4*)pk = ak;
+    }
+    if (p.dv16) {
+      char* hv = p.dv16 + 2 * (b * p.dv16_sb + (int64_t)sidx * p.dv16_ss + h * p.dv16_sh + 4 * c4);
+      *(u32x2*)hv = u32x2{E::pack2(av[0], av[1]), E::pack2(av[2], av[3])};
+    } else {
+      *(f32x4*)pv = av;
+    }
   }
 }
 
@@ -533,9 +552,9 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
     const int64_t items = (int64_t)p.B * p.Sk * p.Hkv * (D / 4);
     int64_t rg = (items + 255) / 256;
     rg = rg > 2048 ? 2048 : rg;
-    hipLaunchKernelGGL((reduce_heads_kernel<D>), dim3((int)rg), dim3(256), 0, st, p.ws_dk, p.ws_dv, p.dk,
+    hipLaunchKernelGGL((reduce_heads_kernel<D, DT>), dim3((int)rg), dim3(256), 0, st, p.ws_dk, p.ws_dv, p.dk,
                        p.dv, p.dk_sb, p.dk_ss, p.dk_sh, p.dv_sb, p.dv_ss, p.dv_sh, p.B, p.Sk, p.Hkv, p.G,
-                       p.accum_dk, p.accum_dv);
+                       p.accum_dk, p.accum_dv, p);
     if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
   }
   // dQ
@@ -569,10 +588,19 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   if (!(a->softmax_scale > 0.f)) return USP_EINVAL;
   if (a->D != 32 && a->D != 64 && a->D != 128) return USP_EUNSUPPORTED;
   if (a->Hq % a->Hkv != 0) return USP_EUNSUPPORTED;
-  if (!a->dout.ptr || !a->q.ptr || !a->k.ptr || !a->v.ptr || !a->dq.ptr || !a->dk.ptr || !a->dv.ptr)
+  if (!a->dout.ptr || !a->q.ptr || !a->k.ptr || !a->v.ptr) return USP_EINVAL;
+  // an fp32 tensor may be absent only if its 16-bit final output is given and nothing is accumulated
+  auto need32 = [](const usp_tensor& t32, const usp_tensor& t16, int accum) { return !t16.ptr || accum; };
+  if ((need32(a->dq, a->dq16, a->accum_dq) && !a->dq.ptr) || (need32(a->dk, a->dk16, a->accum_dk) && !a->dk.ptr) ||
+      (need32(a->dv, a->dv16, a->accum_dv) && !a->dv.ptr))
     return USP_EINVAL;
-  if (!ok16(a->dout, 2) || !ok16(a->q, 2) || !ok16(a->k, 2) || !ok16(a->v, 2) || !ok16(a->dq, 4) ||
-      !ok16(a->dk, 4) || !ok16(a->dv, 4))
+  auto ok32 = [](const usp_tensor& t) { return !t.ptr || ok16(t, 4); };
+  auto okh = [](const usp_tensor& t) {
+    return !t.ptr || ((reinterpret_cast<uintptr_t>(t.ptr) & 7) == 0 && t.stride_b % 4 == 0 &&
+                      t.stride_s % 4 == 0 && t.stride_h % 4 == 0);
+  };
+  if (!ok16(a->dout, 2) || !ok16(a->q, 2) || !ok16(a->k, 2) || !ok16(a->v, 2) || !ok32(a->dq) ||
+      !ok32(a->dk) || !ok32(a->dv) || !okh(a->dq16) || !okh(a->dk16) || !okh(a->dv16))
     return USP_EUNSUPPORTED;
   BwdParams p;
   p.dout = (const char*)a->dout.ptr; p.q = (const char*)a->q.ptr;
@@ -594,6 +622,10 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   p.scale = a->softmax_scale;
   p.scale_log2 = a->softmax_scale * kLog2e;
   p.accum_dq = a->accum_dq ? 1 : 0; p.accum_dk = a->accum_dk ? 1 : 0; p.accum_dv = a->accum_dv ? 1 : 0;
+  p.dq16 = (char*)a->dq16.ptr; p.dk16 = (char*)a->dk16.ptr; p.dv16 = (char*)a->dv16.ptr;
+  p.dq16_sb = a->dq16.stride_b; p.dq16_ss = a->dq16.stride_s; p.dq16_sh = a->dq16.stride_h;
+  p.dk16_sb = a->dk16.stride_b; p.dk16_ss = a->dk16.stride_s; p.dk16_sh = a->dk16.stride_h;
+  p.dv16_sb = a->dv16.stride_b; p.dv16_ss = a->dv16.stride_s; p.dv16_sh = a->dv16.stride_h;
   // GQA head split: with a workspace, every query head of a KV group gets its own workgroups and the
   // per-head partials are summed afterwards; without one the group's heads are looped inside a workgroup.
   const int64_t need = usp_flash_bwd_workspace_bytes(a);

@@ -29,9 +29,9 @@ class HipBlockBackend:
         _C.bwd_delta(dout, out, delta)
 
     def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
-            accum_dk=False, accum_dv=False):
+            accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None):
         _C.flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq,
-                     accum_dk, accum_dv)
+                     accum_dk, accum_dv, dq16, dk16, dv16)
 
     def merge(self, acc, lse, blk_out, blk_lse, first):
         _C.lse_merge(acc, lse, blk_out, blk_lse, first)
@@ -109,17 +109,16 @@ def hip_attn_backward(dout, q, k, v, out, softmax_lse, block_dq_buffer, block_dk
     lse = softmax_lse if softmax_lse.dtype == torch.float32 else softmax_lse.float()
     if lse.stride(-1) != 1:
         lse = lse.contiguous()
-    dq = torch.empty(q.shape, dtype=torch.float32, device=dev)
-    dk = torch.empty(k.shape, dtype=torch.float32, device=dev)
-    dv = torch.empty(v.shape, dtype=torch.float32, device=dev)
-    be.bwd(dout, q, k, v, lse, delta, dq, dk, dv, _default_scale(q, softmax_scale), bool(bwd_causal))
-    for src, dst in ((dq, block_dq_buffer), (dk, block_dk_buffer), (dv, block_dv_buffer)):
-        if dst.is_contiguous() or (dst.dim() == 4 and dst[0].is_contiguous()):
-            be.cast(dst, src)
-        else:
-            tmp = torch.empty(src.shape, dtype=dst.dtype, device=dev)
-            be.cast(tmp, src)
-            dst.copy_(tmp)
+    # the kernels round the final result to 16 bits in their epilogues (no fp32 round trip + cast)
+    def direct(t):
+        return t.dim() == 4 and t.stride(3) == 1 and all(st % 4 == 0 for st in t.stride()[:3])
+    tgt = [t if direct(t) else torch.empty(t.shape, dtype=t.dtype, device=dev)
+           for t in (block_dq_buffer, block_dk_buffer, block_dv_buffer)]
+    be.bwd(dout, q, k, v, lse, delta, None, None, None, _default_scale(q, softmax_scale), bool(bwd_causal),
+           dq16=tgt[0], dk16=tgt[1], dv16=tgt[2])
+    for t, dst in zip(tgt, (block_dq_buffer, block_dk_buffer, block_dv_buffer)):
+        if t is not dst:
+            dst.copy_(t)
 
 
 class _HipAttnFunc(torch.autograd.Function):

@@ -9,7 +9,6 @@ side stream); additionally dq is returned in q.dtype (the reference hard-codes b
 import torch
 import torch.distributed as dist
 
-from ..comm.all_to_all import seq_major_empty
 from ..kernels import AttnType
 from ..kernels.attention import get_block_backend
 from .utils import KVRelay, RingComm
@@ -45,7 +44,7 @@ def ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, 
     r = dist.get_rank(process_group)
     B, S, H, D = q.shape
     dev = q.device
-    out = seq_major_empty(B, S, H, D, q.dtype, dev)
+    out = torch.empty((B, S, H, D), dtype=q.dtype, device=dev)
     lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
     last_compute = r if causal else P - 1
     acc = torch.empty((B, S, H, D), dtype=torch.float32, device=dev) if last_compute > 0 else None
@@ -70,6 +69,11 @@ def ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, sof
     f32 = torch.float32
     delta = torch.empty((B, H, S), dtype=f32, device=dev)
     be.delta(dout, out, delta)
+    if P == 1:   # one block: the kernels round the gradients to q.dtype in their epilogues
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        be.bwd(dout, q, k, v, softmax_lse, delta, None, None, None, softmax_scale, bool(causal),
+               dq16=dq, dk16=dk, dv16=dv)
+        return dq, dk, dv
     dq_acc = torch.empty((B, S, H, D), dtype=f32, device=dev)
     dk_blk = dv_blk = None
     if P > 1:
@@ -104,9 +108,7 @@ def ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, sof
         dk_acc, dv_acc = next_dk, next_dv
     relay.finish()
 
-    dq = seq_major_empty(B, S, H, D, q.dtype, dev)
-    dk = seq_major_empty(*k.shape, k.dtype, dev)
-    dv = seq_major_empty(*v.shape, v.dtype, dev)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     _cast(be, dq, dq_acc)
     _cast(be, dk, dk_acc)
     _cast(be, dv, dv_acc)

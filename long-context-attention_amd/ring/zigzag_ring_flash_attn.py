@@ -21,7 +21,6 @@ MI355X-first differences (results identical up to fp32 rounding order):
 import torch
 import torch.distributed as dist
 
-from ..comm.all_to_all import seq_major_empty
 from ..kernels import AttnType
 from ..kernels.attention import get_block_backend
 from .utils import KVRelay, RingComm
@@ -82,7 +81,7 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
     assert S2 % 2 == 0, "zigzag layout needs an even local sequence length"
     c = S2 // 2
     dev = q.device
-    out = seq_major_empty(B, S2, H, D, q.dtype, dev)
+    out = torch.empty((B, S2, H, D), dtype=q.dtype, device=dev)
     lse = torch.empty((B, H, S2), dtype=torch.float32, device=dev)
     acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev) if P > 1 else None
 
@@ -109,6 +108,10 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
     lse = softmax_lse
     delta = torch.empty((B, H, S2), dtype=f32, device=dev)
     be.delta(dout, out, delta)
+    if P == 1:   # one block: the kernels round the gradients to q.dtype in their epilogues
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        be.bwd(dout, q, k, v, lse, delta, None, None, None, softmax_scale, True, dq16=dq, dk16=dk, dv16=dv)
+        return dq, dk, dv
     dq_acc = torch.empty((B, S2, H, D), dtype=f32, device=dev)
     dk_blk = dv_blk = None
     if P > 1:
@@ -141,9 +144,7 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
         dk_acc, dv_acc = next_dk, next_dv
     relay.finish()
 
-    dq = seq_major_empty(B, S2, H, D, q.dtype, dev)
-    dk = seq_major_empty(*k.shape, k.dtype, dev)
-    dv = seq_major_empty(*v.shape, v.dtype, dev)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     _cast(be, dq, dq_acc)
     _cast(be, dk, dk_acc)
     _cast(be, dv, dv_acc)
@@ -151,13 +152,8 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
 
 
 def _cast(be, dst16, src32):
-    """fp32 (B,S,H,D) contiguous -> 16-bit seq-major view."""
-    if dst16.shape[0] == 1:
-        be.cast(dst16, src32)
-    else:   # seq-major dst is not batch-sliceable: cast contiguous, then one strided copy
-        tmp = torch.empty(src32.shape, dtype=dst16.dtype, device=src32.device)
-        be.cast(tmp, src32)
-        dst16.copy_(tmp)
+    """fp32 (B,S,H,D) contiguous -> 16-bit contiguous."""
+    be.cast(dst16, src32)
 
 
 class ZigZagRingFlashAttnFunc(torch.autograd.Function):

@@ -46,7 +46,7 @@ class OracleBlockBackend:
         _put(delta, np.einsum("bshd,bshd->bhs", _np(dout), _np(out)))
 
     def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
-            accum_dk=False, accum_dv=False):
+            accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None):
         self.calls.append(("bwd", tuple(q.shape), tuple(k.shape), bool(causal)))
         # block_bwd derives delta from `out`; feed it an `out` whose rowsum(dout*out) equals the
         # supplied delta is not possible in general, so restate with delta directly:
@@ -64,8 +64,10 @@ class OracleBlockBackend:
         ds = p * (dp - dl[..., None]) * softmax_scale
         gdq = np.einsum("bhts,bshd->bthd", ds, kk)
         gdk = np.einsum("bhts,bthd->bshd", ds, qn).reshape(B, Sk, Hkv, g, D).sum(3)
-        for dst, val, accum in ((dq, gdq, accum_dq), (dk, gdk, accum_dk), (dv, gdv, accum_dv)):
-            _put(dst, val + _np(dst) if accum else val)
+        for dst, d16, val, accum in ((dq, dq16, gdq, accum_dq), (dk, dk16, gdk, accum_dk),
+                                     (dv, dv16, gdv, accum_dv)):
+            tot = val + _np(dst) if accum else val
+            _put(d16 if d16 is not None else dst, tot)
 
     def merge(self, acc, lse, blk_out, blk_lse, first):
         if first:

@@ -1,0 +1,71 @@
+"""CPU tests of bench.py's helper logic that the single-GPU runs never reach (N > 1)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dist_util import run_distributed
+from oracle import usp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_workloads_match_baseline_configs():
+    b = _bench()
+    w = b.WORKLOADS
+    assert (w[1]["B"], w[1]["S"], w[1]["Hq"], w[1]["D"], w[1]["ud"], w[1]["rd"]) == (2, 8192, 16, 128, 1, 1)
+    assert (w[2]["S"], w[2]["ud"], w[2]["rd"]) == (16384, 2, 1)
+    assert (w[4]["S"], w[4]["ud"], w[4]["rd"], w[4]["impl"]) == (32768, 1, 4, "zigzag")
+    assert (w[8]["S"], w[8]["Hq"], w[8]["Hkv"], w[8]["ud"], w[8]["rd"], w[8]["bwd"]) == (65536, 32, 4, 2, 4, True)
+    for n, c in w.items():
+        assert c["ud"] * c["rd"] == n and c["S"] * c["B"] // n in (8192, 16384)
+    assert b.fwd_flops(2, 16, 8192, 128) == pytest.approx(0.5498e12, rel=1e-3)
+    assert 3.5 * b.fwd_flops(1, 32, 65536, 128) == pytest.approx(123.15e12, rel=1e-3)  # C5 fwd+bwd
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_local_row_ranges_match_extract_layout(n):
+    """bench.parity_check slices the global tensors by these ranges: they must be exactly the rows
+    EXTRACT_FUNC_DICT hands to each rank (oracle restatement of extract_local.py:25-49)."""
+    b = _bench()
+    cfg = dict(b.WORKLOADS[n]); cfg["S"] = 64 * n            # small stand-in with the same grid
+    rows = np.arange(cfg["S"], dtype=np.float32).reshape(1, cfg["S"], 1, 1)
+    for rank in range(n):
+        want = O.EXTRACT[cfg["impl"]](rows, rank, n, cfg["rd"], cfg["ud"])[0, :, 0, 0]
+        got = np.concatenate([np.arange(a, e) for a, e in b.local_row_ranges(cfg, rank, n)])
+        assert np.array_equal(got, want), (rank, got, want)
+
+
+def _probe_worker(rank, ws):
+    import torch.distributed as dist
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    b = _bench()
+    set_block_backend(OracleBlockBackend())
+    Y.set_seq_parallel_pg(1, ws, rank, ws)
+    torch.manual_seed(0)
+    B, S, H, D = 1, 32 * ws, 2, 32
+    glob = [torch.randn(B, S, H, D).to(torch.bfloat16) for _ in range(3)]
+    lq, lk, lv = (Y.EXTRACT_FUNC_DICT["zigzag"](t, rank, world_size=ws, rd=ws, ud=1) for t in glob)
+    attn = Y.LongContextAttention(ring_impl_type="zigzag")
+    ref = attn(lq, lk, lv, causal=True)
+    dev = torch.device("cpu")
+    t = b.timed(lambda: attn(lq, lk, lv, causal=True), 2, ws, dev)
+    ov = b.overlap_probe(lambda: attn(lq, lk, lv, causal=True), 2, ws, dev, t)
+    again = attn(lq, lk, lv, causal=True)          # the probe must restore comm and the block backend
+    assert torch.equal(ref, again)
+    return t > 0 and set(ov) >= {"value", "ms_iter", "ms_compute_only", "ms_comm_only"}
+
+
+def test_timed_and_overlap_probe_on_gloo():
+    assert all(run_distributed(_probe_worker, 2))
