@@ -7,6 +7,7 @@ named long-context-attention_amd; import it as `yunchang_amd` (see yunchang_amd/
 """
 from .hybrid import *  # noqa: F401,F403
 from .ring import *  # noqa: F401,F403
+from .ulysses import *  # noqa: F401,F403
 from .globals import set_seq_parallel_pg, PROCESS_GROUP
 from .comm.extract_local import (
     stripe_extract_local,

@@ -146,3 +146,98 @@ class SeqAllToAll4D(torch.autograd.Function):
                 SeqAllToAll4D.apply(ctx.group, grad_output[0], ctx.gather_idx, ctx.scatter_idx,
                                     ctx.use_sync),
                 None, None, None)
+
+
+# --------------------------------------------------------------------------------------------------
+# packed qkv: (bs, seq, 3, heads, dim)   (yunchang/comm/all_to_all.py:137-259)
+# --------------------------------------------------------------------------------------------------
+def pack_heads_5d(x: Tensor, P: int) -> Tensor:
+    """(B, S/P, T, H, D) -> send buffer (P, S/P, B, T, H/P, D)."""
+    B, Sl, T, H, D = x.shape
+    assert H % P == 0, f"head count {H} not divisible by ulysses degree {P}"
+    hp = H // P
+    if x.stride(4) != 1 or x.stride(3) != D:
+        x = x.contiguous()
+    send = torch.empty((P, Sl, B, T, hp, D), dtype=x.dtype, device=x.device)
+    _copy_rows(send, x, hp * D, (P, Sl, B, T),
+               (Sl * B * T * hp * D, B * T * hp * D, T * hp * D, hp * D),
+               (hp * D, x.stride(1), x.stride(0), x.stride(2)))
+    return send
+
+
+def view_seq_5d(recv: Tensor) -> Tensor:
+    P, Sl, B, T, hp, D = recv.shape
+    return recv.view(P * Sl, B, T, hp, D).transpose(0, 1)
+
+
+def pack_seq_5d(x: Tensor, P: int) -> Tensor:
+    B, S, T, hp, D = x.shape
+    assert S % P == 0, f"sequence {S} not divisible by ulysses degree {P}"
+    if x.transpose(0, 1).is_contiguous():
+        send = x.transpose(0, 1)
+    else:
+        if not x[0, 0].is_contiguous():
+            x = x.contiguous()
+        send = torch.empty((S, B, T, hp, D), dtype=x.dtype, device=x.device)
+        _copy_rows(send, x, T * hp * D, (S, B), (B * T * hp * D, T * hp * D), (x.stride(1), x.stride(0)))
+    return send.view(P, S // P, B, T, hp, D)
+
+
+def unpack_heads_5d(recv: Tensor) -> Tensor:
+    P, Sl, B, T, hp, D = recv.shape
+    H = hp * P
+    out = torch.empty((B, Sl, T, H, D), dtype=recv.dtype, device=recv.device)
+    _copy_rows(out, recv, hp * D, (P, Sl, B, T), (hp * D, T * H * D, Sl * T * H * D, H * D),
+               (Sl * B * T * hp * D, B * T * hp * D, T * hp * D, hp * D))
+    return out
+
+
+def heads_to_seq_5d(x: Tensor, group, use_sync: bool = False, contiguous: bool = False) -> Tensor:
+    """scatter heads / gather sequence: (B, S/P, T, H, D) -> (B, S, T, H/P, D) -- ONE exchange for
+    q, k and v (all_to_all.py:160-192)."""
+    P = dist.get_world_size(group)
+    if P == 1:
+        return x
+    out = view_seq_5d(_exchange(pack_heads_5d(x, P), group, use_sync))
+    return out.contiguous() if contiguous else out
+
+
+def seq_to_heads_5d(x: Tensor, group, use_sync: bool = False) -> Tensor:
+    """scatter sequence / gather heads: (B, S, T, H/P, D) -> (B, S/P, T, H, D) (all_to_all.py:193-233)."""
+    P = dist.get_world_size(group)
+    if P == 1:
+        return x
+    return unpack_heads_5d(_exchange(pack_seq_5d(x, P), group, use_sync))
+
+
+def all_to_all_5D(input: torch.Tensor, scatter_idx: int = 3, gather_idx: int = 1, group=None,
+                  use_sync: bool = False) -> torch.Tensor:
+    assert input.dim() == 5, f"input must be 5D tensor, got {input.dim()} and shape {input.shape}"
+    if scatter_idx == 3 and gather_idx == 1:
+        assert input.shape[2] == 3
+        return heads_to_seq_5d(input, group, use_sync, contiguous=True)
+    if scatter_idx == 1 and gather_idx == 3:
+        return seq_to_heads_5d(input, group, use_sync)
+    raise RuntimeError("scatter_idx must be 1 or 3 and gather_idx must be 1 or 3")
+
+
+class SeqAllToAll5D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx: Any, group, input: Tensor, scatter_idx: int = 3, gather_idx: int = 1,
+                use_sync: bool = False) -> Tensor:
+        ctx.group = group
+        ctx.scatter_idx = scatter_idx
+        ctx.gather_idx = gather_idx
+        ctx.use_sync = use_sync
+        if scatter_idx == 3 and gather_idx == 1:
+            return heads_to_seq_5d(input, group, use_sync)
+        if scatter_idx == 1 and gather_idx == 3:
+            return seq_to_heads_5d(input, group, use_sync)
+        raise RuntimeError("scatter_idx must be 1 or 3 and gather_idx must be 1 or 3")
+
+    @staticmethod
+    def backward(ctx: Any, *grad_output: Tensor) -> Tuple[None, Tensor, None, None, None]:
+        return (None,
+                SeqAllToAll5D.apply(ctx.group, grad_output[0], ctx.gather_idx, ctx.scatter_idx,
+                                    ctx.use_sync),
+                None, None, None)

@@ -9,10 +9,10 @@ import torch
 import torch.distributed as dist
 from torch import Tensor
 
-from ..comm.all_to_all import SeqAllToAll4D
+from ..comm.all_to_all import SeqAllToAll4D, SeqAllToAll5D
 from ..globals import PROCESS_GROUP
 from ..kernels import AttnType
-from .utils import RING_IMPL_DICT
+from .utils import RING_IMPL_DICT, RING_IMPL_QKVPACKED_DICT
 
 
 class LongContextAttention(torch.nn.Module):
@@ -71,3 +71,41 @@ class LongContextAttention(torch.nn.Module):
         output = SeqAllToAll4D.apply(self.ulysses_pg, context_layer, self.gather_idx,
                                      self.scatter_idx, self.use_sync)
         return output
+
+
+class LongContextAttentionQKVPacked(torch.nn.Module):
+    """Same surface as yunchang/hybrid/attn_layer.py:164-259: packed
+    qkv (bs, seq_len/N, 3, head_cnt, head_size) -> ONE head all-to-all (instead of three) -> ring
+    attention on the packed views -> all-to-all of the output back.  Equal head counts only
+    (a packed tensor cannot express GQA, README.md:193)."""
+
+    def __init__(self, scatter_idx: int = 3, gather_idx: int = 1, ring_impl_type: str = "basic",
+                 use_sync: bool = False, attn_type: AttnType = AttnType.FA) -> None:
+        super(LongContextAttentionQKVPacked, self).__init__()
+        self.ring_pg = PROCESS_GROUP.RING_PG
+        self.ulysses_pg = PROCESS_GROUP.ULYSSES_PG
+        assert (
+            self.ulysses_pg is not None or self.ring_pg is not None
+        ), f"use set_seq_parallel_pg() first. Now ulysses pg {self.ulysses_pg} and ring pg {self.ring_pg}"
+        self.scatter_idx = scatter_idx
+        self.gather_idx = gather_idx
+        self.use_sync = use_sync
+        self.ring_attn_fn = RING_IMPL_QKVPACKED_DICT[ring_impl_type]
+        self.attn_type = attn_type
+
+    def forward(self, qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
+                softcap=0.0, alibi_slopes=None, deterministic=False, return_attn_probs=False,
+                *args: Any) -> Tensor:
+        world_size = dist.get_world_size(self.ulysses_pg)
+        if world_size > 1:   # scatter 3 (heads), gather 1 (sequence)
+            qkv = SeqAllToAll5D.apply(self.ulysses_pg, qkv, self.scatter_idx, self.gather_idx, self.use_sync)
+        out = self.ring_attn_fn(qkv, dropout_p=dropout_p, softmax_scale=softmax_scale, causal=causal,
+                                window_size=window_size, softcap=softcap, alibi_slopes=alibi_slopes,
+                                deterministic=deterministic, return_attn_probs=return_attn_probs,
+                                group=self.ring_pg, attn_type=self.attn_type)
+        if type(out) == tuple:
+            out = out[0]
+        if world_size > 1:   # (bs, seq_len, head_cnt/N, head_size) -> (bs, seq_len/N, head_cnt, head_size)
+            out = SeqAllToAll4D.apply(self.ulysses_pg, out, self.gather_idx, self.scatter_idx - 1,
+                                      self.use_sync)
+        return out

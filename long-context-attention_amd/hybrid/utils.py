@@ -3,6 +3,8 @@
 from ..ring import (
     ring_flash_attn_func,
     ring_flash_attn_qkvpacked_func,
+    stripe_flash_attn_func,
+    stripe_flash_attn_qkvpacked_func,
     zigzag_ring_flash_attn_func,
     zigzag_ring_flash_attn_qkvpacked_func,
 )
@@ -20,7 +22,7 @@ def _out_of_scope(name):
 RING_IMPL_DICT = {
     "basic": ring_flash_attn_func,
     "zigzag": zigzag_ring_flash_attn_func,
-    "strip": _out_of_scope("strip"),
+    "strip": stripe_flash_attn_func,
     "basic_pytorch": ring_flash_attn_func,
     "basic_flashinfer": _out_of_scope("basic_flashinfer"),
     "basic_npu": _out_of_scope("basic_npu"),
@@ -29,6 +31,6 @@ RING_IMPL_DICT = {
 RING_IMPL_QKVPACKED_DICT = {
     "basic": ring_flash_attn_qkvpacked_func,
     "zigzag": zigzag_ring_flash_attn_qkvpacked_func,
-    "strip": _out_of_scope("strip"),
+    "strip": stripe_flash_attn_qkvpacked_func,
     "basic_flashinfer": _out_of_scope("basic_flashinfer"),
 }

@@ -8,10 +8,17 @@ from .zigzag_ring_flash_attn import (
     zigzag_ring_flash_attn_kvpacked_func,
     zigzag_ring_flash_attn_qkvpacked_func,
 )
+from .stripe_flash_attn import (
+    stripe_flash_attn_func,
+    stripe_flash_attn_kvpacked_func,
+    stripe_flash_attn_qkvpacked_func,
+)
 from .utils import RingComm, KVRelay, update_out_and_lse
 
 __all__ = [
     "ring_flash_attn_func", "ring_flash_attn_kvpacked_func", "ring_flash_attn_qkvpacked_func",
     "zigzag_ring_flash_attn_func", "zigzag_ring_flash_attn_kvpacked_func",
-    "zigzag_ring_flash_attn_qkvpacked_func", "RingComm", "KVRelay", "update_out_and_lse",
+    "zigzag_ring_flash_attn_qkvpacked_func", "stripe_flash_attn_func",
+    "stripe_flash_attn_kvpacked_func", "stripe_flash_attn_qkvpacked_func", "RingComm", "KVRelay",
+    "update_out_and_lse",
 ]

@@ -97,6 +97,10 @@ class KVRelay:
 
     def __init__(self, process_group, k: torch.Tensor, v: torch.Tensor):
         self.P = dist.get_world_size(process_group)
+        if self.P > 1:
+            # point-to-point transfers need contiguous buffers (the reference makes K/V contiguous at
+            # zigzag_ring_flash_attn.py:208-209); views stay views at ring degree 1
+            k, v = k.contiguous(), v.contiguous()
         self.slots: List[Tuple[torch.Tensor, torch.Tensor]] = [(k, v)]
         self.events = [None]
         self._stream = None

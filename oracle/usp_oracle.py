@@ -82,7 +82,18 @@ def zigzag_extract_local(x: np.ndarray, rank: int, world_size: int, rd: int, ud:
     return np.array(np.array_split(loc, ud, axis=1)[u_rank])
 
 
-EXTRACT = {"basic": basic_extract_local, "zigzag": zigzag_extract_local}
+def stripe_extract_local(x: np.ndarray, rank: int, world_size: int, rd: int, ud: int,
+                         use_ulysses_low: bool = True) -> np.ndarray:
+    """extract_local.py:7-22: token t goes to ring position t % rd ((B, S/rd, rd, ...) ->
+    (B, rd, S/rd, ...)), then the sequence is cut into world_size contiguous chunks."""
+    B, S = x.shape[:2]
+    rest = x.shape[2:]
+    y = x.reshape(B, S // rd, rd, -1).transpose(0, 2, 1, 3).reshape(B, S, -1)
+    y = np.array_split(y, world_size, axis=1)[rank]
+    return np.array(y.reshape((B, S // world_size) + tuple(rest)))
+
+
+EXTRACT = {"basic": basic_extract_local, "zigzag": zigzag_extract_local, "strip": stripe_extract_local}
 
 
 # ----------------------------------------------------------------------------
@@ -286,6 +297,49 @@ def zigzag_ring_backward_sim(douts, qs, ks, vs, outs, lses, softmax_scale=None, 
     return dqs, dks, dvs
 
 
+def stripe_ring_forward_sim(qs, ks, vs, softmax_scale=None, dtype=np.float64):
+    """stripe_flash_attn.py:6-76: every step is causal; steps > rank use q[:, 1:] x k[:, :-1] and
+    update rows 1: only (:48-66)."""
+    P = len(qs)
+    outs, lses = [], []
+    for r in range(P):
+        q = qs[r]
+        out = lse = None
+        for step in range(P):
+            src = (r - step) % P
+            k, v = ks[src], vs[src]
+            if step <= r:
+                bo, bl = block_fwd(q, k, v, softmax_scale, True, dtype)
+                out, lse = update_out_and_lse(out, lse, bo, bl)
+            else:
+                bo, bl = block_fwd(q[:, 1:], k[:, :-1], v[:, :-1], softmax_scale, True, dtype)
+                out, lse = update_out_and_lse(out, lse, bo, bl, row_slice=slice(1, None))
+        outs.append(out)
+        lses.append(np.swapaxes(lse[..., 0], 1, 2))
+    return outs, lses
+
+
+def stripe_ring_backward_sim(douts, qs, ks, vs, outs, lses, softmax_scale=None, dtype=np.float64):
+    """stripe_flash_attn.py:79-195 in exact arithmetic."""
+    P = len(qs)
+    dqs = [np.zeros(q.shape, dtype) for q in qs]
+    dks = [np.zeros(k.shape, dtype) for k in ks]
+    dvs = [np.zeros(v.shape, dtype) for v in vs]
+    for r in range(P):
+        q, do, o, lse = qs[r], douts[r], outs[r], lses[r]
+        for step in range(P):
+            src = (r - step) % P
+            k, v = ks[src], vs[src]
+            if step <= r:
+                dq, dk, dv = block_bwd(do, q, k, v, o, lse, softmax_scale, True, dtype)
+                dqs[r] += dq; dks[src] += dk; dvs[src] += dv
+            else:
+                dq, dk, dv = block_bwd(do[:, 1:], q[:, 1:], k[:, :-1], v[:, :-1], o[:, 1:], lse[:, :, 1:],
+                                       softmax_scale, True, dtype)
+                dqs[r][:, 1:] += dq; dks[src][:, :-1] += dk; dvs[src][:, :-1] += dv
+    return dqs, dks, dvs
+
+
 def basic_ring_forward_sim(qs, ks, vs, softmax_scale=None, causal=True, dtype=np.float64):
     """ring_flash_attn.py:7-62: contiguous layout; under causal only steps <= rank compute
     (:35) and only step 0 is causal (:41)."""
@@ -342,6 +396,9 @@ def usp_forward_sim(local_qs, local_ks, local_vs, ud, rd, ring_impl_type="zigzag
         if ring_impl_type == "zigzag":
             assert causal, "zigzag ring is meaningless for causal=False"
             o, l_ = zigzag_ring_forward_sim(qs, ks, vs, softmax_scale, dtype)
+        elif ring_impl_type == "strip":
+            assert causal, "stripe flash attn only supports causal attention"
+            o, l_ = stripe_ring_forward_sim(qs, ks, vs, softmax_scale, dtype)
         else:
             o, l_ = basic_ring_forward_sim(qs, ks, vs, softmax_scale, causal, dtype)
         for i, r in enumerate(grp):
@@ -375,6 +432,8 @@ def usp_backward_sim(local_douts, ctx, ud, rd, ring_impl_type="zigzag", causal=T
                 [ctx["ring_lse"][r] for r in grp])
         if ring_impl_type == "zigzag":
             dq, dk, dv = zigzag_ring_backward_sim(*args, softmax_scale, dtype)
+        elif ring_impl_type == "strip":
+            dq, dk, dv = stripe_ring_backward_sim(*args, softmax_scale, dtype)
         else:
             dq, dk, dv = basic_ring_backward_sim(*args, softmax_scale, causal, dtype)
         for i, r in enumerate(grp):

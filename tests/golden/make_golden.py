@@ -57,6 +57,11 @@ CASES = [
     # C5 topology: ulysses=2 x ring=4 zigzag, GQA
     ("c5_w8_u2r4_gqa_bf16", 8, 2, 4, "zigzag", 1, 512, 4, 2, 128, "bfloat16", True),
     ("c5_w8_u2r4_gqa_fp16", 8, 2, 4, "zigzag", 1, 512, 4, 2, 64, "float16", True),
+    # SURVEY 8(f) "next" rows: stripe ring, UlyssesAttention, packed-qkv layer (layer suffix after ':')
+    ("n_w4_u1r4_strip_bf16", 4, 1, 4, "strip", 1, 512, 2, 2, 64, "bfloat16", True),
+    ("n_w4_u2r2_strip_bf16", 4, 2, 2, "strip", 1, 256, 4, 4, 64, "bfloat16", True),
+    ("n_w2_ulysses_bf16:ulysses", 2, 2, 1, "basic", 2, 256, 4, 2, 64, "bfloat16", True),
+    ("n_w4_u2r2_qkvpacked_bf16:qkvpacked", 4, 2, 2, "zigzag", 1, 256, 4, 4, 64, "bfloat16", True),
 ]
 SEED = 0
 
@@ -136,6 +141,7 @@ def _bits(t: torch.Tensor) -> np.ndarray:
 
 def _worker(rank, ws, case, port, ret):
     name, _, ud, rd, impl, B, S, Hq, Hkv, D, dtype_s, bwd = case
+    layer = name.split(":")[1] if ":" in name else "hybrid"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=ws)
@@ -155,13 +161,42 @@ def _worker(rank, ws, case, port, ret):
                        for t in (q, k, v, dout))
     if bwd:
         lq.requires_grad_(True); lk.requires_grad_(True); lv.requires_grad_(True)
-    attn = LongContextAttention(ring_impl_type=impl, attn_type=AttnType.TORCH_EFFICIENT)
-    out = attn(lq, lk, lv, dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
-               alibi_slopes=None, deterministic=False, return_attn_probs=True)
+    kw = dict(dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+              deterministic=False, return_attn_probs=True)
+    if layer == "hybrid":
+        attn = LongContextAttention(ring_impl_type=impl, attn_type=AttnType.TORCH_EFFICIENT)
+        out = attn(lq, lk, lv, **kw)
+    elif layer == "ulysses":
+        # the reference's fwd-bwd stage for TORCH_* is its picotron-style ring_pytorch_attn_func,
+        # whose backward raises (ring_pytorch_attn.py:103); UlyssesAttention's semantics are exactly
+        # "all-to-all -> one local attention -> all-to-all", so the local attention is supplied as an
+        # autograd-aware torch function (fp32 attention_ref maths) through the same selector seam.
+        import yunchang.ulysses.attn_layer as UA
+        from yunchang.globals import PROCESS_GROUP
+
+        def local_attn(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, **_):
+            g = q.shape[2] // k.shape[2]
+            kk, vv = k.float().repeat_interleave(g, 2), v.float().repeat_interleave(g, 2)
+            s = torch.einsum("bthd,bshd->bhts", q.float() * softmax_scale, kk)
+            if causal:
+                Sq, Sk = q.shape[1], k.shape[1]
+                s = s.masked_fill(torch.arange(Sk)[None, :] > torch.arange(Sq)[:, None] + Sk - Sq, float("-inf"))
+            return torch.einsum("bhts,bshd->bthd", s.softmax(-1), vv).to(q.dtype)
+        UA.select_flash_attn_impl = lambda *a, **k: local_attn
+        attn = UA.UlyssesAttention(PROCESS_GROUP.ULYSSES_PG, attn_type=AttnType.TORCH_EFFICIENT)
+        out = attn(lq, lk, lv, **kw)
+    else:   # qkvpacked
+        from yunchang import LongContextAttentionQKVPacked
+        qkv = torch.stack([lq.detach(), lk.detach(), lv.detach()], dim=2).requires_grad_(bwd)
+        attn = LongContextAttentionQKVPacked(ring_impl_type=impl, attn_type=AttnType.TORCH_EFFICIENT)
+        out = attn(qkv, **kw)
     res = {"out": _bits(out)}
     if bwd:
         out.backward(ldo)
-        res.update(dq=_bits(lq.grad), dk=_bits(lk.grad), dv=_bits(lv.grad))
+        if layer == "qkvpacked":
+            res.update(dq=_bits(qkv.grad[:, :, 0]), dk=_bits(qkv.grad[:, :, 1]), dv=_bits(qkv.grad[:, :, 2]))
+        else:
+            res.update(dq=_bits(lq.grad), dk=_bits(lk.grad), dv=_bits(lv.grad))
     ret[rank] = res
     dist.barrier()
     dist.destroy_process_group()
@@ -171,14 +206,16 @@ def main():
     only = set(sys.argv[1:])
     for i, case in enumerate(CASES):
         name, ws = case[0], case[1]
-        if only and name not in only:
+        if only and name.split(":")[0] not in only:
             continue
         mgr = mp.Manager()
         ret = mgr.dict()
         mp.spawn(_worker, args=(ws, case, 29650 + i, ret), nprocs=ws, join=True)
         _, _, ud, rd, impl, B, S, Hq, Hkv, D, dtype_s, bwd = case
+        layer = name.split(":")[1] if ":" in name else "hybrid"
+        name = name.split(":")[0]
         blob = dict(ws=ws, ud=ud, rd=rd, impl=impl, B=B, S=S, Hq=Hq, Hkv=Hkv, D=D,
-                    dtype=dtype_s, bwd=bwd, causal=True, seed=SEED)
+                    dtype=dtype_s, bwd=bwd, causal=True, seed=SEED, layer=layer)
         for r in range(ws):
             for key in ("out", "dq", "dk", "dv"):
                 if key in ret[r]:

@@ -58,6 +58,7 @@ class Golden:
         for key in ("ws", "ud", "rd", "B", "S", "Hq", "Hkv", "D", "seed"):
             setattr(self, key, int(z[key]))
         self.impl = str(z["impl"])
+        self.layer = str(z["layer"]) if "layer" in z.files else "hybrid"   # hybrid | ulysses | qkvpacked
         self.dtype = str(z["dtype"])
         self.bwd = bool(z["bwd"])
         self.causal = bool(z["causal"])

@@ -29,13 +29,27 @@ def _usp_worker(rank, ws, path, use_autograd):
     if g.bwd:
         for t in (lq, lk, lv):
             t.requires_grad_(True)
-    attn = Y.LongContextAttention(ring_impl_type=g.impl, attn_type=Y.AttnType.TORCH_EFFICIENT)
-    out = attn(lq, lk, lv, dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
-               alibi_slopes=None, deterministic=False, return_attn_probs=True)
+    kw = dict(dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+              deterministic=False, return_attn_probs=True)
+    qkv = None
+    if g.layer == "hybrid":
+        attn = Y.LongContextAttention(ring_impl_type=g.impl, attn_type=Y.AttnType.TORCH_EFFICIENT)
+        out = attn(lq, lk, lv, **kw)
+    elif g.layer == "ulysses":
+        attn = Y.UlyssesAttention(Y.PROCESS_GROUP.ULYSSES_PG, attn_type=Y.AttnType.HIP)
+        out = attn(lq, lk, lv, **kw)
+    else:
+        qkv = torch.stack([lq.detach(), lk.detach(), lv.detach()], dim=2).requires_grad_(g.bwd)
+        attn = Y.LongContextAttentionQKVPacked(ring_impl_type=g.impl, attn_type=Y.AttnType.HIP)
+        out = attn(qkv, **kw)
     res = {"out": out.detach().float().numpy(), "calls": list(be.calls)}
     if g.bwd:
         out.backward(ldo)
-        res.update(dq=lq.grad.float().numpy(), dk=lk.grad.float().numpy(), dv=lv.grad.float().numpy())
+        if qkv is not None:
+            gq, gk, gv = qkv.grad[:, :, 0], qkv.grad[:, :, 1], qkv.grad[:, :, 2]
+        else:
+            gq, gk, gv = lq.grad, lk.grad, lv.grad
+        res.update(dq=gq.float().numpy(), dk=gk.float().numpy(), dv=gv.float().numpy())
     return res
 
 

@@ -157,6 +157,17 @@ def test_merge_copy_cast_add_kernels(dev):
     back = A.unpack_heads(A.pack_seq(x[:, :, :hp].contiguous(), P))
     want2 = x[:, :, :hp].reshape(B, P, S // P, hp, D).permute(0, 2, 1, 3, 4).reshape(B, S // P, H, D)
     assert torch.equal(back, want2)
+    # packed-qkv (5-D) exchange buffers, B > 1 (bit exact)
+    x5 = torch.randn(B, S, 3, H, D, device=dev).to(torch.bfloat16)
+    send5 = A.pack_heads_5d(x5, P)
+    want5 = x5.reshape(B, S, 3, P, hp, D).permute(3, 1, 0, 2, 4, 5).contiguous()
+    assert torch.equal(send5, want5)
+    seq5 = A.view_seq_5d(send5)
+    assert seq5.shape == (B, P * S, 3, hp, D)
+    y5 = x5[:, :, :, :hp].contiguous()                       # (B, S, 3, hp, D) as if produced locally
+    back5 = A.unpack_heads_5d(A.pack_seq_5d(y5, P))
+    want5b = y5.reshape(B, P, S // P, 3, hp, D).permute(0, 2, 3, 1, 4, 5).reshape(B, S // P, 3, H, D)
+    assert torch.equal(back5, want5b)
     # cast + add (bit exact vs torch)
     a = torch.randn(B, S, H, D, device=dev)
     b = torch.randn(B, S, H, D, device=dev)
@@ -236,13 +247,16 @@ def test_c1_fp32_fixture_is_matched_by_bf16_kernel(dev, single_rank_pg):
 # golden fixtures from the reference: multi-rank grids emulated with VIRTUAL RANKS on one GPU
 # (the package's real pack/unpack kernels and ring step functions; only the wire is emulated)
 # ------------------------------------------------------------------------------------------------
-MULTI = [f for f in golden_files() if "_w1_" not in f]
+# the packed-qkv fixture is the hybrid maths on stacked tensors: its 5-D exchange kernels are unit
+# tested above, the rest is shared with the hybrid path
+MULTI = [f for f in golden_files() if "_w1_" not in f and "qkvpacked" not in f]
 
 
 def _virtual_usp(g, dev, with_bwd):
     from yunchang_amd.comm import all_to_all as A
     from yunchang_amd.kernels import get_block_backend
     from yunchang_amd.ring import ring_flash_attn as RB
+    from yunchang_amd.ring import stripe_flash_attn as RS
     from yunchang_amd.ring import zigzag_ring_flash_attn as RZ
     be = get_block_backend()
     assert be.name == "hip"
@@ -285,13 +299,16 @@ def _virtual_usp(g, dev, with_bwd):
         for r, rank in enumerate(grp):
             q = hq[rank]
             B, S, H, D = q.shape
-            out = A.seq_major_empty(B, S, H, D, tdt, dev)
+            out = torch.empty((B, S, H, D), dtype=tdt, device=dev)
             lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
             acc = torch.empty((B, S, H, D), dtype=torch.float32, device=dev) if P > 1 else None
             for step in range(P):
                 src = grp[(r - step) % P]
                 if g.impl == "zigzag":
                     RZ.zigzag_fwd_step(be, r, P, step, q, hk[src], hv[src], scale, lse, out, acc)
+                elif g.impl == "strip":
+                    RS.stripe_fwd_step(be, r, P, step, q, hk[src].contiguous(), hv[src].contiguous(), scale,
+                                       lse, out, acc)
                 else:
                     RB.basic_fwd_step(be, r, P, step, True, q, hk[src], hv[src], scale, lse, out, acc)
             outs[rank], lses[rank] = out, lse
@@ -329,6 +346,11 @@ def _virtual_usp(g, dev, with_bwd):
                                         s["delta"], scale, s["dq"], dst_k, dst_v)
                     if step > 0:
                         RZ.zigzag_bwd_fold(be, r, step, c, s["dk"], s["dv"], s["bk"], s["bv"])
+                elif g.impl == "strip":
+                    RS.stripe_bwd_block(be, r, P, step, hdo[rank], hq[rank], hk[src].contiguous(),
+                                        hv[src].contiguous(), lses[rank], s["delta"], scale, s["dq"], dst_k, dst_v)
+                    if step > 0:
+                        RS.stripe_bwd_fold(be, r, step, s["dk"], s["dv"], s["bk"], s["bv"])
                 else:
                     did = RB.basic_bwd_block(be, r, P, step, True, hdo[rank], hq[rank], hk[src], hv[src],
                                              lses[rank], s["delta"], scale, s["dq"], dst_k, dst_v)

@@ -78,10 +78,13 @@ def test_registry_keys_and_exports():
                                     "basic_npu"]                          # hybrid/utils.py:14-21
     assert set(RING_IMPL_QKVPACKED_DICT) == {"basic", "zigzag", "strip", "basic_flashinfer"}
     with pytest.raises(NotImplementedError):
-        RING_IMPL_DICT["strip"](None, None, None)
+        RING_IMPL_DICT["basic_flashinfer"](None, None, None)      # third-party backend: out of scope
+    assert RING_IMPL_DICT["strip"] is Y.stripe_flash_attn_func
     for name in ("LongContextAttention", "set_seq_parallel_pg", "EXTRACT_FUNC_DICT", "AttnType",
                  "PROCESS_GROUP", "zigzag_ring_flash_attn_func", "ring_flash_attn_func", "RingComm",
-                 "update_out_and_lse", "basic_extract_local", "zigzag_extract_local", "__version__"):
+                 "update_out_and_lse", "basic_extract_local", "zigzag_extract_local", "__version__",
+                 "UlyssesAttention", "LongContextAttentionQKVPacked", "stripe_flash_attn_func",
+                 "stripe_extract_local"):
         assert hasattr(Y, name), name
 
 
