@@ -268,6 +268,8 @@ def main():
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="skip the compute-only / comm-only runs (N > 1)")
     ap.add_argument("--bwd", type=int, default=-1, help="override: 1 = fwd+bwd, 0 = fwd only")
+    ap.add_argument("--async-ulysses", action="store_true",
+                    help="use AsyncLongContextAttention (head-group pipelined all-to-all) instead of LongContextAttention")
     args = ap.parse_args()
 
     ws = int(os.environ.get("WORLD_SIZE", "1"))
@@ -297,7 +299,10 @@ def main():
     if cfg["bwd"]:
         for t in (lq, lk, lv):
             t.requires_grad_(True)
-    attn = Y.LongContextAttention(ring_impl_type=cfg["impl"], attn_type=Y.AttnType.HIP)
+    if args.async_ulysses:
+        attn = Y.AsyncLongContextAttention(ring_impl_type=cfg["impl"])
+    else:
+        attn = Y.LongContextAttention(ring_impl_type=cfg["impl"], attn_type=Y.AttnType.HIP)
 
     def step():
         out = attn(lq, lk, lv, causal=True)
@@ -345,6 +350,7 @@ def main():
             "config": {"workload": cfg["name"], "global_shape_BSHD": [cfg["B"], cfg["S"], cfg["Hq"], cfg["D"]],
                        "kv_heads": cfg["Hkv"], "parallelism": f"ulysses{cfg['ud']}xring{cfg['rd']}",
                        "layout": cfg["impl"], "pass": "fwd+bwd" if cfg["bwd"] else "fwd",
+                       "layer": "AsyncLongContextAttention" if args.async_ulysses else "LongContextAttention",
                        "tokens_per_gpu": cfg["S"] * cfg["B"] // ws,
                        "assumed": "B=1 and causal=True where BASELINE.json's config string is silent"},
             "frac_of_mfma_roofline": round(value / (ws * PEAK_BF16_TFLOPS), 4),

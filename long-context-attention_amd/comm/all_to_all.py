@@ -66,6 +66,28 @@ def pack_heads(x: Tensor, P: int) -> Tensor:
     return send
 
 
+def pack_head_group(x5: Tensor) -> Tensor:
+    """x5: a (B, S/P, P, h, D) VIEW (any strides on the first three dims, (h, D) contiguous) selecting
+    h heads per destination rank -> send buffer (P, S/P, B, h, D).  Used by the head-group pipeline."""
+    B, Sl, P, h, D = x5.shape
+    assert x5.stride(4) == 1 and x5.stride(3) == D
+    send = torch.empty((P, Sl, B, h, D), dtype=x5.dtype, device=x5.device)
+    base = x5.as_strided((1,), (1,), x5.storage_offset())          # element pointer of the view
+    _copy_rows(send, base, h * D, (P, Sl, B), (Sl * B * h * D, B * h * D, h * D),
+               (x5.stride(2), x5.stride(1), x5.stride(0)))
+    return send
+
+
+def unpack_head_group(recv: Tensor, dst5: Tensor) -> None:
+    """receive buffer (P, S/P, B, h, D) [chunk p = head group of rank p] -> dst5, a (B, S/P, P, h, D)
+    VIEW into the full (B, S/P, H, D) result."""
+    P, Sl, B, h, D = recv.shape
+    assert dst5.stride(4) == 1 and dst5.stride(3) == D
+    base = dst5.as_strided((1,), (1,), dst5.storage_offset())
+    _copy_rows(base, recv, h * D, (P, Sl, B), (dst5.stride(2), dst5.stride(1), dst5.stride(0)),
+               (Sl * B * h * D, B * h * D, h * D))
+
+
 def view_seq(recv: Tensor) -> Tensor:
     """receive buffer (P, S/P, B, H/P, D) -> (B, S, H/P, D) strided view (no copy)."""
     P, Sl, B, hp, D = recv.shape

@@ -1,0 +1,192 @@
+"""AsyncLongContextAttention: same surface as yunchang/hybrid/async_attn_layer.py:13-202
+ -- the Ulysses all-to-all hidden behind the ring attention by pipelining over
+head groups.
+
+The heads each rank owns after the exchange are split into groups (one KV head + its query heads per
+group); the exchanges of all groups are queued on a side HIP stream up-front, group i's ring attention
+starts as soon as ITS exchange has landed, and its output exchange runs behind group i+1's attention.
+Only the first input exchange and the last output exchange stay exposed.
+
+Beyond the reference (which is forward-only `:199-202`, needs Hkv == Hq `:78` and puts one head per rank
+in a group): GQA, a backward pass (same pipeline, mirrored), and results that are bit-identical in head
+placement to LongContextAttention (group i of rank p = kv head p*Hkv/P + i).
+"""
+from typing import Any
+
+import torch
+import torch.distributed as dist
+from torch import Tensor
+
+from ..comm import all_to_all as A
+from ..globals import PROCESS_GROUP
+from ..kernels import AttnType
+from ..ring.ring_flash_attn import ring_flash_attn_backward, ring_flash_attn_forward
+from ..ring.stripe_flash_attn import stripe_flash_attn_backward, stripe_flash_attn_forward
+from ..ring.utils import _side_stream
+from ..ring.zigzag_ring_flash_attn import (_check_hot_path_args, zigzag_ring_flash_attn_backward,
+                                           zigzag_ring_flash_attn_forward)
+
+_RING_FWD_BWD = {
+    "basic": (ring_flash_attn_forward, ring_flash_attn_backward),
+    "zigzag": (zigzag_ring_flash_attn_forward, zigzag_ring_flash_attn_backward),
+    "strip": (stripe_flash_attn_forward, stripe_flash_attn_backward),
+}
+
+
+class _Lane:
+    """The side stream the exchanges run on (no-op on host tensors: gloo tests)."""
+
+    def __init__(self, ref: Tensor):
+        self.cuda = ref.is_cuda
+        if self.cuda:
+            self.main = torch.cuda.current_stream()
+            self.side = _side_stream(ref.device)
+
+    def exchange(self, send: Tensor, group) -> tuple:
+        """Queue all_to_all_single(send) behind everything currently on the main stream; returns
+        (recv, event).  `send` must stay referenced until `wait` (the caller keeps it)."""
+        if not self.cuda:
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=group)
+            return recv, None
+        ready = torch.cuda.Event()
+        ready.record(self.main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=group)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        send.record_stream(self.side)
+        recv.record_stream(self.main)
+        return recv, done
+
+    def wait(self, event):
+        if event is not None:
+            torch.cuda.current_stream().wait_event(event)
+
+    def finish(self):
+        if self.cuda:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+_MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer workgroups per launch)
+
+
+def _groups(Hq, Hkv, P):
+    """(number of head groups, kv heads per rank per group, query heads per kv head).  A group is a
+    set of whole KV heads (with their query heads) of every rank's post-exchange share."""
+    assert Hq % P == 0 and Hkv % P == 0, f"heads ({Hq}, {Hkv}) not divisible by ulysses degree {P}"
+    per_rank = Hkv // P
+    ng = 1
+    if P > 1:                       # nothing to hide without an exchange
+        for cand in range(min(_MAX_GROUPS, per_rank), 0, -1):
+            if per_rank % cand == 0:
+                ng = cand
+                break
+    return ng, per_rank // ng, Hq // Hkv
+
+
+def _to_seq(lane, x, P, ng, h, i, group):
+    """Exchange head group i of x (B, S/P, H, D): returns ((B, S, h, D) view, event)."""
+    B, Sl, H, D = x.shape
+    if x.stride(3) != 1 or x.stride(2) != D:
+        x = x.contiguous()
+    x5 = x.view(B, Sl, P, ng, h, D)[:, :, :, i]                   # heads p*(ng*h) + i*h + (0..h)
+    recv, ev = lane.exchange(A.pack_head_group(x5), group)
+    return A.view_seq(recv), ev
+
+
+def _to_heads_issue(lane, x, P, group):
+    """Queue the exchange of (B, S, h, D) back to sequence sharding; returns (recv, event)."""
+    return lane.exchange(A.pack_seq(x, P), group)
+
+
+class _AsyncUSPFunc(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, softmax_scale, causal, ulysses_pg, ring_pg, impl):
+        fwd, _ = _RING_FWD_BWD[impl]
+        P = dist.get_world_size(ulysses_pg)
+        B, Sl, Hq, D = q.shape
+        Hkv = k.shape[2]
+        ng, kvh, g = _groups(Hq, Hkv, P)
+        if softmax_scale is None:
+            softmax_scale = D ** (-0.5)
+        lane = _Lane(q)
+        ins = []
+        for i in range(ng):          # every input exchange is queued before any attention runs
+            ins.append((_to_seq(lane, q, P, ng, kvh * g, i, ulysses_pg),
+                        _to_seq(lane, k, P, ng, kvh, i, ulysses_pg), _to_seq(lane, v, P, ng, kvh, i, ulysses_pg)))
+        saved, outs = [], []
+        for i in range(ng):
+            (qi, eq), (ki, ek), (vi, evv) = ins[i]
+            for e in (eq, ek, evv):
+                lane.wait(e)
+            oi, lse_i = fwd(ring_pg, qi, ki, vi, softmax_scale=softmax_scale, causal=causal)
+            saved += [qi, ki, vi, oi, lse_i]
+            outs.append(_to_heads_issue(lane, oi, P, ulysses_pg))
+        out = torch.empty((B, Sl, Hq, D), dtype=q.dtype, device=q.device)
+        o5 = out.view(B, Sl, P, ng, kvh * g, D)
+        for i, (recv, ev) in enumerate(outs):
+            lane.wait(ev)
+            A.unpack_head_group(recv, o5[:, :, :, i])
+        lane.finish()
+        ctx.save_for_backward(*saved)
+        ctx.meta = (softmax_scale, causal, ulysses_pg, ring_pg, impl, P, ng, kvh, g, Hq, Hkv)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        softmax_scale, causal, ulysses_pg, ring_pg, impl, P, ng, kvh, g, Hq, Hkv = ctx.meta
+        _, bwd = _RING_FWD_BWD[impl]
+        saved = ctx.saved_tensors
+        B, Sl, _, D = dout.shape
+        lane = _Lane(dout)
+        douts = [_to_seq(lane, dout, P, ng, kvh * g, i, ulysses_pg) for i in range(ng)]
+        pend = []
+        for i in range(ng):
+            qi, ki, vi, oi, lse_i = saved[5 * i:5 * i + 5]
+            doi, ev = douts[i]
+            lane.wait(ev)
+            dqi, dki, dvi = bwd(ring_pg, doi, qi, ki, vi, oi, lse_i, softmax_scale=softmax_scale, causal=causal)
+            pend.append((_to_heads_issue(lane, dqi, P, ulysses_pg), _to_heads_issue(lane, dki, P, ulysses_pg),
+                         _to_heads_issue(lane, dvi, P, ulysses_pg)))
+        dq = torch.empty((B, Sl, Hq, D), dtype=dout.dtype, device=dout.device)
+        dk = torch.empty((B, Sl, Hkv, D), dtype=dout.dtype, device=dout.device)
+        dv = torch.empty_like(dk)
+        q5 = dq.view(B, Sl, P, ng, kvh * g, D)
+        k5, v5 = dk.view(B, Sl, P, ng, kvh, D), dv.view(B, Sl, P, ng, kvh, D)
+        for i, ((rq, e1), (rk, e2), (rv, e3)) in enumerate(pend):
+            for e in (e1, e2, e3):
+                lane.wait(e)
+            A.unpack_head_group(rq, q5[:, :, :, i])
+            A.unpack_head_group(rk, k5[:, :, :, i])
+            A.unpack_head_group(rv, v5[:, :, :, i])
+        lane.finish()
+        return dq, dk, dv, None, None, None, None, None
+
+
+class AsyncLongContextAttention(torch.nn.Module):
+    """Arguments (identical to the reference): scatter_idx, gather_idx, ring_impl_type."""
+
+    def __init__(self, scatter_idx: int = 2, gather_idx: int = 1, ring_impl_type: str = "basic") -> None:
+        super(AsyncLongContextAttention, self).__init__()
+        self.ring_pg = PROCESS_GROUP.RING_PG
+        self.ulysses_pg = PROCESS_GROUP.ULYSSES_PG
+        assert (
+            self.ulysses_pg is not None or self.ring_pg is not None
+        ), f"use set_seq_parallel_pg() first. Now ulysses pg {self.ulysses_pg} and ring pg {self.ring_pg}"
+        self.scatter_idx = scatter_idx
+        self.gather_idx = gather_idx
+        if ring_impl_type not in _RING_FWD_BWD:
+            raise KeyError(ring_impl_type)
+        self.ring_impl_type = ring_impl_type
+
+    def forward(self, query: Tensor, key: Tensor, value: Tensor, dropout_p=0.0, softmax_scale=None,
+                causal=False, window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
+                return_attn_probs=False, *args: Any) -> Tensor:
+        """query (bs, seqlen/P, hc, hs); key/value (bs, seqlen/P, hc_kv, hs) -> (bs, seqlen/P, hc, hs)."""
+        assert alibi_slopes is None
+        _check_hot_path_args(dropout_p, window_size, softcap)
+        return _AsyncUSPFunc.apply(query, key, value, softmax_scale, causal, self.ulysses_pg, self.ring_pg,
+                                   self.ring_impl_type)

@@ -122,3 +122,36 @@ def _a2a_worker(rank, ws):
 @pytest.mark.parametrize("ws", [2, 4])
 def test_all_to_all_round_trip(ws):
     assert all(run_distributed(_a2a_worker, ws))
+
+
+def _async_worker(rank, ws, ud, rd, impl, Hq, Hkv):
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    set_block_backend(OracleBlockBackend())
+    Y.set_seq_parallel_pg(ud, rd, rank, ws)
+    torch.manual_seed(0)
+    B, S, D = 2, 32 * ws, 32
+    q = torch.randn(B, S, Hq, D).to(torch.bfloat16)
+    k = torch.randn(B, S, Hkv, D).to(torch.bfloat16)
+    v = torch.randn(B, S, Hkv, D).to(torch.bfloat16)
+    do = torch.randn(B, S, Hq, D).to(torch.bfloat16)
+    ext = Y.EXTRACT_FUNC_DICT[impl]
+    res = []
+    for cls in (Y.LongContextAttention, Y.AsyncLongContextAttention):
+        lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=rd, ud=ud).detach().clone() for t in (q, k, v, do))
+        for t in (lq, lk, lv):
+            t.requires_grad_(True)
+        out = cls(ring_impl_type=impl)(lq, lk, lv, causal=True)
+        out.backward(ldo)
+        res.append([t.detach().float() for t in (out, lq.grad, lk.grad, lv.grad)])
+    # same maths per head, only the exchange is regrouped: results must be identical
+    return all(torch.equal(a, b) for a, b in zip(*res))
+
+
+@pytest.mark.parametrize("ws,ud,rd,impl,Hq,Hkv", [(4, 2, 2, "zigzag", 8, 4), (2, 2, 1, "basic", 4, 4),
+                                                  (4, 4, 1, "basic", 16, 8)])
+def test_async_layer_equals_hybrid_layer(ws, ud, rd, impl, Hq, Hkv):
+    """AsyncLongContextAttention (head-group pipeline) == LongContextAttention,
+    forward and backward, including GQA (which the reference's async layer cannot do)."""
+    assert all(run_distributed(_async_worker, ws, ud, rd, impl, Hq, Hkv))

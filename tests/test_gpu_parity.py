@@ -233,6 +233,31 @@ def test_single_rank_golden_through_long_context_attention(dev, single_rank_pg, 
             assert_close(_f(t.grad), getattr(g, key)[0], *TOL[g.dtype]["grad"], f"{g.name} {key}")
 
 
+def test_async_layer_on_gpu_streams(dev, single_rank_pg):
+    """AsyncLongContextAttention on the real side-stream lane (1-rank RCCL group: exchanges are
+    self-exchanges, 4 head groups): same result as LongContextAttention, forward and backward."""
+    import yunchang_amd as Y
+    import yunchang_amd.hybrid.async_attn_layer as AL
+    B, S, Hq, Hkv, D = 2, 1024, 8, 4, 128
+    groups = AL._groups
+    AL._groups = lambda hq, hkv, P: (4, hkv // P // 4, hq // hkv)      # force 4 groups at P = 1
+    request_restore = groups
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    q, k, v, do = (torch.randn(B, S, h, D, generator=gen).to(torch.bfloat16).to(dev) for h in (Hq, Hkv, Hkv, Hq))
+    res = []
+    for cls in (Y.LongContextAttention, Y.AsyncLongContextAttention):
+        tq, tk, tv = (t.clone().requires_grad_(True) for t in (q, k, v))
+        for _ in range(3):                      # repeat: exposes stream / allocator races
+            tq.grad = tk.grad = tv.grad = None
+            out = cls(ring_impl_type="zigzag")(tq, tk, tv, causal=True)
+            out.backward(do)
+        torch.cuda.synchronize()
+        res.append([out.detach(), tq.grad, tk.grad, tv.grad])
+    AL._groups = request_restore
+    for a, b, n in zip(res[0], res[1], ("out", "dq", "dk", "dv")):
+        assert torch.allclose(a.float(), b.float(), atol=4e-3, rtol=4e-3), n
+
+
 def test_c1_fp32_fixture_is_matched_by_bf16_kernel(dev, single_rank_pg):
     """BASELINE configs[0] (the reference's CPU-runnable case, fp32): our 16-bit kernel on the
     bf16-rounded inputs must sit within the bf16 envelope of the reference's fp32 result."""
