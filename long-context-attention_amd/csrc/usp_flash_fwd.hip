@@ -13,8 +13,8 @@
 //     A operand of V^T P^T directly; one block = exactly one LDS bank row per half-wave.
 //   * P needs no cross-lane shuffle: the key order of each PV k-step is DEFINED as the order in
 //     which the S^T accumulator holds keys, and V is read in that same order.
-//   * K/V are register-staged and double-buffered: global loads for tile t+1 are issued before
-//     the MFMAs of tile t and written to the other LDS buffer after them (one barrier per tile).
+//   * K/V tiles are double-buffered in LDS and filled by LDS-DMA (buffer_load ... lds) one tile (V) /
+//     two tiles (K) ahead: no staging registers, no ds_write; one barrier per tile.
 //   * exp2 with softmax_scale*log2(e) folded into one FMA per score.
 #include "usp_common.hpp"
 #include "usp_hip.h"
@@ -54,8 +54,6 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
   constexpr int KBYTES = kBN * ROWB;          // one K (or V) tile
   constexpr int NKT = D / 16;                 // k-steps of K Q^T
   constexpr int NDJ = D / 32;                 // 32-wide dim tiles of O^T
-  constexpr int NCH = kBN * D / 8;            // 16-byte chunks per tile
-  constexpr int NP = (NCH + kThreads - 1) / kThreads;
   // LDS: Kbuf[0], Kbuf[1], Vbuf[0], Vbuf[1]
   constexpr int VOFF = 2 * KBYTES;
 
@@ -113,59 +111,56 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
     for (int t = 0; t < NKT; ++t) qf[t] = *(const u32x4*)(qp + 32 * t);
   }
 
-  // ---- staging maps (per thread, tile independent) -------------------------------------------
+  // ---- staging: LDS-DMA (buffer_load ... lds): no staging registers, no ds_write ---------------------
+  // One wave-instruction fills 1 KiB of LDS linearly (wave-uniform base + lane*16):
+  //   K tile (row-major, slot swizzle): 1024/ROWB whole rows; the lane landing on physical slot p of row
+  //     r fetches logical slot p ^ swz(r) of that row (swizzle applied on the SOURCE side);
+  //   V tile ([4 keys][32 dims] blocks of 256 B): 4 blocks; lane l fetches key 4*kb + (l%16)/4,
+  //     dims 32*dj + 8*(l%4) .. +7 of block (kb, dj) = (4*piece + l/16) / NDJ, % NDJ.
+  // The tile offset is folded into the 64-bit descriptor base (no 32-bit overflow at any sequence
+  // length); num_records makes rows >= Sk read as 0 (they are masked).  hipcc drains the DMA
+  // (vmcnt(0)) in front of the s_barrier that ends the iteration.
   const char* kbase = p.k + 2 * (b * p.k_sb + hkv * p.k_sh);
   const char* vbase = p.v + 2 * (b * p.v_sb + hkv * p.v_sh);
-  int k_row[NP], k_goff[NP], k_loff[NP], v_row[NP], v_goff[NP], v_loff[NP];
+  constexpr int NW = kThreads / 64;
+  constexpr int CHUNKS = KBYTES / 1024;           // 1 KiB pieces per tile
+  constexpr int CPW = (CHUNKS + NW - 1) / NW;     // pieces per wave per tile
+  int k_voff[CPW], v_voff[CPW];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    const int c = i * kThreads + tid;
-    {  // K: row-major, swizzled slots
-      const int r = c / (D / 8), c8 = c % (D / 8);
-      k_row[i] = r;
-      k_goff[i] = c8 * 16;
-      k_loff[i] = r * ROWB + ((c8 ^ KSwz<D>::of(r)) * 16);
+  for (int i = 0; i < CPW; ++i) {
+    const int cidx = wave + NW * i;
+    {
+      const int r = cidx * (1024 / ROWB) + lane / (D / 8);
+      const int c8 = (lane % (D / 8)) ^ KSwz<D>::of(r);
+      k_voff[i] = r * (int)p.k_ss * 2 + c8 * 16;
     }
-    {  // V: 16 consecutive threads fill one [4 keys][32 dims] block
-      const int q4 = c & 3, kr = (c >> 2) & 3, r2 = c >> 4;
-      const int dj = r2 % NDJ, kb = r2 / NDJ;
-      v_row[i] = 4 * kb + kr;
-      v_goff[i] = (32 * dj + 8 * q4) * 2;
-      v_loff[i] = VOFF + (kb * NDJ + dj) * 256 + kr * 64 + q4 * 16;
+    {
+      const int blk = 4 * cidx + (lane >> 4);
+      const int kb = blk / NDJ, dj = blk % NDJ;
+      const int key = 4 * kb + ((lane & 15) >> 2), d = 32 * dj + 8 * (lane & 3);
+      v_voff[i] = key * (int)p.v_ss * 2 + d * 2;
     }
   }
-  u32x4 kst[NP], vst[NP];
-  auto load_k = [&](int tile) {
-    const int k0 = tile * kBN;
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-      if (NCH % kThreads == 0 || i * kThreads + tid < NCH) {
-        int kr = k0 + k_row[i];
-        kr = kr < p.Sk ? kr : p.Sk - 1;
-        kst[i] = *(const u32x4*)(kbase + 2 * (int64_t)kr * p.k_ss + k_goff[i]);
-      }
+  auto tile_rsrc = [&](const char* base, int64_t ss, int tile) {
+    const int64_t toff = (int64_t)tile * kBN * ss * 2;
+    int64_t rem = ((int64_t)(p.Sk - 1 - tile * kBN) * ss + D) * 2;
+    rem = rem < 0 ? 0 : (rem > 0xffffffffLL ? 0xffffffffLL : rem);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + toff), 0, (int)(uint32_t)rem, 0x00020000);
   };
-  auto load_v = [&](int tile) {
-    const int k0 = tile * kBN;
+  // piece i (of CPW) of K tile `tile` -> Kbuf[buf]; likewise V -> Vbuf[buf]
+  auto dma_k = [&](int tile, int buf) {
+    const auto rs_ = tile_rsrc(kbase, p.k_ss, tile);
 #pragma unroll
-    for (int i = 0; i < NP; ++i)
-      if (NCH % kThreads == 0 || i * kThreads + tid < NCH) {
-        int vr = k0 + v_row[i];
-        vr = vr < p.Sk ? vr : p.Sk - 1;
-        vst[i] = *(const u32x4*)(vbase + 2 * (int64_t)vr * p.v_ss + v_goff[i]);
-      }
+    for (int i = 0; i < CPW; ++i)
+      if (CHUNKS % NW == 0 || wave + NW * i < CHUNKS)
+        lds_dma16(rs_, smem + buf * KBYTES + (wave + NW * i) * 1024, k_voff[i]);
   };
-  auto store_k = [&](int buf) {
+  auto dma_v = [&](int tile, int buf) {
+    const auto rs_ = tile_rsrc(vbase, p.v_ss, tile);
 #pragma unroll
-    for (int i = 0; i < NP; ++i)
-      if (NCH % kThreads == 0 || i * kThreads + tid < NCH)
-        *(USP_LDS u32x4*)(smem + buf * KBYTES + k_loff[i]) = kst[i];
-  };
-  auto store_v = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-      if (NCH % kThreads == 0 || i * kThreads + tid < NCH)
-        *(USP_LDS u32x4*)(smem + buf * KBYTES + v_loff[i]) = vst[i];
+    for (int i = 0; i < CPW; ++i)
+      if (CHUNKS % NW == 0 || wave + NW * i < CHUNKS)
+        lds_dma16(rs_, smem + VOFF + buf * KBYTES + (wave + NW * i) * 1024, v_voff[i]);
   };
 
   // ---- per-lane LDS read bases -----------------------------------------------------------------
@@ -264,9 +259,8 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
 #pragma unroll
   for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
   if (nt > 0) {
-    load_k(0); load_v(0);
-    store_k(0); store_v(0);
-    if (nt > 1) { load_k(1); store_k(1); }
+    dma_k(0, 0); dma_v(0, 0);
+    if (nt > 1) dma_k(1, 1);
   }
   __syncthreads();
   if (nt > 0 && wave_kv_end > 0) qk(0, sa, sb);
@@ -303,41 +297,12 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
         for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
     }
   };
-  // Buffer loads: the tile offset is folded into the (64-bit, scalar) descriptor base so that no
-  // 32-bit offset can overflow at any sequence length; num_records makes rows >= Sk read as 0.
-  int k_voff[NP], v_voff[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    k_voff[i] = k_row[i] * (int)p.k_ss * 2 + k_goff[i];
-    v_voff[i] = v_row[i] * (int)p.v_ss * 2 + v_goff[i];
-  }
-  auto tile_rsrc = [&](const char* base, int64_t ss, int tile) {
-    const int64_t toff = (int64_t)tile * kBN * ss * 2;
-    int64_t rem = ((int64_t)(p.Sk - 1 - tile * kBN) * ss + D) * 2;
-    rem = rem < 0 ? 0 : (rem > 0xffffffffLL ? 0xffffffffLL : rem);
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(base + toff), 0, (int)(uint32_t)rem, 0x00020000);
-  };
-  auto bload_k = [&](int tile) {
-    const auto rs_ = tile_rsrc(kbase, p.k_ss, tile);
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-      if (NCH % kThreads == 0 || i * kThreads + tid < NCH)
-        kst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, k_voff[i], 0, 0);
-  };
-  auto bload_v = [&](int tile) {
-    const auto rs_ = tile_rsrc(vbase, p.v_ss, tile);
-#pragma unroll
-    for (int i = 0; i < NP; ++i)
-      if (NCH % kThreads == 0 || i * kThreads + tid < NCH)
-        vst[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_, v_voff[i], 0, 0);
-  };
-
   // one pipelined iteration: softmax + PV of tile jj (scores in ca/cb), scores of tile jj+1 into na/nb
   auto iter = [&](int jj, f32x16& ca, f32x16& cb, f32x16& na, f32x16& nb) {
     const int jk = jj + 2 < nt ? jj + 2 : nt - 1;           // clamped prefetch (redundant load at the end)
 #ifndef USP_ABLATE_NOSTAGE
-    bload_k(jk);
-    bload_v(jj + 1);
+    dma_k(jk, jj & 1);            // Kbuf[jj&1] held K(jj): last read in the previous iteration
+    dma_v(jj + 1, (jj + 1) & 1);  // Vbuf[(jj+1)&1] held V(jj-1): last read in the previous iteration
 #endif
     // ---------------- phase A ----------------
     USP_LDS const char* kb = smem + ((jj + 1) & 1) * KBYTES + k_rd_row;
@@ -351,8 +316,12 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
       kc[kt] = *(USP_LDS const u32x4*)(kb + 32 * ROWB + slot);
 #endif
     };
-    rd_k(0);
-    if (NKT > 1) rd_k(1);
+#ifndef USP_PF
+#define USP_PF 2
+#endif
+    constexpr int PF = USP_PF;                                  // LDS fragment prefetch distance (k-steps / MFMAs)
+#pragma unroll
+    for (int t = 0; t < PF && t < NKT; ++t) rd_k(t);
     const float mc = ((m_run == USP_NEG_INF) ? 0.f : m_run) * c;
     float rs = 0.f;
     u32x4 pf[4];
@@ -380,7 +349,7 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
     for (int sl = 0; sl < NA; ++sl) {
       const int kt = sl >> 1;
       if ((sl & 1) == 0) {
-        if (kt + 2 < NKT) rd_k(kt + 2);
+        if (kt + PF < NKT) rd_k(kt + PF);
         na = E::mfma(ka[kt], qf[kt], kt == 0 ? zero : na);
       } else {
         nb = E::mfma(kc[kt], qf[kt], kt == 0 ? zero : nb);
@@ -403,13 +372,13 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
       va[i] = u32x4{v0[0], v0[1], v1[0], v1[1]};
 #endif
     };
-    rd_v(0);
-    if (NB > 1) rd_v(1);
+#pragma unroll
+    for (int t = 0; t < PF && t < NB; ++t) rd_v(t);
     float mt = USP_NEG_INF;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      if (i + 2 < NB) rd_v(i + 2);
+      if (i + PF < NB) rd_v(i + PF);
       o[i % NDJ] = E::mfma(va[i], pf[i / NDJ], o[i % NDJ]);
       if (i < NB / 2) {
 #pragma unroll
@@ -421,10 +390,6 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
       __builtin_amdgcn_sched_barrier(0);
     }
     l_run += rs;
-#ifndef USP_ABLATE_NOSTAGE
-    store_k(jj & 1);
-    store_v((jj + 1) & 1);
-#endif
     decide(xhalf_max(mt));
 #ifndef USP_ABLATE_NOBARRIER
     __syncthreads();
@@ -452,8 +417,8 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
   // ---- generic tail: masked and/or inactive tiles ---------------------------------------------------
   for (; j < nt; ++j) {
     const int kt0 = j * kBN;
-    if (j + 2 < nt) load_k(j + 2);
-    if (j + 1 < nt) load_v(j + 1);
+    if (j + 2 < nt) dma_k(j + 2, j & 1);
+    if (j + 1 < nt) dma_v(j + 1, (j + 1) & 1);
     f32x16 na, nb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { na[r] = 0.f; nb[r] = 0.f; }
@@ -466,8 +431,6 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
       pv(j & 1, pf);
     }
     sa = na; sb = nb;
-    if (j + 2 < nt) store_k(j & 1);
-    if (j + 1 < nt) store_v((j + 1) & 1);
     __syncthreads();
   }
 
