@@ -123,9 +123,9 @@ def kernel_roofline(cfg, dev, iters=20):
 
 def pmc_traffic():
     """HBM bytes per launch of the forward kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_rocprof_v1_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
+    (profiles/r01_rocprof_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
     passes, C2 shape).  Counters cannot be collected inside this process; null if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_rocprof_v1_summary.txt")
+    path = os.path.join(ROOT, "profiles", "r01_rocprof_summary.txt")
     try:
         rd = wr = None
         for ln in open(path):
@@ -136,7 +136,7 @@ def pmc_traffic():
         if rd is None or wr is None:
             return None
         return {"read_MB": rd, "write_MB": wr, "algorithmic_MB": 268.4,
-                "source": "profiles/r01_rocprof_v1_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
+                "source": "profiles/r01_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"}
     except OSError:
         return None
 
