@@ -16,6 +16,8 @@
 //   * K/V tiles are double-buffered in LDS and filled by LDS-DMA (buffer_load ... lds) one tile (V) /
 //     two tiles (K) ahead: no staging registers, no ds_write; one barrier per tile.
 //   * exp2 with softmax_scale*log2(e) folded into one FMA per score.
+#include <stdlib.h>
+
 #include "usp_common.hpp"
 #include "usp_hip.h"
 
@@ -36,9 +38,7 @@ struct FwdParams {
   int merge_in, final_begin, final_end;
 };
 
-constexpr int kBM = 256;   // query rows per workgroup
 constexpr int kBN = 64;    // keys per KV tile
-constexpr int kThreads = 512;
 
 template <int D> struct KSwz {
   // 16-byte slots per K row and rows per 256-byte LDS bank row
@@ -47,9 +47,13 @@ template <int D> struct KSwz {
   static USP_DEV int of(int row) { return (row / RPB) & (SPR - 1); }
 };
 
-template <int D, int DT, bool CAUSAL>
-__global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams p) {
+// NWAVES waves per workgroup, 32 query rows each: 8 (one 256-row workgroup per CU) or 4 (two 128-row
+// workgroups per CU: half the causal diagonal waste, and the two workgroups desynchronise).
+template <int D, int DT, bool CAUSAL, int NWAVES>
+__global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdParams p) {
   using E = Elem<DT>;
+  constexpr int kThreads = 64 * NWAVES;
+  constexpr int kBM = 32 * NWAVES;
   constexpr int ROWB = D * 2;                 // bytes per K row
   constexpr int KBYTES = kBN * ROWB;          // one K (or V) tile
   constexpr int NKT = D / 16;                 // k-steps of K Q^T
@@ -482,15 +486,30 @@ __global__ __launch_bounds__(kThreads, 2) void flash_fwd_kernel(const FwdParams 
   }
 }
 
-template <int D, int DT>
-static int launch_fwd(const FwdParams& p, bool causal, hipStream_t st) {
+template <int D, int DT, int NWAVES>
+static int launch_fwd_w(FwdParams p, bool causal, hipStream_t st) {
+  p.nq = (p.Sq + 32 * NWAVES - 1) / (32 * NWAVES);
   const int grid = p.B * p.Hq * p.nq;
   const size_t lds = 2 * 2 * kBN * D * 2;
   if (causal)
-    hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true>), dim3(grid), dim3(kThreads), lds, st, p);
+    hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
   else
-    hipLaunchKernelGGL((flash_fwd_kernel<D, DT, false>), dim3(grid), dim3(kThreads), lds, st, p);
+    hipLaunchKernelGGL((flash_fwd_kernel<D, DT, false, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
   return hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
+}
+
+template <int D, int DT>
+static int launch_fwd(const FwdParams& p, bool causal, hipStream_t st) {
+  // Workgroup shape: 8 waves (256 rows) is 2-3 % faster when the chip is well filled (less K/V staging
+  // per row); 4 waves (128 rows, two workgroups per CU) wins by 15-17 % when the 8-wave grid would put at
+  // most two workgroups on each of the 256 CUs (measured, profiles/).  USP_FWD_WAVES=4|8 forces a shape.
+  static const int forced = [] { const char* e = getenv("USP_FWD_WAVES"); return e ? atoi(e) : 0; }();
+  int waves = forced;
+  if (waves != 4 && waves != 8) {
+    const int64_t grid8 = (int64_t)p.B * p.Hq * ((p.Sq + 255) / 256);
+    waves = grid8 <= 2 * 256 ? 4 : 8;
+  }
+  return waves == 4 ? launch_fwd_w<D, DT, 4>(p, causal, st) : launch_fwd_w<D, DT, 8>(p, causal, st);
 }
 
 static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
@@ -534,7 +553,7 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   p.lse_sb = a->lse_stride_b; p.lse_sh = a->lse_stride_h;
   p.B = a->B; p.Sq = a->Sq; p.Sk = a->Sk; p.Hq = a->Hq; p.Hkv = a->Hkv;
   p.G = a->Hq / a->Hkv;
-  p.nq = (a->Sq + kBM - 1) / kBM;
+  p.nq = 0;   // set per workgroup shape in launch_fwd_w
   p.causal_off = a->Sk - a->Sq;
   p.scale = a->softmax_scale;
   p.scale_log2 = a->softmax_scale * kLog2e;
