@@ -13,6 +13,10 @@
 // register-resident fragment sets R1,R2, S = X1 R1^T, T = X2 R2^T, and tr-read "X^T" operands for
 // the gradient MFMAs.  As in the forward, no cross-lane shuffle is needed for P / dS: the k-step
 // order of the gradient MFMAs is defined as the order the S accumulator holds rows.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "usp_common.hpp"
 #include "usp_hip.h"
 
@@ -493,6 +497,340 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   }
 }
 
+// ======================================================================================================
+// dK/dV, role-specialised waves (the default dK/dV launch; MODE 1 above is the single-role fallback).
+//
+// MODE 1 needs K AND V fragments (64 regs) plus dK AND dV accumulators (128 regs) per wave: > 256
+// registers, i.e. ONE wave per SIMD, and a lone wave can hide only ~5 instructions per MFMA (measured:
+// 57 % of its cycles are active issue, MFMA pipe 32 % busy).  Here every 32-key slice is served by TWO
+// waves that sit on the same SIMD (wave w and w + 4):
+//   role A (waves 0-3): S = Q K^T -> P = exp2(S*c - lse)  -> dV^T += dO^T P      (K frags, dV acc)
+//   role B (waves 4-7): dP = dO V^T, P from A, dS = P*(dP - delta) -> dK^T += Q^T dS (V frags, dK acc)
+// A hands P (bf16, 4 KiB per 64x32 block, raw register image: lane-linear ds_write/ds_read_b128) to B
+// through LDS; B runs ONE TILE BEHIND A, so the hand-off is ordered by the per-tile s_barrier that
+// exists anyway (double-buffered P slots, triple-buffered Q/dO tiles).  No recompute: 32 MFMAs per
+// wave and tile instead of 64, < 256 registers per wave, two waves per SIMD with complementary
+// MFMA / transcendental mixes.
+// ======================================================================================================
+template <int D, int DT, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams p) {
+  using E = Elem<DT>;
+  constexpr int NT = 512, NW = 8, OWN = 128;
+  constexpr int ROWB = D * 2;
+  constexpr int TILEB = kTile * ROWB;
+  constexpr int STATB = 2 * kTile * 4;
+  constexpr int BUFB = 2 * TILEB + STATB;
+  constexpr int NBUF = 3;
+  constexpr int PSLOT = 4096;                    // P of one 64 x 32 block, 16-bit
+  constexpr int POFF = NBUF * BUFB;              // P exchange: [4 slices][2 slots][PSLOT]
+  constexpr int NKT = D / 16;
+  constexpr int NDJ = D / 32;
+  constexpr int CHUNKS = TILEB / 1024;
+  constexpr int CPW = (CHUNKS + NW - 1) / NW;
+  constexpr int RPC = 1024 / ROWB;
+  constexpr int NGR = 2 * NDJ;                   // gradient MFMAs per half
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  USP_LDS char* smem = (USP_LDS char*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2;                    // 0: A (S, P, dV)   1: B (dP, dS, dK)
+  const int slice = wave & 3;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  const int off = p.causal_off;
+
+  int w = xcd_remap(blockIdx.x, gridDim.x);
+  const int blk = w % p.nblk;                    // early key blocks are seen by most rows: first
+  int rest = w / p.nblk;
+  int g = 0;
+  if (p.split) { g = rest % p.G; rest /= p.G; }
+  const int hkv = rest % p.Hkv, b = rest / p.Hkv;
+  const int h0 = hkv * p.G + g;
+  const int own0 = blk * OWN;
+  const int ow = own0 + slice * 32;
+  const int orow = ow + l31;
+  const int orow_c = orow < p.Sk ? orow : p.Sk - 1;
+
+  // K (role A) or V (role B) fragments of this wave's 32 keys
+  u32x4 rf[NKT];
+  {
+    const char* pr = role == 0 ? p.k + 2 * (b * p.k_sb + (int64_t)orow_c * p.k_ss + hkv * p.k_sh)
+                               : p.v + 2 * (b * p.v_sb + (int64_t)orow_c * p.v_ss + hkv * p.v_sh);
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) rf[t] = *(const u32x4*)(pr + 32 * t + 16 * hi);
+  }
+
+  int t_begin = 0, t_end = (p.Sq + kTile - 1) / kTile;
+  if (CAUSAL) {
+    const int first_q = own0 - off > 0 ? own0 - off : 0;
+    t_begin = first_q / kTile;
+    if (t_begin > t_end) t_begin = t_end;
+  }
+  const int per_head = t_end - t_begin;
+  const int heads_here = p.split ? 1 : p.G;
+  const int n_iter = per_head * heads_here;
+
+  // ---- LDS-DMA staging of the Q / dO tiles (as in flash_bwd_kernel) -------------------------------
+  int dma_voff1[CPW], dma_voff2[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const int cidx = wave + NW * i;
+    const int r = cidx * RPC + lane / (D / 8);
+    const int c8 = (lane % (D / 8)) ^ tile_swz<D>(r);
+    dma_voff1[i] = r * (int)p.q_ss * 2 + c8 * 16;
+    dma_voff2[i] = r * (int)p.do_ss * 2 + c8 * 16;
+  }
+  float st_lse = 0.f, st_delta = 0.f;
+  decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0)) rs1, rs2;
+  int dma_buf = 0;
+  const int64_t tb1 = (int64_t)kTile * p.q_ss * 2, tb2 = (int64_t)kTile * p.do_ss * 2;
+  int pf_tile = t_begin, pf_hh = 0;
+  const char *pf_p1 = nullptr, *pf_p2 = nullptr;
+  int64_t pf_rem1 = 0, pf_rem2 = 0;
+  auto pf_head = [&]() {
+    pf_tile = t_begin;
+    pf_p1 = p.q + 2 * (b * p.q_sb + (h0 + pf_hh) * p.q_sh) + t_begin * tb1;
+    pf_p2 = p.dout + 2 * (b * p.do_sb + (h0 + pf_hh) * p.do_sh) + t_begin * tb2;
+    pf_rem1 = ((int64_t)(p.Sq - 1 - t_begin * kTile) * p.q_ss + D) * 2;
+    pf_rem2 = ((int64_t)(p.Sq - 1 - t_begin * kTile) * p.do_ss + D) * 2;
+  };
+  pf_head();
+  auto stage_setup = [&](int buf) {
+    auto clampu = [](int64_t r) { return (int)(uint32_t)(r < 0 ? 0 : (r > 0xffffffffLL ? 0xffffffffLL : r)); };
+    rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)pf_p1, 0, clampu(pf_rem1), 0x00020000);
+    rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)pf_p2, 0, clampu(pf_rem2), 0x00020000);
+    dma_buf = buf;
+    if (tid < kTile) {
+      const int r = pf_tile * kTile + tid;
+      if (r < p.Sq) {
+        const float l_ = p.lse[b * p.lse_sb + (h0 + pf_hh) * p.lse_sh + r];
+        st_lse = (l_ == USP_NEG_INF) ? __builtin_inff() : l_ * kLog2e;
+        st_delta = p.delta[b * p.dl_sb + (h0 + pf_hh) * p.dl_sh + r];
+      } else {
+        st_lse = __builtin_inff();
+        st_delta = 0.f;
+      }
+    }
+    ++pf_tile;
+    pf_p1 += tb1; pf_p2 += tb2; pf_rem1 -= tb1; pf_rem2 -= tb2;
+    if (heads_here > 1 && pf_tile == t_end) { ++pf_hh; pf_head(); }
+  };
+  auto stage_all = [&]() {
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const int cidx = wave + NW * i;
+      if (CHUNKS % NW == 0 || cidx < CHUNKS) {
+        USP_LDS char* d1 = smem + dma_buf * BUFB + cidx * 1024;
+        lds_dma16(rs1, d1, dma_voff1[i]);
+        lds_dma16(rs2, d1 + TILEB, dma_voff2[i]);
+      }
+    }
+  };
+  auto stage_stats = [&](int buf) {
+    if (tid < kTile) {
+      *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * tid) = st_lse;
+      *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * kTile + 4 * tid) = st_delta;
+    }
+  };
+
+  // ---- per-lane LDS addresses ------------------------------------------------------------------------
+  const int rd_row = l31 * ROWB;
+  const int rd_x = hi ^ tile_swz<D>(l31);
+  int tr_addr[NDJ][2];
+  {
+    const int i = lane & 15, grp = (lane >> 4) & 1;
+#pragma unroll
+    for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int rr = 8 * e + 4 * hi + (i >> 2);
+        const int slot = 4 * dj + 2 * grp + ((i & 3) >> 1);
+        tr_addr[dj][e] = rr * ROWB + ((slot ^ tile_swz<D>(rr)) * 16) + (i & 1) * 8;
+      }
+  }
+  USP_LDS char* pex = smem + POFF + slice * 2 * PSLOT + lane * 16;   // + slot*PSLOT + (2h+k2)*1024
+
+  f32x16 acc[NDJ];                               // dV^T (role A) / dK^T (role B)
+#pragma unroll
+  for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[dj][r] = 0.f;
+  const float c = p.scale_log2;
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+  if (n_iter > 0) { stage_setup(0); stage_all(); stage_stats(0); }
+  __syncthreads();
+
+  // The streaming loop is instantiated once per role, with ROLE a compile-time constant, and the role
+  // is chosen by ONE branch around the whole loop: both roles execute the same barrier sequence.  (With
+  // run-time role tests inside the per-element code every MFMA slot was split into several basic
+  // blocks: 5.9 SALU per MFMA and 51 % of wave cycles parked; with one loop holding both roles' tile
+  // bodies their loop invariants added up and the kernel spilled.)
+  auto stream = [&](auto role_c) {
+    constexpr int ROLE = decltype(role_c)::value;
+    int tile_a = t_begin;                          // streamed tile role A works on in iteration `it`
+    int tile_b = t_begin;                          // ... and role B (the previous tile of A)
+    int buf_a = 0, buf_b = NBUF - 1;               // LDS buffers of those tiles (it % 3, (it - 1) % 3)
+    for (int it = 0; it <= n_iter; ++it) {
+      const bool prefetch = it + 1 < n_iter;
+      const int buf_n = buf_a + 1 == NBUF ? 0 : buf_a + 1;      // (it + 1) % NBUF
+      if (prefetch) { stage_setup(buf_n); stage_all(); }
+
+      const int my_it = it - ROLE;
+      const int buf_of_my = ROLE == 0 ? buf_a : buf_b;
+      const int tile = ROLE == 0 ? tile_a : tile_b;
+      tile_b = tile_a;
+      tile_a = (tile_a + 1 == t_end) ? t_begin : tile_a + 1;
+      const int s0 = tile * kTile;
+      const bool valid = my_it >= 0 && my_it < n_iter;
+      const bool active = valid && ow < p.Sk && (!CAUSAL || (s0 + kTile - 1 + off >= ow));
+      const bool need_mask = CAUSAL && (s0 + off < ow + 31);
+
+      if (active) {
+        {
+          const int buf = buf_of_my;
+          USP_LDS const char* x1 = smem + buf * BUFB;            // Q tile
+          USP_LDS const char* x2 = x1 + TILEB;                   // dO tile
+          USP_LDS const char* xs = ROLE == 0 ? x1 : x2;          // row-read operand of the S / dP chain
+          USP_LDS const char* xg = ROLE == 0 ? x2 : x1;          // transpose-read operand of the gradient
+          USP_LDS const char* stat = x1 + 2 * TILEB + (ROLE == 0 ? 0 : 4 * kTile);
+          USP_LDS char* pslot = pex + (my_it & 1) * PSLOT;
+          f32x16 sc[2];                                          // S (role A) / dP (role B) of the two halves
+          u32x4 pk[2][2];                                        // packed P (A) / dS (B): B operand of the gradient
+          u32x4 pin[2][2];                                       // role B: P received from A
+          f32x4 st4;
+          f32x4 stq[4];                                          // row statistics of one half, fetched ahead of use
+          auto load_stat = [&](int h, int j) {
+            stq[j] = *(USP_LDS const f32x4*)(stat + (32 * h + 4 * hi) * 4 + 32 * j);
+          };
+          auto load_stats = [&](int h) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) load_stat(h, j);
+          };
+
+          // element r of half h: role A: P = exp2(S*c - lse2); role B: dS = P * (dP - delta)
+          auto elem = [&](int h, int r) {
+            if ((r & 3) == 0) st4 = stq[r >> 2];
+            float val;
+            if (ROLE == 0) {
+              val = fast_exp2(__builtin_fmaf(sc[h][r], c, -st4[r & 3]));
+            } else {
+              const uint32_t wd = pin[h][r >> 3][(r & 7) >> 1];
+              const float pr = (r & 1) ? E::hi(wd) : E::lo(wd);
+              val = pr * (sc[h][r] - st4[r & 3]);
+            }
+            sc[h][r] = val;
+            if (r & 1) pk[h][r >> 3][(r & 7) >> 1] = E::pack2(sc[h][r - 1], sc[h][r]);
+            if (ROLE == 0 && (r & 7) == 7)                        // 8 elements done: hand one k-step of P to B
+              *(USP_LDS u32x4*)(pslot + (2 * h + (r >> 3)) * 1024) = pk[h][r >> 3];
+          };
+          auto chain_phase = [&](int h, int vh) {
+            u32x4 f[NKT];
+            auto rd = [&](int kt) {
+              f[kt] = *(USP_LDS const u32x4*)(xs + h * 32 * ROWB + rd_row + (((2 * kt) ^ rd_x) * 16));
+            };
+            rd(0);
+            if (NKT > 1) rd(1);
+            if (ROLE == 1) {                                     // fetch A's P of this half early
+              pin[h][0] = *(USP_LDS const u32x4*)(pslot + (2 * h) * 1024);
+              pin[h][1] = *(USP_LDS const u32x4*)(pslot + (2 * h + 1) * 1024);
+            }
+            if (vh >= 0) load_stats(vh);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+              if (kt + 2 < NKT) rd(kt + 2);
+              sc[h] = E::mfma(f[kt], rf[kt], kt == 0 ? zero16 : sc[h]);
+              if (vh >= 0) {
+#pragma unroll
+                for (int e = kt * 16 / NKT; e < (kt + 1) * 16 / NKT; ++e) elem(vh, e);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          };
+          auto grad_phase = [&](int h, int vh) {
+            u32x4 xa[NGR];
+            auto rd = [&](int i) {
+              const int k2 = i / NDJ, dj = i % NDJ;
+              USP_LDS const char* xb = xg + (2 * h + k2) * 16 * ROWB;
+              const u32x2 a0 = lds_read_tr16(xb + tr_addr[dj][0]);
+              const u32x2 a1 = lds_read_tr16(xb + tr_addr[dj][1]);
+              xa[i] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+            };
+            rd(0);
+            if (NGR > 1) rd(1);
+            if (vh >= 0) load_stats(vh);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NGR; ++i) {
+              if (i + 2 < NGR) rd(i + 2);
+              acc[i % NDJ] = E::mfma(xa[i], pk[h][i / NDJ], acc[i % NDJ]);
+              if (vh >= 0) {
+#pragma unroll
+                for (int e = i * 16 / NGR; e < (i + 1) * 16 / NGR; ++e) elem(vh, e);
+              }
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          };
+          auto apply_mask = [&](int h) {                         // role A only: query row i sees key j iff j <= i + off
+            const int d = orow - off - s0 - 4 * hi;              // one VGPR; thresholds are inline constants
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (d > 32 * h + (r & 3) + 8 * (r >> 2)) sc[h][r] = USP_NEG_INF;
+          };
+
+          chain_phase(0, -1);
+          if (ROLE == 0 && need_mask) apply_mask(0);
+          chain_phase(1, 0);
+          if (ROLE == 0 && need_mask) apply_mask(1);
+          grad_phase(0, 1);
+          grad_phase(1, -1);
+        }
+      }
+
+      if (prefetch) stage_stats(buf_n);
+      buf_b = buf_a;
+      buf_a = buf_n;
+      __syncthreads();
+    }
+
+  };
+  if (role == 0) stream(std::integral_constant<int, 0>{});
+  else stream(std::integral_constant<int, 1>{});
+
+  // ---- epilogue ------------------------------------------------------------------------------------------
+  if (orow < p.Sk) {
+    float* o32;
+    char* o16 = nullptr;
+    int accf;
+    const float mul = role == 0 ? 1.f : p.scale;
+    if (p.split) {
+      const int64_t wo = ((((int64_t)g * p.B + b) * p.Sk + orow) * p.Hkv + hkv) * D;
+      o32 = (role == 0 ? p.ws_dv : p.ws_dk) + wo; accf = 0;
+    } else if (role == 0) {
+      o32 = p.dv + b * p.dv_sb + (int64_t)orow * p.dv_ss + hkv * p.dv_sh; accf = p.accum_dv;
+      if (p.dv16) o16 = p.dv16 + 2 * (b * p.dv16_sb + (int64_t)orow * p.dv16_ss + hkv * p.dv16_sh);
+    } else {
+      o32 = p.dk + b * p.dk_sb + (int64_t)orow * p.dk_ss + hkv * p.dk_sh; accf = p.accum_dk;
+      if (p.dk16) o16 = p.dk16 + 2 * (b * p.dk16_sb + (int64_t)orow * p.dk16_ss + hkv * p.dk16_sh);
+    }
+#pragma unroll
+    for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int d0 = 32 * dj + 8 * g4 + 4 * hi;
+        f32x4 v = {acc[dj][4 * g4] * mul, acc[dj][4 * g4 + 1] * mul, acc[dj][4 * g4 + 2] * mul,
+                   acc[dj][4 * g4 + 3] * mul};
+        if (accf) v += *(const f32x4*)(o32 + d0);
+        if (o16) *(u32x2*)(o16 + 2 * d0) = u32x2{E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+        else *(f32x4*)(o32 + d0) = v;
+      }
+  }
+}
+
 // dst[b,s,h,:] (+)= sum_g ws[g][b][s][h][:]   -- combines the per-query-head dK / dV partials
 template <int D, int DT>
 __global__ __launch_bounds__(256) void reduce_heads_kernel(const float* ws_k, const float* ws_v,
@@ -543,10 +881,19 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   // dK,dV
   p.nblk = (p.Sk + 127) / 128;
   int grid = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1);
-  if (causal)
-    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 1>), dim3(grid), dim3(256), lds1, st, p);
-  else
-    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 1>), dim3(grid), dim3(256), lds1, st, p);
+  static const bool legacy = [] { const char* e = getenv("USP_BWD_DKDV"); return e && e[0] == 'l'; }();
+  if (legacy) {      // single-role kernel, one wave per SIMD (kept for A/B runs: USP_BWD_DKDV=legacy)
+    if (causal)
+      hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 1>), dim3(grid), dim3(256), lds1, st, p);
+    else
+      hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 1>), dim3(grid), dim3(256), lds1, st, p);
+  } else {
+    constexpr size_t lds2 = 3 * (2 * kTile * D * 2 + 2 * kTile * 4) + 4 * 2 * 4096;
+    if (causal)
+      hipLaunchKernelGGL((flash_bwd_dkdv_kernel<D, DT, true>), dim3(grid), dim3(512), lds2, st, p);
+    else
+      hipLaunchKernelGGL((flash_bwd_dkdv_kernel<D, DT, false>), dim3(grid), dim3(512), lds2, st, p);
+  }
   if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
   if (p.split) {
     const int64_t items = (int64_t)p.B * p.Sk * p.Hkv * (D / 4);
