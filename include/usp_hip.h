@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USP_ABI_VERSION 2
+#define USP_ABI_VERSION 3
 
 enum { USP_BF16 = 0, USP_FP16 = 1 };
 
@@ -63,6 +63,19 @@ typedef struct usp_tensor {
  *     otherwise                      : acc[i] <- o  (fp32)             (needs acc.ptr != NULL)
  * `lse` is (B,Hq,Sq) with seq stride 1.  A single non-ring call uses merge_in=0,
  * final_begin=0, final_end=Sq, acc.ptr=NULL.
+ *
+ * Packed variable-length batches (replaces _flash_attn_varlen_forward as called at
+ * yunchang/ring/zigzag_ring_flash_attn_varlen.py:88-112 and ring_flash_attn_varlen.py:56-71, the
+ * k[half_index0] / q[half_index1] gathers at zigzag_ring_flash_attn_varlen.py:127-140, and the LSE
+ * (un)flatten of yunchang/ring/utils.py:96-117): seq_q / seq_k point to B (first_row, rows) int32
+ * pairs in DEVICE memory.  q/out/acc are (T,Hq,D) and k/v (T',Hkv,D) row-major token tensors
+ * (stride_b ignored); sequence b attends rows [first, first+rows) of each side, causal alignment per
+ * sequence; lse is (Hq,T): lse[h*lse_stride_h + row].  Sq / Sk are the MAXIMUM rows over the batch
+ * (they size the launch).  Sequences with 0 query rows are skipped; a sequence with 0 key rows gives
+ * blk_out = 0, blk_lse = -inf.  A (first,rows) pair may address any sub-range of the token tensors,
+ * e.g. the front or back half of every sequence -- no gather copies are needed.  In this mode
+ * final_begin / final_end count HALF sequences (0, 1 or 2): rows [final_begin*rows/2,
+ * final_end*rows/2) of every sequence are final (2 = to the end).
  * -------------------------------------------------------------------------------------------- */
 typedef struct usp_fwd_args {
   int32_t dtype;                 /* USP_BF16 | USP_FP16: element type of q,k,v,out */
@@ -76,6 +89,8 @@ typedef struct usp_fwd_args {
   int64_t lse_stride_b, lse_stride_h;
   int32_t merge_in;              /* 0 | 1 */
   int32_t final_begin, final_end;/* row range of this call whose result is final */
+  const int32_t* seq_q;          /* packed variable-length batch (both NULL = dense), see below */
+  const int32_t* seq_k;
 } usp_fwd_args;
 
 int usp_flash_fwd(const usp_fwd_args* args, void* stream);
@@ -95,6 +110,14 @@ int usp_flash_fwd(const usp_fwd_args* args, void* stream);
  * Outputs are fp32 (B,S,H,D) tensors: dq (+)= dQ, dk (+)= dK, dv (+)= dV, where "+=" is used when
  * the matching accum_* flag is non-zero and "=" otherwise.  Deterministic (no atomics).
  * `workspace` (optional) enables the GQA head split described at usp_flash_bwd_workspace_bytes().
+ *
+ * Packed variable-length batches (replaces _flash_attn_varlen_backward as called at
+ * yunchang/ring/zigzag_ring_flash_attn_varlen.py:208-231 / ring_flash_attn_varlen.py:125-147, the
+ * half-index gathers / scatters around it (:246-264) and get_half_lse (:45-58)): seq_q / seq_k as in
+ * usp_fwd_args -- B (first_row, rows) pairs in device memory; dout/q/dq/dq16 are (T,Hq,D) token
+ * tensors addressed through seq_q, k/v/dk/dv/dk16/dv16 (T',Hkv,D) through seq_k, lse/delta are
+ * (Hq,T); Sq / Sk are the maximum rows over the batch.  Gradient rows outside every sequence's
+ * range are not touched; sequences with 0 rows on either side are skipped entirely.
  * -------------------------------------------------------------------------------------------- */
 typedef struct usp_bwd_args {
   int32_t dtype;
@@ -113,6 +136,9 @@ typedef struct usp_bwd_args {
                                     there instead of being written back to the fp32 tensor X */
   void* workspace;               /* optional scratch (device, 16-byte aligned), see below; may be NULL */
   int64_t workspace_bytes;
+  const int32_t* seq_q;          /* packed variable-length batch (both NULL = dense), see below */
+  const int32_t* seq_k;
+  int64_t total_k;               /* packed mode: rows of the k/v/dk/dv token tensors (sizes the workspace) */
 } usp_bwd_args;
 
 int usp_flash_bwd(const usp_bwd_args* args, void* stream);

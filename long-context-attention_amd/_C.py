@@ -17,7 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libusp_hip.so")
 _lib = None
 
 USP_BF16, USP_FP16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class UspTensor(ctypes.Structure):
@@ -35,7 +35,8 @@ class UspFwdArgs(ctypes.Structure):
                 ("lse", ctypes.c_void_p), ("lse_stride_b", ctypes.c_int64),
                 ("lse_stride_h", ctypes.c_int64),
                 ("merge_in", ctypes.c_int32), ("final_begin", ctypes.c_int32),
-                ("final_end", ctypes.c_int32)]
+                ("final_end", ctypes.c_int32),
+                ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p)]
 
 
 class UspBwdArgs(ctypes.Structure):
@@ -51,7 +52,8 @@ class UspBwdArgs(ctypes.Structure):
                 ("accum_dq", ctypes.c_int32), ("accum_dk", ctypes.c_int32),
                 ("accum_dv", ctypes.c_int32),
                 ("dq16", UspTensor), ("dk16", UspTensor), ("dv16", UspTensor),
-                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64)]
+                ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
+                ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("total_k", ctypes.c_int64)]
 
 
 EXPORTS = ("usp_flash_fwd", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
@@ -160,6 +162,84 @@ def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=No
     a.final_begin = final_begin
     a.final_end = Sq if final_end is None else final_end
     _check(load().usp_flash_fwd(ctypes.byref(a), _stream()), "usp_flash_fwd")
+
+
+def _t3(t: Optional[torch.Tensor]) -> UspTensor:
+    """(T,H,D) token tensor with unit dim stride -> usp_tensor (batch stride unused)."""
+    if t is None:
+        return UspTensor(None, 0, 0, 0)
+    assert t.dim() == 3, t.shape
+    if t.stride(2) != 1:
+        raise ValueError("last (head_dim) stride must be 1")
+    return UspTensor(t.data_ptr(), 0, t.stride(0), t.stride(1))
+
+
+def _lse2(t: torch.Tensor):
+    """(H,T) fp32 with unit token stride -> (ptr, 0, stride_h)."""
+    assert t.dim() == 2 and t.dtype == torch.float32
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        raise ValueError("lse/delta must have unit stride along the tokens")
+    return ctypes.c_void_p(t.data_ptr()), 0, t.stride(0)
+
+
+def _seq(t: torch.Tensor, n: int) -> ctypes.c_void_p:
+    """(n,2) int32 device tensor of (first_row, rows) pairs."""
+    if t.dtype != torch.int32 or tuple(t.shape) != (n, 2) or not t.is_contiguous():
+        raise ValueError("sequence table must be a contiguous (num_seq, 2) int32 tensor")
+    _require_cuda(t)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def flash_fwd_packed(q, k, v, seq_q, seq_k, max_q: int, max_k: int, softmax_scale: float,
+                     causal: bool, lse, out=None, acc=None, merge_in: bool = False,
+                     final_begin: int = 0, final_end: int = 2):
+    """usp_flash_fwd in packed variable-length mode.  q/out/acc (T,Hq,D), k/v (T',Hkv,D), lse (Hq,T)
+    fp32; seq_q/seq_k (num_seq,2) int32 device tables of (first_row, rows); final_begin/final_end
+    count half sequences (0,1,2)."""
+    _require_cuda(q, k, v, lse, out, acc)
+    n = seq_q.shape[0]
+    a = UspFwdArgs()
+    a.dtype = dtype_code(q.dtype)
+    a.B, a.Sq, a.Sk, a.Hq, a.Hkv, a.D = n, int(max_q), int(max_k), q.shape[1], k.shape[1], q.shape[2]
+    a.causal = 1 if causal else 0
+    a.softmax_scale = float(softmax_scale)
+    a.q, a.k, a.v, a.out, a.acc = _t3(q), _t3(k), _t3(v), _t3(out), _t3(acc)
+    a.lse, a.lse_stride_b, a.lse_stride_h = _lse2(lse)
+    a.merge_in = 1 if merge_in else 0
+    a.final_begin, a.final_end = int(final_begin), int(final_end)
+    a.seq_q, a.seq_k = _seq(seq_q, n), _seq(seq_k, n)
+    _check(load().usp_flash_fwd(ctypes.byref(a), _stream()), "usp_flash_fwd")
+
+
+def flash_bwd_packed(dout, q, k, v, lse, delta, seq_q, seq_k, max_q: int, max_k: int, dq, dk, dv,
+                     softmax_scale: float, causal: bool, accum_dq=False, accum_dk=False,
+                     accum_dv=False, dq16=None, dk16=None, dv16=None):
+    """usp_flash_bwd in packed variable-length mode (layouts as flash_fwd_packed; lse/delta (Hq,T))."""
+    _require_cuda(dout, q, k, v, lse, delta, dq, dk, dv, dq16, dk16, dv16)
+    n = seq_q.shape[0]
+    a = UspBwdArgs()
+    a.dtype = dtype_code(q.dtype)
+    a.B, a.Sq, a.Sk, a.Hq, a.Hkv, a.D = n, int(max_q), int(max_k), q.shape[1], k.shape[1], q.shape[2]
+    a.causal = 1 if causal else 0
+    a.softmax_scale = float(softmax_scale)
+    a.dout, a.q, a.k, a.v = _t3(dout), _t3(q), _t3(k), _t3(v)
+    a.lse, a.lse_stride_b, a.lse_stride_h = _lse2(lse)
+    a.delta, a.delta_stride_b, a.delta_stride_h = _lse2(delta)
+    for t in (dq, dk, dv):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("dq/dk/dv buffers of usp_flash_bwd are fp32")
+    a.dq, a.dk, a.dv = _t3(dq), _t3(dk), _t3(dv)
+    a.dq16, a.dk16, a.dv16 = _t3(dq16), _t3(dk16), _t3(dv16)
+    a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
+    a.seq_q, a.seq_k = _seq(seq_q, n), _seq(seq_k, n)
+    a.total_k = k.shape[0]
+    L = load()
+    need = L.usp_flash_bwd_workspace_bytes(ctypes.byref(a))
+    ws = None
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
+    _check(L.usp_flash_bwd(ctypes.byref(a), _stream()), "usp_flash_bwd")
 
 
 def bwd_delta(dout, out, delta):

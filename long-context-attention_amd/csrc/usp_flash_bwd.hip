@@ -40,9 +40,33 @@ struct BwdParams {
   int accum_dq, accum_dk, accum_dv;
   char* dq16; char* dk16; char* dv16;   // optional 16-bit final outputs
   int64_t dq16_sb, dq16_ss, dq16_sh, dk16_sb, dk16_ss, dk16_sh, dv16_sb, dv16_ss, dv16_sh;
-  float* ws_dk; float* ws_dv;        // head-split partials [G][B][Sk][Hkv][D] fp32 (MODE 1, G > 1)
+  float* ws_dk; float* ws_dv;        // head-split partials [G][ws_rows][Hkv][D] fp32 (G > 1)
+  int64_t ws_rows;                    // key rows per head-group slab: B*Sk, packed mode: rows of k
   int split;                          // 1: one workgroup per (query head, key block)
+  const int* seq_q; const int* seq_k; // packed variable-length batch: B (first row, rows) pairs, or NULL
 };
+
+// Packed variable-length batch: rebase the local copy of the parameters on the rows of sequence b (the
+// host passes batch strides of 0 in this mode, so every `b * stride_b` vanishes).  Returns false if the
+// sequence is empty on either side; *ws_row0 = first row of the sequence in the dK/dV workspace slabs.
+USP_DEV bool bind_sequence(BwdParams& p, int b, int64_t* ws_row0) {
+  if (p.seq_q == nullptr) { *ws_row0 = (int64_t)b * p.Sk; return true; }
+  const int qf = p.seq_q[2 * b], ql = p.seq_q[2 * b + 1];
+  const int kf = p.seq_k[2 * b], kl = p.seq_k[2 * b + 1];
+  *ws_row0 = kf;
+  if (ql <= 0 || kl <= 0) return false;
+  p.dout += 2 * qf * p.do_ss; p.q += 2 * qf * p.q_ss;
+  p.k += 2 * kf * p.k_ss; p.v += 2 * kf * p.v_ss;
+  p.lse += qf; p.delta += qf;
+  if (p.dq) p.dq += qf * p.dq_ss;
+  if (p.dk) p.dk += kf * p.dk_ss;
+  if (p.dv) p.dv += kf * p.dv_ss;
+  if (p.dq16) p.dq16 += 2 * qf * p.dq16_ss;
+  if (p.dk16) p.dk16 += 2 * kf * p.dk16_ss;
+  if (p.dv16) p.dv16 += 2 * kf * p.dv16_ss;
+  p.Sq = ql; p.Sk = kl; p.causal_off = kl - ql;
+  return true;
+}
 
 constexpr int kTile = 64;           // streamed rows per LDS tile
 
@@ -55,7 +79,7 @@ template <int D> USP_DEV int tile_swz(int row) {
 
 template <int D, int DT, bool CAUSAL, int MODE>
 __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flash_bwd_kernel(
-    const BwdParams p) {
+    const BwdParams p_in) {
   using E = Elem<DT>;
   constexpr int NT = MODE == 0 ? 512 : 256;     // threads
   constexpr int OWN = (NT / 64) * 32;           // rows owned by the workgroup (256 q rows / 128 keys)
@@ -74,9 +98,9 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31;
   const int hi = lane >> 5;
-  const int off = p.causal_off;
 
   // ---- work item --------------------------------------------------------------------------------
+  BwdParams p = p_in;
   int w = xcd_remap(blockIdx.x, gridDim.x);
   const int blk_r = w % p.nblk;
   int rest = w / p.nblk;
@@ -94,7 +118,11 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
     h0 = hkv * p.G + g;
     split_g = g;
   }
+  int64_t ws_row0;
+  if (!bind_sequence(p, b, &ws_row0)) return;
   const int own0 = blk * OWN;                  // first owned row (query row / key)
+  if (p.seq_q != nullptr && own0 >= (MODE == 0 ? p.Sq : p.Sk)) return;   // past the end of its sequence
+  const int off = p.causal_off;
   const int ow = own0 + wave * 32;             // first row owned by this wave
   const int orow = ow + l31;                   // this lane's row
   const int own_len = MODE == 0 ? p.Sq : p.Sk;
@@ -466,7 +494,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
       if (p.dq16) h1 = p.dq16 + 2 * (b * p.dq16_sb + (int64_t)orow * p.dq16_ss + h0 * p.dq16_sh);
     } else {
       if (p.split) {   // per-head partial, combined (deterministically) by reduce_heads_kernel
-        const int64_t wo = ((((int64_t)split_g * p.B + b) * p.Sk + orow) * p.Hkv + hkv) * D;
+        const int64_t wo = (((int64_t)split_g * p.ws_rows + ws_row0 + orow) * p.Hkv + hkv) * D;
         o1 = p.ws_dk + wo; acc_f1 = 0;
         o2 = p.ws_dv + wo; acc_f2 = 0;
       } else {
@@ -513,7 +541,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 // MFMA / transcendental mixes.
 // ======================================================================================================
 template <int D, int DT, bool CAUSAL>
-__global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams p) {
+__global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams p_in) {
   using E = Elem<DT>;
   constexpr int NT = 512, NW = 8, OWN = 128;
   constexpr int ROWB = D * 2;
@@ -540,8 +568,8 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   const int slice = wave & 3;
   const int l31 = lane & 31;
   const int hi = lane >> 5;
-  const int off = p.causal_off;
 
+  BwdParams p = p_in;
   int w = xcd_remap(blockIdx.x, gridDim.x);
   const int blk = w % p.nblk;                    // early key blocks are seen by most rows: first
   int rest = w / p.nblk;
@@ -549,7 +577,11 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   if (p.split) { g = rest % p.G; rest /= p.G; }
   const int hkv = rest % p.Hkv, b = rest / p.Hkv;
   const int h0 = hkv * p.G + g;
+  int64_t ws_row0;
+  if (!bind_sequence(p, b, &ws_row0)) return;
   const int own0 = blk * OWN;
+  if (p.seq_q != nullptr && own0 >= p.Sk) return;            // past the end of its sequence
+  const int off = p.causal_off;
   const int ow = own0 + slice * 32;
   const int orow = ow + l31;
   const int orow_c = orow < p.Sk ? orow : p.Sk - 1;
@@ -808,7 +840,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
     int accf;
     const float mul = role == 0 ? 1.f : p.scale;
     if (p.split) {
-      const int64_t wo = ((((int64_t)g * p.B + b) * p.Sk + orow) * p.Hkv + hkv) * D;
+      const int64_t wo = (((int64_t)g * p.ws_rows + ws_row0 + orow) * p.Hkv + hkv) * D;
       o32 = (role == 0 ? p.ws_dv : p.ws_dk) + wo; accf = 0;
     } else if (role == 0) {
       o32 = p.dv + b * p.dv_sb + (int64_t)orow * p.dv_ss + hkv * p.dv_sh; accf = p.accum_dv;
@@ -831,18 +863,15 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   }
 }
 
-// dst[b,s,h,:] (+)= sum_g ws[g][b][s][h][:]   -- combines the per-query-head dK / dV partials
+// dst[b,s,h,:] (+)= sum_g ws[g][row][h][:]   -- combines the per-query-head dK / dV partials.
+// Dense: row = b*S + s.  Packed: (b, s) runs over B x max rows; sequence b owns rows first_b + s, s < rows_b.
 template <int D, int DT>
-__global__ __launch_bounds__(256) void reduce_heads_kernel(const float* ws_k, const float* ws_v,
-                                                           float* dk, float* dv, int64_t dk_sb,
-                                                           int64_t dk_ss, int64_t dk_sh, int64_t dv_sb,
-                                                           int64_t dv_ss, int64_t dv_sh, int B, int S, int H,
-                                                           int G, int acc_k, int acc_v, BwdParams p) {
+__global__ __launch_bounds__(256) void reduce_heads_kernel(const BwdParams p) {
   using E = Elem<DT>;
   constexpr int C4 = D / 4;
-  const int64_t rows = (int64_t)B * S * H;
-  const int64_t total = rows * C4;
-  const int64_t gstride = rows * D;
+  const int S = p.Sk, H = p.Hkv;
+  const int64_t total = (int64_t)p.B * S * H * C4;
+  const int64_t gstride = p.ws_rows * H * D;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c4 = (int)(i % C4);
     const int64_t r = i / C4;
@@ -850,23 +879,30 @@ __global__ __launch_bounds__(256) void reduce_heads_kernel(const float* ws_k, co
     const int64_t bs = r / H;
     const int sidx = (int)(bs % S);
     const int b = (int)(bs / S);
-    float* pk = dk + b * dk_sb + (int64_t)sidx * dk_ss + h * dk_sh + 4 * c4;
-    float* pv = dv + b * dv_sb + (int64_t)sidx * dv_ss + h * dv_sh + 4 * c4;
-    f32x4 ak = acc_k ? *(const f32x4*)pk : f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 av = acc_v ? *(const f32x4*)pv : f32x4{0.f, 0.f, 0.f, 0.f};
-    const int64_t o = r * D + 4 * c4;
-    for (int g = 0; g < G; ++g) {
-      ak += *(const f32x4*)(ws_k + g * gstride + o);
-      av += *(const f32x4*)(ws_v + g * gstride + o);
+    int64_t row = sidx, wrow = bs, bb = b;       // row inside dk/dv (with b), row inside a workspace slab
+    if (p.seq_k != nullptr) {
+      if (sidx >= p.seq_k[2 * b + 1] || p.seq_q[2 * b + 1] <= 0) continue;
+      row = wrow = p.seq_k[2 * b] + sidx;
+      bb = 0;
+    }
+    const int64_t e = 4 * c4;
+    float* pk = p.dk ? p.dk + bb * p.dk_sb + row * p.dk_ss + h * p.dk_sh + e : nullptr;
+    float* pv = p.dv ? p.dv + bb * p.dv_sb + row * p.dv_ss + h * p.dv_sh + e : nullptr;
+    f32x4 ak = p.accum_dk ? *(const f32x4*)pk : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 av = p.accum_dv ? *(const f32x4*)pv : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t o = (wrow * H + h) * D + e;
+    for (int g = 0; g < p.G; ++g) {
+      ak += *(const f32x4*)(p.ws_dk + g * gstride + o);
+      av += *(const f32x4*)(p.ws_dv + g * gstride + o);
     }
     if (p.dk16) {
-      char* hk = p.dk16 + 2 * (b * p.dk16_sb + (int64_t)sidx * p.dk16_ss + h * p.dk16_sh + 4 * c4);
+      char* hk = p.dk16 + 2 * (bb * p.dk16_sb + row * p.dk16_ss + h * p.dk16_sh + e);
       *(u32x2*)hk = u32x2{E::pack2(ak[0], ak[1]), E::pack2(ak[2], ak[3])};
     } else {
       *(f32x4*)pk = ak;
     }
     if (p.dv16) {
-      char* hv = p.dv16 + 2 * (b * p.dv16_sb + (int64_t)sidx * p.dv16_ss + h * p.dv16_sh + 4 * c4);
+      char* hv = p.dv16 + 2 * (bb * p.dv16_sb + row * p.dv16_ss + h * p.dv16_sh + e);
       *(u32x2*)hv = u32x2{E::pack2(av[0], av[1]), E::pack2(av[2], av[3])};
     } else {
       *(f32x4*)pv = av;
@@ -899,9 +935,7 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
     const int64_t items = (int64_t)p.B * p.Sk * p.Hkv * (D / 4);
     int64_t rg = (items + 255) / 256;
     rg = rg > 2048 ? 2048 : rg;
-    hipLaunchKernelGGL((reduce_heads_kernel<D, DT>), dim3((int)rg), dim3(256), 0, st, p.ws_dk, p.ws_dv, p.dk,
-                       p.dv, p.dk_sb, p.dk_ss, p.dk_sh, p.dv_sb, p.dv_ss, p.dv_sh, p.B, p.Sk, p.Hkv, p.G,
-                       p.accum_dk, p.accum_dv, p);
+    hipLaunchKernelGGL((reduce_heads_kernel<D, DT>), dim3((int)rg), dim3(256), 0, st, p);
     if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
   }
   // dQ
@@ -922,9 +956,13 @@ static bool ok16(const usp_tensor& t, int esize) {
 
 }  // namespace usp
 
+static int64_t ws_rows_of(const usp_bwd_args* a) {
+  return (a->seq_q || a->seq_k) ? a->total_k : (int64_t)a->B * a->Sk;
+}
+
 extern "C" int64_t usp_flash_bwd_workspace_bytes(const usp_bwd_args* a) {
   if (!a || a->Hkv <= 0 || a->Hq <= a->Hkv || a->Hq % a->Hkv != 0) return 0;
-  return 2LL * a->Hq / a->Hkv * a->B * a->Sk * a->Hkv * a->D * 4;   // dK and dV partials, fp32
+  return 2LL * a->Hq / a->Hkv * ws_rows_of(a) * a->Hkv * a->D * 4;   // dK and dV partials, fp32
 }
 
 extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
@@ -936,6 +974,8 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   if (a->D != 32 && a->D != 64 && a->D != 128) return USP_EUNSUPPORTED;
   if (a->Hq % a->Hkv != 0) return USP_EUNSUPPORTED;
   if (!a->dout.ptr || !a->q.ptr || !a->k.ptr || !a->v.ptr) return USP_EINVAL;
+  const bool packed = a->seq_q != nullptr || a->seq_k != nullptr;
+  if (packed && !(a->seq_q && a->seq_k && a->total_k > 0)) return USP_EINVAL;
   // an fp32 tensor may be absent only if its 16-bit final output is given and nothing is accumulated
   auto need32 = [](const usp_tensor& t32, const usp_tensor& t16, int accum) { return !t16.ptr || accum; };
   if ((need32(a->dq, a->dq16, a->accum_dq) && !a->dq.ptr) || (need32(a->dk, a->dk16, a->accum_dk) && !a->dk.ptr) ||
@@ -975,6 +1015,12 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   p.dv16_sb = a->dv16.stride_b; p.dv16_ss = a->dv16.stride_s; p.dv16_sh = a->dv16.stride_h;
   // GQA head split: with a workspace, every query head of a KV group gets its own workgroups and the
   // per-head partials are summed afterwards; without one the group's heads are looped inside a workgroup.
+  p.seq_q = a->seq_q; p.seq_k = a->seq_k;
+  p.ws_rows = ws_rows_of(a);
+  if (packed) {
+    p.do_sb = p.q_sb = p.k_sb = p.v_sb = p.lse_sb = p.dl_sb = 0;
+    p.dq_sb = p.dk_sb = p.dv_sb = p.dq16_sb = p.dk16_sb = p.dv16_sb = 0;
+  }
   const int64_t need = usp_flash_bwd_workspace_bytes(a);
   p.split = 0; p.ws_dk = nullptr; p.ws_dv = nullptr;
   if (need > 0 && a->workspace && a->workspace_bytes >= need &&

@@ -36,6 +36,7 @@ struct FwdParams {
   int causal_off;                 // Sk - Sq
   float scale, scale_log2;
   int merge_in, final_begin, final_end;
+  const int* seq_q; const int* seq_k;   // packed variable-length batch: B (first row, rows) pairs, or NULL
 };
 
 constexpr int kBN = 64;    // keys per KV tile
@@ -50,7 +51,7 @@ template <int D> struct KSwz {
 // NWAVES waves per workgroup, 32 query rows each: 8 (one 256-row workgroup per CU) or 4 (two 128-row
 // workgroups per CU: half the causal diagonal waste, and the two workgroups desynchronise).
 template <int D, int DT, bool CAUSAL, int NWAVES>
-__global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdParams p) {
+__global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdParams p_in) {
   using E = Elem<DT>;
   constexpr int kThreads = 64 * NWAVES;
   constexpr int kBM = 32 * NWAVES;
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   const int hi = lane >> 5;
 
   // ---- which (batch, head, query tile) ------------------------------------------------------
+  FwdParams p = p_in;
   int w = xcd_remap(blockIdx.x, gridDim.x);
   const int qt_r = w % p.nq;
   int rest = w / p.nq;
@@ -80,6 +82,26 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   const int hkv = rest % p.Hkv;
   const int b = rest / p.Hkv;
   const int h = hkv * p.G + g;
+
+  // ---- packed variable-length batch: bind this workgroup to the rows of sequence b -------------------
+  // (the host passes batch strides of 0 in this mode, so every `b * stride_b` below vanishes)
+  if (p.seq_q != nullptr) {
+    const int q_first = p.seq_q[2 * b], q_len = p.seq_q[2 * b + 1];
+    const int k_first = p.seq_k[2 * b], k_len = p.seq_k[2 * b + 1];
+    if (qt * kBM >= q_len) return;                          // whole workgroup past the end of its sequence
+    p.q += 2 * q_first * p.q_ss;
+    p.k += 2 * k_first * p.k_ss;
+    p.v += 2 * k_first * p.v_ss;
+    if (p.out) p.out += 2 * q_first * p.o_ss;
+    if (p.acc) p.acc += q_first * p.a_ss;
+    p.lse += q_first;
+    p.Sq = q_len;
+    p.Sk = k_len > 0 ? k_len : 0;
+    p.causal_off = p.Sk - q_len;
+    const int half = q_len >> 1;                            // final_begin/_end count half sequences here
+    p.final_begin = p.final_begin >= 2 ? q_len : p.final_begin * half;
+    p.final_end = p.final_end >= 2 ? q_len : p.final_end * half;
+  }
 
   const int q0 = qt * kBM;
   const int qw = q0 + wave * 32;
@@ -531,10 +553,13 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   if (a->Hq % a->Hkv != 0) return USP_EUNSUPPORTED;
   if (!tensor16_ok(a->q, 2) || !tensor16_ok(a->k, 2) || !tensor16_ok(a->v, 2))
     return USP_EUNSUPPORTED;
+  const bool packed = a->seq_q != nullptr || a->seq_k != nullptr;
+  if (packed && !(a->seq_q && a->seq_k)) return USP_EINVAL;
+  const int f_all = packed ? 2 : a->Sq;          // packed: final_begin/_end count half sequences (0,1,2)
   int fb = a->final_begin < 0 ? 0 : a->final_begin;
-  int fe = a->final_end > a->Sq ? a->Sq : a->final_end;
+  int fe = a->final_end > f_all ? f_all : a->final_end;
   if (fe < fb) fe = fb;
-  const bool any_final = fe > fb, any_acc = (fb > 0 || fe < a->Sq);
+  const bool any_final = fe > fb, any_acc = (fb > 0 || fe < f_all);
   if (any_final && !(a->out.ptr && (reinterpret_cast<uintptr_t>(a->out.ptr) & 7) == 0 &&
                      a->out.stride_b % 4 == 0 && a->out.stride_s % 4 == 0 &&
                      a->out.stride_h % 4 == 0))
@@ -559,6 +584,8 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   p.scale_log2 = a->softmax_scale * kLog2e;
   p.merge_in = a->merge_in ? 1 : 0;
   p.final_begin = fb; p.final_end = fe;
+  p.seq_q = a->seq_q; p.seq_k = a->seq_k;
+  if (packed) p.q_sb = p.k_sb = p.v_sb = p.o_sb = p.a_sb = p.lse_sb = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool causal = a->causal != 0;
   switch (a->D * 2 + a->dtype) {

@@ -33,6 +33,17 @@ class HipBlockBackend:
         _C.flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq,
                      accum_dk, accum_dv, dq16, dk16, dv16)
 
+    def fwd_packed(self, q, k, v, seq_q, seq_k, max_q, max_k, softmax_scale, causal, lse, out=None,
+                   acc=None, merge_in=False, final_begin=0, final_end=2):
+        _C.flash_fwd_packed(q, k, v, seq_q, seq_k, max_q, max_k, softmax_scale, causal, lse, out, acc,
+                            merge_in, final_begin, final_end)
+
+    def bwd_packed(self, dout, q, k, v, lse, delta, seq_q, seq_k, max_q, max_k, dq, dk, dv,
+                   softmax_scale, causal, accum_dq=False, accum_dk=False, accum_dv=False, dq16=None,
+                   dk16=None, dv16=None):
+        _C.flash_bwd_packed(dout, q, k, v, lse, delta, seq_q, seq_k, max_q, max_k, dq, dk, dv,
+                            softmax_scale, causal, accum_dq, accum_dk, accum_dv, dq16, dk16, dv16)
+
     def merge(self, acc, lse, blk_out, blk_lse, first):
         _C.lse_merge(acc, lse, blk_out, blk_lse, first)
 

@@ -375,6 +375,87 @@ def basic_ring_backward_sim(douts, qs, ks, vs, outs, lses, softmax_scale=None, c
 
 
 # ----------------------------------------------------------------------------
+# packed variable-length batches  (yunchang/ring/zigzag_ring_flash_attn_varlen.py,
+# yunchang/ring/ring_flash_attn_varlen.py, LSE layouts of yunchang/ring/utils.py:96-117)
+#
+# Token tensors are (T,H,D); sequence i owns rows cu_seqlens[i]:cu_seqlens[i+1].  Every step of the
+# reference's varlen schedules acts on each sequence independently (the varlen flash kernels never mix
+# sequences; get_half_index :27-42 and get_half_lse :45-58 cut every sequence in half exactly like the
+# dense `c = S // 2`), so the oracle runs the dense schedule restatements above per sequence with B = 1.
+# ----------------------------------------------------------------------------
+def _cu(cu_seqlens) -> List[int]:
+    return [int(c) for c in cu_seqlens]
+
+
+def zigzag_extract_local_varlen(x: np.ndarray, cu_seqlens, rank: int, world_size: int) -> np.ndarray:
+    """Ring rank `rank`'s shard of a packed (T,...) tensor: for every sequence, chunks `rank` and
+    `2P-1-rank` of its 2P equal chunks (the per-sequence form of extract_local.py:29-49, ud = 1).
+    Local cu_seqlens = cu_seqlens // P."""
+    cu = _cu(cu_seqlens)
+    parts = []
+    for a, b in zip(cu[:-1], cu[1:]):
+        assert (b - a) % (2 * world_size) == 0, "every sequence must split into 2*world_size chunks"
+        ch = np.array_split(x[a:b], 2 * world_size, axis=0)
+        parts += [ch[rank], ch[2 * world_size - 1 - rank]]
+    return np.concatenate(parts, axis=0)
+
+
+def basic_extract_local_varlen(x: np.ndarray, cu_seqlens, rank: int, world_size: int) -> np.ndarray:
+    """Contiguous chunk `rank` of every sequence (per-sequence form of extract_local.py:25-26)."""
+    cu = _cu(cu_seqlens)
+    parts = []
+    for a, b in zip(cu[:-1], cu[1:]):
+        assert (b - a) % world_size == 0
+        parts.append(np.array_split(x[a:b], world_size, axis=0)[rank])
+    return np.concatenate(parts, axis=0)
+
+
+def varlen_attention_ref(q, k, v, cu_seqlens, causal=True, softmax_scale=None, dtype=np.float64):
+    """Per-sequence attention_ref over a packed batch.  Returns out (T,Hq,D), lse (Hq,T) -- the
+    flattened LSE layout of utils.py:96-103."""
+    cu = _cu(cu_seqlens)
+    outs, lses = [], []
+    for a, b in zip(cu[:-1], cu[1:]):
+        o, l_ = attention_ref(q[None, a:b], k[None, a:b], v[None, a:b], causal, softmax_scale, dtype)
+        outs.append(o[0]); lses.append(l_[0])
+    return np.concatenate(outs, axis=0), np.concatenate(lses, axis=1)
+
+
+def _per_sequence(fwd_sim, bwd_sim, cu_local, qs, ks, vs, douts, softmax_scale, dtype, **kw):
+    cu = _cu(cu_local)
+    P = len(qs)
+    cut = lambda xs, a, b: [np.asarray(x[a:b], dtype)[None] for x in xs]
+    res = {key: [[] for _ in range(P)] for key in ("out", "lse", "dq", "dk", "dv")}
+    for a, b in zip(cu[:-1], cu[1:]):
+        q_i, k_i, v_i = cut(qs, a, b), cut(ks, a, b), cut(vs, a, b)
+        outs, lses = fwd_sim(q_i, k_i, v_i, softmax_scale, dtype=dtype, **kw)
+        for r in range(P):
+            res["out"][r].append(outs[r][0]); res["lse"][r].append(lses[r][0])
+        if douts is not None:
+            dqs, dks, dvs = bwd_sim(cut(douts, a, b), q_i, k_i, v_i, outs, lses, softmax_scale,
+                                    dtype=dtype, **kw)
+            for r in range(P):
+                res["dq"][r].append(dqs[r][0]); res["dk"][r].append(dks[r][0]); res["dv"][r].append(dvs[r][0])
+    cat = lambda key, ax: [np.concatenate(x, axis=ax) for x in res[key]] if res[key][0] else None
+    return cat("out", 0), cat("lse", 1), cat("dq", 0), cat("dk", 0), cat("dv", 0)
+
+
+def zigzag_ring_varlen_sim(qs, ks, vs, cu_seqlens_local, douts=None, softmax_scale=None, dtype=np.float64):
+    """zigzag_ring_flash_attn_varlen.py:61-157 (forward) and :160-290 (backward).  qs/ks/vs[r]: ring
+    rank r's local packed (T_local,H,D) tensors, every sequence in zigzag layout.  Returns per-rank
+    (outs (T,H,D), lses (H,T), dqs, dks, dvs); gradients are None without `douts`."""
+    return _per_sequence(zigzag_ring_forward_sim, zigzag_ring_backward_sim, cu_seqlens_local, qs, ks, vs,
+                         douts, softmax_scale, dtype)
+
+
+def basic_ring_varlen_sim(qs, ks, vs, cu_seqlens_local, douts=None, softmax_scale=None, causal=True,
+                          dtype=np.float64):
+    """ring_flash_attn_varlen.py:28-85 (forward) and :88-176 (backward): contiguous shards."""
+    return _per_sequence(basic_ring_forward_sim, basic_ring_backward_sim, cu_seqlens_local, qs, ks, vs,
+                         douts, softmax_scale, dtype, causal=causal)
+
+
+# ----------------------------------------------------------------------------
 # the whole hybrid layer, simulated  (yunchang/hybrid/attn_layer.py:57-161)
 # ----------------------------------------------------------------------------
 def usp_forward_sim(local_qs, local_ks, local_vs, ud, rd, ring_impl_type="zigzag", causal=True,

@@ -20,7 +20,24 @@ TOL = {
 
 
 def golden_files():
-    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+    """Dense fixtures (make_golden.py); the packed variable-length ones are varlen_golden_files()."""
+    return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
+                  if not os.path.basename(f).startswith("v_"))
+
+
+def varlen_golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "v_*.npz")))
+
+
+def make_inputs_varlen(lens, Hq, Hkv, D, seed=0):
+    """Must stay identical to tests/golden/make_golden_varlen.py:make_inputs_varlen."""
+    T = int(sum(lens))
+    rs = np.random.RandomState(seed)
+    q = rs.standard_normal((T, Hq, D)).astype(np.float32)
+    k = rs.standard_normal((T, Hkv, D)).astype(np.float32)
+    v = rs.standard_normal((T, Hkv, D)).astype(np.float32)
+    dout = rs.standard_normal((T, Hq, D)).astype(np.float32)
+    return q, k, v, dout
 
 
 def make_inputs(B, S, Hq, Hkv, D, seed=0):
@@ -72,6 +89,36 @@ class Golden:
 
     def shard(self, x, rank):
         return O.EXTRACT[self.impl](x, rank, self.ws, self.rd, self.ud)
+
+
+class VarlenGolden:
+    """A v_*.npz fixture: the reference's (zigzag_)ring_flash_attn_varlen_func run on gloo."""
+
+    def __init__(self, path):
+        z = np.load(path)
+        self.name = os.path.basename(path)[:-4]
+        for key in ("ws", "Hq", "Hkv", "D", "seed"):
+            setattr(self, key, int(z[key]))
+        self.impl = str(z["impl"])                      # zigzag | basic
+        self.dtype = str(z["dtype"])
+        self.lens = [int(x) for x in z["lens"]]          # global sequence lengths
+        self.cu = np.concatenate([[0], np.cumsum(self.lens)]).astype(np.int64)
+        self.cu_local = self.cu // self.ws
+        self.max_local = max(self.lens) // self.ws
+        q, k, v, dout = make_inputs_varlen(self.lens, self.Hq, self.Hkv, self.D, self.seed)
+        self.q, self.k, self.v, self.dout = (round_to(t, self.dtype) for t in (q, k, v, dout))
+        for key in ("out", "dq", "dk", "dv"):
+            setattr(self, key, [decode(z[f"{key}_r{r}"], self.dtype) for r in range(self.ws)])
+        self.lse = [z[f"lse_r{r}"].astype(np.float32) for r in range(self.ws)]     # (H, T_local)
+
+    def shard(self, x, rank):
+        f = O.zigzag_extract_local_varlen if self.impl == "zigzag" else O.basic_extract_local_varlen
+        return f(x, self.cu, rank, self.ws)
+
+    def sim(self, douts=None):
+        lq, lk, lv = ([self.shard(t, r) for r in range(self.ws)] for t in (self.q, self.k, self.v))
+        f = O.zigzag_ring_varlen_sim if self.impl == "zigzag" else O.basic_ring_varlen_sim
+        return f(lq, lk, lv, self.cu_local, douts)
 
 
 def assert_close(got, want, atol, rtol, what=""):

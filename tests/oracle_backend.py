@@ -69,6 +69,33 @@ class OracleBlockBackend:
             tot = val + _np(dst) if accum else val
             _put(d16 if d16 is not None else dst, tot)
 
+    # packed variable-length mode (include/usp_hip.h): every sequence is one B = 1 dense call on views
+    def fwd_packed(self, q, k, v, seq_q, seq_k, max_q, max_k, softmax_scale, causal, lse, out=None,
+                   acc=None, merge_in=False, final_begin=0, final_end=2):
+        for (qf, ql), (kf, kl) in zip(seq_q.tolist(), seq_k.tolist()):
+            assert ql <= max_q and kl <= max_k
+            if ql <= 0:
+                continue
+            half = ql // 2
+            fb = ql if final_begin >= 2 else final_begin * half
+            fe = ql if final_end >= 2 else final_end * half
+            self.fwd(q[None, qf:qf + ql], k[None, kf:kf + kl], v[None, kf:kf + kl], softmax_scale, causal,
+                     lse[None, :, qf:qf + ql], None if out is None else out[None, qf:qf + ql],
+                     None if acc is None else acc[None, qf:qf + ql], merge_in, fb, fe)
+
+    def bwd_packed(self, dout, q, k, v, lse, delta, seq_q, seq_k, max_q, max_k, dq, dk, dv,
+                   softmax_scale, causal, accum_dq=False, accum_dk=False, accum_dv=False, dq16=None,
+                   dk16=None, dv16=None):
+        cut = lambda t, a, n: None if t is None else t[None, a:a + n]
+        for (qf, ql), (kf, kl) in zip(seq_q.tolist(), seq_k.tolist()):
+            assert ql <= max_q and kl <= max_k
+            if ql <= 0 or kl <= 0:
+                continue
+            self.bwd(cut(dout, qf, ql), cut(q, qf, ql), cut(k, kf, kl), cut(v, kf, kl),
+                     lse[None, :, qf:qf + ql], delta[None, :, qf:qf + ql], cut(dq, qf, ql), cut(dk, kf, kl),
+                     cut(dv, kf, kl), softmax_scale, causal, accum_dq, accum_dk, accum_dv,
+                     cut(dq16, qf, ql), cut(dk16, kf, kl), cut(dv16, kf, kl))
+
     def merge(self, acc, lse, blk_out, blk_lse, first):
         if first:
             _put(acc, _np(blk_out)); _put(lse, _np(blk_lse))

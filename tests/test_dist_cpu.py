@@ -155,3 +155,56 @@ def test_async_layer_equals_hybrid_layer(ws, ud, rd, impl, Hq, Hkv):
     """AsyncLongContextAttention (head-group pipeline) == LongContextAttention,
     forward and backward, including GQA (which the reference's async layer cannot do)."""
     assert all(run_distributed(_async_worker, ws, ud, rd, impl, Hq, Hkv))
+
+
+# ---- packed variable-length ring schedules (SURVEY.md 8(f) row 4) -------------------------------------
+def _varlen_worker(rank, ws, path, packed_qkv):
+    import torch.distributed as dist
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    from golden_util import VarlenGolden
+
+    g = VarlenGolden(path)
+    set_block_backend(OracleBlockBackend())
+    dtype = getattr(torch, g.dtype)
+    layout = "zigzag" if g.impl == "zigzag" else "basic"
+    lq, lk, lv, ldo = (Y.extract_local_varlen(torch.from_numpy(t).to(dtype), g.cu, rank, ws, layout)
+                       for t in (g.q, g.k, g.v, g.dout))
+    cu_local = torch.tensor(g.cu_local, dtype=torch.int32)
+    kw = dict(dropout_p=0.0, causal=True, window_size=(-1, -1), alibi_slopes=None, deterministic=False,
+              return_attn_probs=True, group=dist.group.WORLD)
+    if packed_qkv:       # equal head counts only: exercises the strided-view (qkv[:, i]) path
+        qkv = torch.stack([lq, lk, lv], dim=1).requires_grad_(True)
+        fn = (Y.zigzag_ring_flash_attn_varlen_qkvpacked_func if g.impl == "zigzag"
+              else Y.ring_flash_attn_varlen_qkvpacked_func)
+        out, lse, _ = fn(qkv, cu_local, g.max_local, **kw)
+        out.backward(ldo)
+        gq, gk, gv = qkv.grad[:, 0], qkv.grad[:, 1], qkv.grad[:, 2]
+    else:
+        for t in (lq, lk, lv):
+            t.requires_grad_(True)
+        fn = Y.zigzag_ring_flash_attn_varlen_func if g.impl == "zigzag" else Y.ring_flash_attn_varlen_func
+        out, lse, _ = fn(lq, lk, lv, cu_local, g.max_local, **kw)
+        out.backward(ldo)
+        gq, gk, gv = lq.grad, lk.grad, lv.grad
+    assert lse.shape == (len(g.lens), g.Hq, g.max_local)          # the reference's padded layout
+    return dict(out=out.detach().float().numpy(), lse=Y.flatten_lse(lse.detach(), cu_local).numpy(),
+                dq=gq.float().numpy(), dk=gk.float().numpy(), dv=gv.float().numpy())
+
+
+from golden_util import varlen_golden_files  # noqa: E402
+
+
+@pytest.mark.parametrize("path", varlen_golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_varlen_ring_on_gloo_matches_reference_golden(path):
+    from golden_util import VarlenGolden
+    g = VarlenGolden(path)
+    res = run_distributed(_varlen_worker, g.ws, path, g.Hq == g.Hkv and "oneseq" in g.name)
+    atol, rtol = TOL[g.dtype]["out"]
+    gt, gr = TOL[g.dtype]["grad"]
+    for r in range(g.ws):
+        assert_close(res[r]["out"], g.out[r], atol, rtol, f"{g.name} out rank {r}")
+        assert_close(res[r]["lse"], g.lse[r], atol, rtol, f"{g.name} lse rank {r}")
+        for key in ("dq", "dk", "dv"):
+            assert_close(res[r][key], getattr(g, key)[r], gt, gr, f"{g.name} {key} rank {r}")

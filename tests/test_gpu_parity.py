@@ -480,3 +480,218 @@ def test_c5_rank_block_gqa_backward_sampled(dev):
     assert_close(_f(dq)[:, :, sl], rdq, *TOL[dt]["grad"], "dq")
     assert_close(_f(dk)[:, :, 1:2], rdk, 8e-2, 5e-2, "dk (sum over 8 query heads)")
     assert_close(_f(dv)[:, :, 1:2], rdv, 8e-2, 5e-2, "dv (sum over 8 query heads)")
+
+
+# ------------------------------------------------------------------------------------------------
+# packed variable-length mode (include/usp_hip.h seq_q / seq_k): kernels vs oracle, then the varlen ring
+# schedules vs the reference's own runs with virtual ranks
+# ------------------------------------------------------------------------------------------------
+PACKED = [
+    # lens_q, lens_k (None = same), Hq, Hkv, D, causal, dtype
+    ((64, 192, 320, 8), None, 4, 2, 128, True, "bfloat16"),      # GQA -> head-split workspace path
+    ((130, 62, 257, 1), None, 2, 2, 64, True, "bfloat16"),       # ragged, single-row sequence
+    ((100, 300), (260, 40), 2, 1, 128, False, "float16"),        # different q / k lengths, full
+    ((96, 33), (200, 77), 3, 3, 32, True, "bfloat16"),           # bottom-right causal per sequence
+]
+
+
+def _tables(lens, dev):
+    first = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    return torch.tensor(np.stack([first, lens], 1), dtype=torch.int32, device=dev)
+
+
+@pytest.mark.parametrize("lq,lk,Hq,Hkv,D,causal,dt", PACKED)
+def test_packed_kernels_vs_oracle(dev, lq, lk, Hq, Hkv, D, causal, dt):
+    from yunchang_amd import _C
+    lk = lq if lk is None else lk
+    Tq, Tk = sum(lq), sum(lk)
+    q, k, v, do = (_rand(s, dt, 10 + i) for i, s in enumerate(
+        [(Tq, Hq, D), (Tk, Hkv, D), (Tk, Hkv, D), (Tq, Hq, D)]))
+    tq, tk, tv, tdo = (_t(x, dt, dev) for x in (q, k, v, do))
+    sq, sk = _tables(lq, dev), _tables(lk, dev)
+    scale = D ** -0.5
+    out = torch.full((Tq, Hq, D), float("nan"), dtype=tq.dtype, device=dev)
+    lse = torch.full((Hq, Tq), float("nan"), dtype=torch.float32, device=dev)
+    _C.flash_fwd_packed(tq, tk, tv, sq, sk, max(lq), max(lk), scale, causal, lse, out=out)
+    cq, ck = np.concatenate([[0], np.cumsum(lq)]), np.concatenate([[0], np.cumsum(lk)])
+    ro = np.zeros((Tq, Hq, D)); rl = np.zeros((Hq, Tq))
+    rdq = np.zeros((Tq, Hq, D)); rdk = np.zeros((Tk, Hkv, D)); rdv = np.zeros((Tk, Hkv, D))
+    for i in range(len(lq)):
+        a, b, c, d = cq[i], cq[i + 1], ck[i], ck[i + 1]
+        o_i, l_i = O.block_fwd(q[None, a:b], k[None, c:d], v[None, c:d], scale, causal)
+        ro[a:b], rl[:, a:b] = o_i[0], l_i[0]
+    atol, rtol = TOL[dt]["out"]
+    assert_close(_f(out), ro, atol, rtol, "packed out")
+    fin = np.isfinite(rl)
+    lse_h = _f(lse)
+    assert (np.isfinite(lse_h) == fin).all()
+    assert_close(lse_h[fin], rl[fin], 2e-3, 1e-4, "packed lse")
+    # backward, fed with the oracle's rounded out / exact lse
+    o16 = round_to(ro.astype(np.float32), dt)
+    for i in range(len(lq)):
+        a, b, c, d = cq[i], cq[i + 1], ck[i], ck[i + 1]
+        g = O.block_bwd(do[None, a:b], q[None, a:b], k[None, c:d], v[None, c:d], o16[None, a:b],
+                        rl[None, :, a:b], scale, causal)
+        rdq[a:b], rdk[c:d], rdv[c:d] = g[0][0], g[1][0], g[2][0]
+    delta = torch.empty((Hq, Tq), dtype=torch.float32, device=dev)
+    _C.bwd_delta(tdo[None], _t(o16, dt, dev)[None], delta[None])
+    lse_t = torch.from_numpy(rl.astype(np.float32)).to(dev)
+    dq, dk, dv = (torch.empty_like(t) for t in (tq, tk, tv))
+    _C.flash_bwd_packed(tdo, tq, tk, tv, lse_t, delta, sq, sk, max(lq), max(lk), None, None, None, scale,
+                        causal, dq16=dq, dk16=dk, dv16=dv)
+    atol, rtol = TOL[dt]["grad"]
+    assert_close(_f(dq), rdq, atol, rtol, "packed dq")
+    assert_close(_f(dk), rdk, atol, rtol, "packed dk")
+    assert_close(_f(dv), rdv, atol, rtol, "packed dv")
+
+
+def test_packed_half_tables_merge_and_accumulate(dev):
+    """Sub-range tables (the zigzag s<=r / s>r steps): rows outside the tables must not be touched, the
+    fused merge must equal the oracle merge, fp32 gradients must accumulate in place."""
+    from yunchang_amd import _C
+    from yunchang_amd.ring.varlen_utils import SeqTables
+    dt, H, D = "bfloat16", 2, 64
+    lens = (64, 200, 36)
+    T = sum(lens)
+    q, k, v, do = (_rand((T, H, D), dt, 20 + i) for i in range(4))
+    tq, tk, tv, tdo = (_t(x, dt, dev) for x in (q, k, v, do))
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=dev)
+    tb = SeqTables(cu, max(lens), dev)
+    scale = D ** -0.5
+    # step A: q x front halves (full), adopt; step B: back halves of q x everything, merged in place
+    acc = torch.full((T, H, D), float("nan"), dtype=torch.float32, device=dev)
+    out = torch.full((T, H, D), float("nan"), dtype=tq.dtype, device=dev)
+    lse = torch.full((H, T), float("nan"), dtype=torch.float32, device=dev)
+    _C.flash_fwd_packed(tq, tk, tv, tb.full, tb.front, tb.max_full, tb.max_half, scale, False, lse, out, acc,
+                        False, 0, 1)                        # front half rows final, back half rows -> acc
+    _C.flash_fwd_packed(tq, tk, tv, tb.back, tb.full, tb.max_half, tb.max_full, scale, False, lse, out, acc,
+                        True, 0, 2)
+    ro = np.zeros((T, H, D)); rl = np.zeros((H, T))
+    cs = np.concatenate([[0], np.cumsum(lens)])
+    for i, n in enumerate(lens):
+        a, h = cs[i], n // 2
+        o1, l1 = O.block_fwd(q[None, a:a + n], k[None, a:a + h], v[None, a:a + h], scale, False)
+        o2, l2 = O.block_fwd(q[None, a + h:a + n], k[None, a:a + n], v[None, a:a + n], scale, False)
+        o, l_ = O.update_out_and_lse(None, None, o1, l1)
+        o, l_ = O.update_out_and_lse(o, l_, o2, l2, row_slice=slice(h, None))
+        ro[a:a + n], rl[:, a:a + n] = o[0], l_[0, :, :, 0].T
+    assert_close(_f(out), ro, *TOL[dt]["out"], "merged out")
+    assert_close(_f(lse), rl, 2e-3, 1e-4, "merged lse")
+    # backward into front-half key rows only, accumulating on top of known values
+    delta = torch.zeros((H, T), dtype=torch.float32, device=dev)
+    lse_t = torch.from_numpy(rl.astype(np.float32)).to(dev)
+    base = 3.0
+    dq = torch.full((T, H, D), base, dtype=torch.float32, device=dev)
+    dk = torch.full((T, H, D), base, dtype=torch.float32, device=dev)
+    dv = torch.full((T, H, D), base, dtype=torch.float32, device=dev)
+    _C.flash_bwd_packed(tdo, tq, tk, tv, lse_t, delta, tb.full, tb.front, tb.max_full, tb.max_half, dq, dk, dv,
+                        scale, False, accum_dq=True, accum_dk=True, accum_dv=True)
+    rdq = np.full((T, H, D), base); rdk = np.full((T, H, D), base); rdv = np.full((T, H, D), base)
+    for i, n in enumerate(lens):
+        a, h = cs[i], n // 2
+        zero_out = np.zeros((1, n, H, D))                      # delta = 0  <=>  out = 0
+        g = O.block_bwd(do[None, a:a + n], q[None, a:a + n], k[None, a:a + h], v[None, a:a + h], zero_out,
+                        rl[None, :, a:a + n], scale, False)
+        rdq[a:a + n] += g[0][0]; rdk[a:a + h] += g[1][0]; rdv[a:a + h] += g[2][0]
+    atol, rtol = TOL[dt]["grad"]
+    assert_close(_f(dq), rdq, atol, rtol, "dq")
+    assert_close(_f(dk), rdk, atol, rtol, "dk (back-half rows must stay untouched)")
+    assert_close(_f(dv), rdv, atol, rtol, "dv (back-half rows must stay untouched)")
+
+
+from golden_util import VarlenGolden, varlen_golden_files  # noqa: E402
+
+
+@pytest.mark.parametrize("path", varlen_golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_varlen_ring_golden_with_virtual_ranks(dev, path):
+    """The package's packed ring step functions on the HIP kernels, the ring emulated with virtual ranks on
+    one GPU, against the reference's (zigzag_)ring_flash_attn_varlen_func run (tests/golden/v_*.npz)."""
+    from yunchang_amd.kernels import get_block_backend
+    from yunchang_amd.ring import ring_flash_attn_varlen as RB
+    from yunchang_amd.ring import zigzag_ring_flash_attn_varlen as RZ
+    from yunchang_amd.ring.varlen_utils import SeqTables
+    g = VarlenGolden(path)
+    be = get_block_backend()
+    assert be.name == "hip"
+    P, dt = g.ws, g.dtype
+    tdt, f32 = getattr(torch, dt), torch.float32
+    scale = g.D ** -0.5
+    loc = {n: [_t(g.shard(getattr(g, n), r), dt, dev) for r in range(P)] for n in ("q", "k", "v", "dout")}
+    tb = SeqTables(torch.tensor(g.cu_local, dtype=torch.int32), g.max_local, dev)
+    T = loc["q"][0].shape[0]
+    outs, lses = [], []
+    for r in range(P):
+        out = torch.empty((T, g.Hq, g.D), dtype=tdt, device=dev)
+        lse = torch.empty((g.Hq, T), dtype=f32, device=dev)
+        acc = torch.empty((T, g.Hq, g.D), dtype=f32, device=dev)
+        for step in range(P):
+            src = (r - step) % P
+            if g.impl == "zigzag":
+                RZ.zigzag_varlen_fwd_step(be, r, P, step, tb, loc["q"][r], loc["k"][src], loc["v"][src], scale,
+                                          lse, out, acc)
+            else:
+                RB.basic_varlen_fwd_step(be, r, P, step, True, tb, loc["q"][r], loc["k"][src], loc["v"][src],
+                                         scale, lse, out, acc)
+        outs.append(out); lses.append(lse)
+        assert_close(_f(out), g.out[r], *TOL[dt]["out"], f"{g.name} out rank {r}")
+        assert_close(_f(lse), g.lse[r], *TOL[dt]["out"], f"{g.name} lse rank {r}")
+    st = []
+    for r in range(P):
+        delta = torch.empty((g.Hq, T), dtype=f32, device=dev)
+        be.delta(loc["dout"][r][None], outs[r][None], delta[None])
+        kshape = loc["k"][r].shape
+        st.append(dict(delta=delta, dq=torch.empty((T, g.Hq, g.D), dtype=f32, device=dev),
+                       dk=torch.empty(kshape, dtype=f32, device=dev), dv=torch.empty(kshape, dtype=f32, device=dev),
+                       bk=torch.empty(kshape, dtype=f32, device=dev), bv=torch.empty(kshape, dtype=f32, device=dev)))
+    for step in range(P):
+        if step > 0:                                           # the wire: accumulators move to rank+1
+            dks, dvs = [s["dk"] for s in st], [s["dv"] for s in st]
+            for r in range(P):
+                st[r]["dk"], st[r]["dv"] = dks[(r - 1) % P], dvs[(r - 1) % P]
+        for r in range(P):
+            s, src = st[r], (r - step) % P
+            dst_k, dst_v = (s["dk"], s["dv"]) if step == 0 else (s["bk"], s["bv"])
+            args = (loc["dout"][r], loc["q"][r], loc["k"][src], loc["v"][src], lses[r], s["delta"], scale, s["dq"],
+                    dst_k, dst_v)
+            if g.impl == "zigzag":
+                if 0 < step <= r:
+                    dst_k.zero_(); dst_v.zero_()
+                RZ.zigzag_varlen_bwd_block(be, r, P, step, tb, *args)
+                did = True
+            else:
+                did = RB.basic_varlen_bwd_block(be, r, P, step, True, tb, *args)
+            if step > 0 and did:
+                be.add(s["dk"], s["dk"], s["bk"]); be.add(s["dv"], s["dv"], s["bv"])
+    dks, dvs = [s["dk"] for s in st], [s["dv"] for s in st]
+    for r in range(P):                                         # final hop lands on the owner
+        assert_close(_f(st[r]["dq"].to(tdt)), g.dq[r], *TOL[dt]["grad"], f"{g.name} dq rank {r}")
+        assert_close(_f(dks[(r - 1) % P].to(tdt)), g.dk[r], *TOL[dt]["grad"], f"{g.name} dk rank {r}")
+        assert_close(_f(dvs[(r - 1) % P].to(tdt)), g.dv[r], *TOL[dt]["grad"], f"{g.name} dv rank {r}")
+
+
+def test_varlen_func_single_rank_autograd(dev, single_rank_pg):
+    """zigzag_ring_flash_attn_varlen_func end to end at ring degree 1 (autograd glue, padded LSE)."""
+    import torch.distributed as dist
+    import yunchang_amd as Y
+    dt, H, D = "bfloat16", 4, 128
+    lens = (256, 64, 130)
+    T = sum(lens)
+    q, k, v, do = (_rand((T, H, D), dt, 30 + i) for i in range(4))
+    tq, tk, tv = (_t(x, dt, dev).requires_grad_(True) for x in (q, k, v))
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=dev)
+    out, lse, _ = Y.zigzag_ring_flash_attn_varlen_func(tq, tk, tv, cu, max(lens), causal=True,
+                                                       return_attn_probs=True, group=dist.group.WORLD)
+    out.backward(_t(do, dt, dev))
+    ro, rl = O.varlen_attention_ref(q, k, v, np.concatenate([[0], np.cumsum(lens)]), True)
+    assert_close(_f(out), ro, *TOL[dt]["out"], "out")
+    assert lse.shape == (len(lens), H, max(lens))
+    assert_close(_f(Y.flatten_lse(lse.detach(), cu)), rl, 2e-3, 1e-4, "lse")
+    cs = np.concatenate([[0], np.cumsum(lens)])
+    o16 = round_to(ro.astype(np.float32), dt)
+    for i, n in enumerate(lens):
+        a = cs[i]
+        gq, gk, gv = O.block_bwd(do[None, a:a + n], q[None, a:a + n], k[None, a:a + n], v[None, a:a + n],
+                                 o16[None, a:a + n], rl[None, :, a:a + n], None, True)
+        assert_close(_f(tq.grad)[a:a + n], gq[0], *TOL[dt]["grad"], f"dq seq {i}")
+        assert_close(_f(tk.grad)[a:a + n], gk[0], *TOL[dt]["grad"], f"dk seq {i}")
+        assert_close(_f(tv.grad)[a:a + n], gv[0], *TOL[dt]["grad"], f"dv seq {i}")

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libusp_hip.so does not export {name}"
     assert set(_C.EXPORTS) == declared
     L = _C.load()
-    assert L.usp_abi_version() == 2
+    assert L.usp_abi_version() == _C.ABI_VERSION == 3
     assert b"head_dim" in L.usp_strerror(-2)
 
 

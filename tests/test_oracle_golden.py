@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import usp_oracle as O
-from golden_util import Golden, TOL, assert_close, golden_files
+from golden_util import Golden, TOL, VarlenGolden, assert_close, golden_files, varlen_golden_files
 
 FILES = golden_files()
 
@@ -46,3 +46,38 @@ def test_sharded_sim_equals_global_attention(path):
     outs = O.usp_forward_sim(lq, lk, lv, g.ud, g.rd, g.impl, causal=True)
     for r in range(g.ws):
         np.testing.assert_allclose(outs[r], g.shard(full, r), atol=1e-12, rtol=1e-10)
+
+
+VFILES = varlen_golden_files()
+
+
+def test_varlen_fixtures_present():
+    assert len(VFILES) >= 4, "run tests/golden/make_golden_varlen.py in the build container"
+
+
+@pytest.mark.parametrize("path", VFILES, ids=lambda p: p.split("/")[-1][:-4])
+def test_varlen_oracle_matches_reference_run(path):
+    """Packed variable-length ring schedules: oracle vs the reference's own run (out, lse, dq, dk, dv)."""
+    g = VarlenGolden(path)
+    ldo = [g.shard(g.dout, r) for r in range(g.ws)]
+    outs, lses, dqs, dks, dvs = g.sim(ldo)
+    atol, rtol = TOL[g.dtype]["out"]
+    gt, gr = TOL[g.dtype]["grad"]
+    for r in range(g.ws):
+        assert outs[r].shape == g.out[r].shape and lses[r].shape == g.lse[r].shape
+        assert_close(g.out[r], outs[r], atol, rtol, f"{g.name} out rank {r}")
+        assert_close(g.lse[r], lses[r], atol, rtol, f"{g.name} lse rank {r}")
+        assert_close(g.dq[r], dqs[r], gt, gr, f"{g.name} dq rank {r}")
+        assert_close(g.dk[r], dks[r], gt, gr, f"{g.name} dk rank {r}")
+        assert_close(g.dv[r], dvs[r], gt, gr, f"{g.name} dv rank {r}")
+
+
+@pytest.mark.parametrize("path", VFILES[:2], ids=lambda p: p.split("/")[-1][:-4])
+def test_varlen_sharded_sim_equals_per_sequence_attention(path):
+    """Size-independent property: the ring schedule over shards == attention on each whole sequence."""
+    g = VarlenGolden(path)
+    full, full_lse = O.varlen_attention_ref(g.q, g.k, g.v, g.cu, causal=True)
+    outs, lses, *_ = g.sim()
+    for r in range(g.ws):
+        np.testing.assert_allclose(outs[r], g.shard(full, r), atol=1e-12, rtol=1e-10)
+        np.testing.assert_allclose(lses[r], g.shard(full_lse.T, r).T, atol=1e-12, rtol=1e-10)
