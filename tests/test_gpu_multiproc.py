@@ -1,0 +1,141 @@
+"""N > 1 on ONE GPU: several processes share cuda:0 and talk over gloo (RCCL refuses two ranks on one
+device), running the package's real path -- HIP kernels, KVRelay side stream + events, all-to-all
+pack/unpack kernels, autograd -- against the reference's golden runs.  What this adds over
+tests/test_dist_cpu.py (CPU tensors, oracle block kernel) is the device-side ordering between the compute
+stream, the relay stream and the transport; what it cannot cover is RCCL itself.
+
+gloo's point-to-point path is NOT stream-ordered for device tensors: its threads read / write the device
+buffer directly from the CPU as soon as the call is posted, where RCCL enqueues the transfer behind the
+work already on the stream.  `_order_p2p_like_rccl` therefore makes every RingComm.commit wait for the
+device first (a send posted right after the kernel that produces its payload would otherwise race with
+that kernel -- observed on the travelling dK/dV accumulators at world size 8).  With that, the ordering
+these tests check is the package's own: the relay stream vs the compute stream, buffer reuse across
+iterations, and the all-to-all pack / unpack kernels between processes."""
+import numpy as np
+import pytest
+import torch
+
+from dist_util import run_distributed
+from golden_util import Golden, TOL, VarlenGolden, assert_close, golden_files, varlen_golden_files
+
+pytestmark = pytest.mark.gpu
+
+
+def _order_p2p_like_rccl():
+    import yunchang_amd.ring.utils as U
+    if getattr(U.RingComm, "_gloo_ordered", False):
+        return
+    orig = U.RingComm.commit
+
+    def commit(self):
+        torch.cuda.synchronize()
+        return orig(self)
+
+    U.RingComm.commit = commit
+    U.RingComm._gloo_ordered = True
+
+
+def _usp_gpu_worker(rank, ws, path):
+    import yunchang_amd as Y
+    _order_p2p_like_rccl()
+    from yunchang_amd.kernels import get_block_backend
+    assert get_block_backend().name == "hip"
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    g = Golden(path)
+    dtype = getattr(torch, g.dtype)
+    Y.set_seq_parallel_pg(g.ud, g.rd, rank, ws)
+    ext = Y.EXTRACT_FUNC_DICT[g.impl]
+    glob = [torch.from_numpy(t).to(dtype) for t in (g.q, g.k, g.v, g.dout)]
+    lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=g.rd, ud=g.ud).detach().clone().to(dev) for t in glob)
+    for t in (lq, lk, lv):
+        t.requires_grad_(True)
+    kw = dict(dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+              deterministic=False, return_attn_probs=True)
+    if g.layer == "ulysses":
+        attn = Y.UlyssesAttention(Y.PROCESS_GROUP.ULYSSES_PG, attn_type=Y.AttnType.HIP)
+    else:
+        attn = Y.LongContextAttention(ring_impl_type=g.impl, attn_type=Y.AttnType.HIP)
+    res = {}
+    for it in range(2):                      # twice: buffers / streams must be reusable
+        for t in (lq, lk, lv):
+            t.grad = None
+        out = attn(lq, lk, lv, **kw)
+        out.backward(ldo)
+        torch.cuda.synchronize()
+        res = dict(out=out.detach().float().cpu().numpy(), dq=lq.grad.float().cpu().numpy(),
+                   dk=lk.grad.float().cpu().numpy(), dv=lv.grad.float().cpu().numpy())
+    return res
+
+
+def _probe_worker(rank, ws):
+    import torch.distributed as dist
+    t = torch.full((4,), float(rank), device="cuda:0")
+    if rank == 0:
+        dist.send(t, 1)
+    else:
+        dist.recv(t, 0)
+    torch.cuda.synchronize()
+    return float(t[0])
+
+
+def _gloo_moves_device_tensors():
+    """gloo in this build must be able to send/recv device tensors; otherwise these tests cannot run."""
+    try:
+        return run_distributed(_probe_worker, 2) == [0.0, 0.0]
+    except AssertionError:
+        return False
+
+
+@pytest.fixture(scope="module")
+def gloo_cuda():
+    if not _gloo_moves_device_tensors():
+        pytest.skip("gloo cannot move device tensors in this build")
+
+
+DENSE = [f for f in golden_files() if "_w1" not in f and "qkvpacked" not in f]
+
+
+@pytest.mark.parametrize("path", DENSE, ids=lambda p: p.split("/")[-1][:-4])
+def test_usp_multiprocess_one_gpu(gloo_cuda, path):
+    g = Golden(path)
+    res = run_distributed(_usp_gpu_worker, g.ws, path)
+    for r in range(g.ws):
+        assert_close(res[r]["out"], g.out[r], *TOL[g.dtype]["out"], f"{g.name} out rank {r}")
+        for key in ("dq", "dk", "dv"):
+            assert_close(res[r][key], getattr(g, key)[r], *TOL[g.dtype]["grad"], f"{g.name} {key} rank {r}")
+
+
+def _varlen_gpu_worker(rank, ws, path):
+    import torch.distributed as dist
+    import yunchang_amd as Y
+    _order_p2p_like_rccl()
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    g = VarlenGolden(path)
+    dtype = getattr(torch, g.dtype)
+    layout = "zigzag" if g.impl == "zigzag" else "basic"
+    lq, lk, lv, ldo = (Y.extract_local_varlen(torch.from_numpy(t).to(dtype), g.cu, rank, ws, layout).to(dev)
+                       for t in (g.q, g.k, g.v, g.dout))
+    for t in (lq, lk, lv):
+        t.requires_grad_(True)
+    cu_local = torch.tensor(g.cu_local, dtype=torch.int32, device=dev)
+    fn = Y.zigzag_ring_flash_attn_varlen_func if g.impl == "zigzag" else Y.ring_flash_attn_varlen_func
+    out, lse, _ = fn(lq, lk, lv, cu_local, g.max_local, causal=True, return_attn_probs=True,
+                     group=dist.group.WORLD)
+    out.backward(ldo)
+    torch.cuda.synchronize()
+    return dict(out=out.detach().float().cpu().numpy(), lse=Y.flatten_lse(lse.detach(), cu_local).cpu().numpy(),
+                dq=lq.grad.float().cpu().numpy(), dk=lk.grad.float().cpu().numpy(),
+                dv=lv.grad.float().cpu().numpy())
+
+
+@pytest.mark.parametrize("path", varlen_golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_varlen_ring_multiprocess_one_gpu(gloo_cuda, path):
+    g = VarlenGolden(path)
+    res = run_distributed(_varlen_gpu_worker, g.ws, path)
+    for r in range(g.ws):
+        assert_close(res[r]["out"], g.out[r], *TOL[g.dtype]["out"], f"{g.name} out rank {r}")
+        assert_close(res[r]["lse"], g.lse[r], *TOL[g.dtype]["out"], f"{g.name} lse rank {r}")
+        for key in ("dq", "dk", "dv"):
+            assert_close(res[r][key], getattr(g, key)[r], *TOL[g.dtype]["grad"], f"{g.name} {key} rank {r}")
