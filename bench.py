@@ -283,14 +283,25 @@ def main():
     cfg = dict(WORKLOADS[args.gpus])
     if args.bwd >= 0:
         cfg["bwd"] = bool(args.bwd)
+    # USP_BENCH_BACKEND=gloo is a DEVELOPMENT smoke mode, not a measurement: all ranks share cuda:0 and
+    # talk over gloo, so the N > 1 code path of this script can be exercised on a 1-GPU box (RCCL refuses
+    # two ranks on one device).  The line it prints is tagged "smoke" and must not be read as a result.
+    backend = os.environ.get("USP_BENCH_BACKEND", "nccl")
+    smoke = backend != "nccl"
+    if smoke:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if ws == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29751")
-    dist.init_process_group("nccl", rank=rank, world_size=ws)
+    dist.init_process_group(backend, rank=rank, world_size=ws)
 
     import yunchang_amd as Y
+    if smoke:      # gloo's p2p is not stream-ordered for device tensors (tests/test_gpu_multiproc.py)
+        import yunchang_amd.ring.utils as _U
+        _commit = _U.RingComm.commit
+        _U.RingComm.commit = lambda self: (torch.cuda.synchronize(), _commit(self))[1]
     Y.set_seq_parallel_pg(cfg["ud"], cfg["rd"], rank, ws)
     q, k, v, do = make_global(cfg, dev)
     ext = Y.EXTRACT_FUNC_DICT[cfg["impl"]]
@@ -358,6 +369,8 @@ def main():
         }
         if overlap is not None:
             line["overlap"] = overlap
+        if smoke:
+            line["smoke"] = f"backend={backend}, all ranks on cuda:0 -- NOT a measurement"
         if ws == 1:
             line["roofline"] = kernel_roofline(cfg, dev)
             if not args.no_cpu_baseline:
