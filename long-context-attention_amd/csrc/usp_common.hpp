@@ -129,4 +129,27 @@ USP_DEV int xcd_remap(int id, int n) {
   return ((n & 7) == 0) ? (id & 7) * (n >> 3) + (id >> 3) : id;
 }
 
+// Persistent workgroups: a launch has min(items, resident workgroup slots) workgroups and each walks a
+// static list of work items.  The dispatcher places workgroup id on XCD id % 8; every XCD owns a
+// contiguous run of the item list (all sharers of one K/V sit behind one L2) and deals it out to its
+// workgroups in passes of alternating direction, which pairs a heavy causal item with a light one.
+// Saves the per-workgroup launch / drain and lets item i+1's first loads overlap item i's epilogue
+// (measured: ~14 us -> ~5 us of fixed cost per 256-row forward item at C2).
+struct ItemWalk {
+  int wg_l, wgs_l, items_l, item0;
+  USP_DEV explicit ItemWalk(int n_items) {
+    const int n_wg = gridDim.x;
+    const bool by_xcd = ((n_wg & 7) == 0) && ((n_items & 7) == 0);
+    wg_l = by_xcd ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;        // index inside the XCD
+    wgs_l = by_xcd ? (n_wg >> 3) : n_wg;
+    items_l = by_xcd ? (n_items >> 3) : n_items;
+    item0 = by_xcd ? (int)(blockIdx.x & 7) * items_l : 0;
+  }
+  // item of pass `pass`, or -1 when this workgroup's list is exhausted
+  USP_DEV int at(int pass) const {
+    const int loc = pass * wgs_l + ((pass & 1) ? (wgs_l - 1 - wg_l) : wg_l);
+    return loc < items_l ? item0 + loc : -1;
+  }
+};
+
 }  // namespace usp

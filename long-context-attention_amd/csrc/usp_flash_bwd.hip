@@ -35,6 +35,7 @@ struct BwdParams {
   int64_t dk_sb, dk_ss, dk_sh;
   int64_t dv_sb, dv_ss, dv_sh;
   int B, Sq, Sk, Hq, Hkv, G, nblk;   // nblk = blocks along the owned sequence
+  int n_items;                        // work items of this launch (persistent workgroups walk them)
   int causal_off;
   float scale, scale_log2;
   int accum_dq, accum_dk, accum_dv;
@@ -99,9 +100,12 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   const int l31 = lane & 31;
   const int hi = lane >> 5;
 
-  // ---- work item --------------------------------------------------------------------------------
+  // ---- work items (persistent workgroups, usp_common.hpp ItemWalk) ------------------------------------
+  const ItemWalk walk(p_in.n_items);
+  for (int pass = 0;; ++pass) {
+  int w = walk.at(pass);
+  if (w < 0) break;
   BwdParams p = p_in;
-  int w = xcd_remap(blockIdx.x, gridDim.x);
   const int blk_r = w % p.nblk;
   int rest = w / p.nblk;
   int b, hkv, h0, blk, split_g = 0;
@@ -119,9 +123,9 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
     split_g = g;
   }
   int64_t ws_row0;
-  if (!bind_sequence(p, b, &ws_row0)) return;
+  if (!bind_sequence(p, b, &ws_row0)) continue;
   const int own0 = blk * OWN;                  // first owned row (query row / key)
-  if (p.seq_q != nullptr && own0 >= (MODE == 0 ? p.Sq : p.Sk)) return;   // past the end of its sequence
+  if (p.seq_q != nullptr && own0 >= (MODE == 0 ? p.Sq : p.Sk)) continue;   // past the end of its sequence
   const int off = p.causal_off;
   const int ow = own0 + wave * 32;             // first row owned by this wave
   const int orow = ow + l31;                   // this lane's row
@@ -523,6 +527,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
         }
       }
   }
+  }  // next item
 }
 
 // ======================================================================================================
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 template <int D, int DT, bool CAUSAL>
 __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams p_in) {
   using E = Elem<DT>;
-  constexpr int NT = 512, NW = 8, OWN = 128;
+  constexpr int NW = 8, OWN = 128;
   constexpr int ROWB = D * 2;
   constexpr int TILEB = kTile * ROWB;
   constexpr int STATB = 2 * kTile * 4;
@@ -569,8 +574,11 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   const int l31 = lane & 31;
   const int hi = lane >> 5;
 
+  const ItemWalk walk(p_in.n_items);             // persistent workgroups (usp_common.hpp)
+  for (int pass = 0;; ++pass) {
+  int w = walk.at(pass);
+  if (w < 0) break;
   BwdParams p = p_in;
-  int w = xcd_remap(blockIdx.x, gridDim.x);
   const int blk = w % p.nblk;                    // early key blocks are seen by most rows: first
   int rest = w / p.nblk;
   int g = 0;
@@ -578,9 +586,9 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   const int hkv = rest % p.Hkv, b = rest / p.Hkv;
   const int h0 = hkv * p.G + g;
   int64_t ws_row0;
-  if (!bind_sequence(p, b, &ws_row0)) return;
+  if (!bind_sequence(p, b, &ws_row0)) continue;
   const int own0 = blk * OWN;
-  if (p.seq_q != nullptr && own0 >= p.Sk) return;            // past the end of its sequence
+  if (p.seq_q != nullptr && own0 >= p.Sk) continue;          // past the end of its sequence
   const int off = p.causal_off;
   const int ow = own0 + slice * 32;
   const int orow = ow + l31;
@@ -861,6 +869,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
         else *(f32x4*)(o32 + d0) = v;
       }
   }
+  }  // next item
 }
 
 // dst[b,s,h,:] (+)= sum_g ws[g][row][h][:]   -- combines the per-query-head dK / dV partials.
@@ -915,8 +924,18 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   constexpr size_t lds0 = 2 * (2 * kTile * D * 2);
   constexpr size_t lds1 = 2 * (2 * kTile * D * 2 + 2 * kTile * 4);
   // dK,dV
+  // persistent launches: one workgroup per CU (both kernels fit once per CU), each walks n_items / grid items
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  static const bool persist = [] { const char* e = getenv("USP_BWD_PERSIST"); return !(e && e[0] == '0'); }();
   p.nblk = (p.Sk + 127) / 128;
-  int grid = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1);
+  p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1);
+  int grid = (persist && p.n_items > cus) ? cus : p.n_items;
   static const bool legacy = [] { const char* e = getenv("USP_BWD_DKDV"); return e && e[0] == 'l'; }();
   if (legacy) {      // single-role kernel, one wave per SIMD (kept for A/B runs: USP_BWD_DKDV=legacy)
     if (causal)
@@ -940,7 +959,8 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   }
   // dQ
   p.nblk = (p.Sq + 255) / 256;
-  grid = p.B * p.Hq * p.nblk;
+  p.n_items = p.B * p.Hq * p.nblk;
+  grid = (persist && p.n_items > cus) ? cus : p.n_items;
   if (causal)
     hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 0>), dim3(grid), dim3(512), lds0, st, p);
   else

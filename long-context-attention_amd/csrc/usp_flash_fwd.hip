@@ -32,7 +32,7 @@ struct FwdParams {
   int64_t o_sb, o_ss, o_sh;
   int64_t a_sb, a_ss, a_sh;
   int64_t lse_sb, lse_sh;
-  int B, Sq, Sk, Hq, Hkv, G, nq;
+  int B, Sq, Sk, Hq, Hkv, G, nq, n_items;
   int causal_off;                 // Sk - Sq
   float scale, scale_log2;
   int merge_in, final_begin, final_end;
@@ -71,9 +71,12 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   const int l31 = lane & 31;
   const int hi = lane >> 5;
 
-  // ---- which (batch, head, query tile) ------------------------------------------------------
+  // ---- persistent workgroups: each walks a static list of (batch, head, query tile) items (ItemWalk) --
+  const ItemWalk walk(p_in.n_items);
+  for (int pass = 0;; ++pass) {
+  int w = walk.at(pass);
+  if (w < 0) break;
   FwdParams p = p_in;
-  int w = xcd_remap(blockIdx.x, gridDim.x);
   const int qt_r = w % p.nq;
   int rest = w / p.nq;
   const int qt = CAUSAL ? (p.nq - 1 - qt_r) : qt_r;      // heavy (late) tiles first
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   if (p.seq_q != nullptr) {
     const int q_first = p.seq_q[2 * b], q_len = p.seq_q[2 * b + 1];
     const int k_first = p.seq_k[2 * b], k_len = p.seq_k[2 * b + 1];
-    if (qt * kBM >= q_len) return;                          // whole workgroup past the end of its sequence
+    if (qt * kBM >= q_len) continue;                        // whole workgroup past the end of its sequence
     p.q += 2 * q_first * p.q_ss;
     p.k += 2 * k_first * p.k_ss;
     p.v += 2 * k_first * p.v_ss;
@@ -506,12 +509,24 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       }
     }
   }
+  }  // next item
 }
 
 template <int D, int DT, int NWAVES>
 static int launch_fwd_w(FwdParams p, bool causal, hipStream_t st) {
   p.nq = (p.Sq + 32 * NWAVES - 1) / (32 * NWAVES);
-  const int grid = p.B * p.Hq * p.nq;
+  p.n_items = p.B * p.Hq * p.nq;
+  // persistent launch: one workgroup per resident slot (8 waves: 1 per CU, 4 waves: 2 per CU)
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  static const bool persist = [] { const char* e = getenv("USP_FWD_PERSIST"); return !(e && e[0] == '0'); }();
+  const int slots = cus * (NWAVES == 8 ? 1 : 2);
+  const int grid = (persist && p.n_items > slots) ? slots : p.n_items;
   const size_t lds = 2 * 2 * kBN * D * 2;
   if (causal)
     hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
