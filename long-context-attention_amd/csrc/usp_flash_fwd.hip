@@ -36,6 +36,7 @@ struct FwdParams {
   int causal_off;                 // Sk - Sq
   float scale, scale_log2;
   int merge_in, final_begin, final_end;
+  int out_wide;                   // out rows are 16-byte aligned: 16-byte epilogue stores
   const int* seq_q; const int* seq_k;   // packed variable-length batch: B (first row, rows) pairs, or NULL
 };
 
@@ -470,7 +471,11 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   const float blk_lse = empty ? USP_NEG_INF : (m_run * c + log2f(l_tot)) * kLn2;
   float w_blk = inv, w_old = 0.f, new_lse = blk_lse;
   float* lse_p = p.lse + b * p.lse_sb + h * p.lse_sh + row;
-  if (row < p.Sq) {
+  const bool valid = row < p.Sq;
+  const bool fin = row >= p.final_begin && row < p.final_end;
+  // single-pass call whose 32 rows are all final and 16-byte aligned: straight-line widened stores
+  const bool wide = !p.merge_in && p.out_wide && __all(!valid || fin);
+  if (valid) {
     if (p.merge_in) {
       const float old = *lse_p;
       const float mx = fmaxf(old, blk_lse);
@@ -486,25 +491,44 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       }
     }
     if (hi == 0) *lse_p = new_lse;
-    const bool fin = row >= p.final_begin && row < p.final_end;
     const int64_t arow = b * p.a_sb + (int64_t)row * p.a_ss + h * p.a_sh;
     const int64_t orow = b * p.o_sb + (int64_t)row * p.o_ss + h * p.o_sh;
+    if (wide) {
+      // Each row is split across the two half-waves in 8-byte pieces; one v_permlane32_swap per dword
+      // regroups two adjacent pieces into 16 contiguous bytes per lane: 2*NDJ dwordx4 stores instead of
+      // 4*NDJ dwordx2 (the store tail is issue-bound; the fp32 path already stores 16 bytes per lane).
+      char* op = p.out + 2 * orow;
 #pragma unroll
-    for (int dj = 0; dj < NDJ; ++dj) {
+      for (int dj = 0; dj < NDJ; ++dj)
 #pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        const int d0 = 32 * dj + 8 * g4 + 4 * hi;
-        f32x4 val = {o[dj][4 * g4] * w_blk, o[dj][4 * g4 + 1] * w_blk, o[dj][4 * g4 + 2] * w_blk,
-                     o[dj][4 * g4 + 3] * w_blk};
-        if (p.merge_in) {
-          const f32x4 a = *(const f32x4*)(p.acc + arow + d0);
-          val += a * w_old;
+        for (int g2 = 0; g2 < 2; ++g2) {
+          const int r0 = 8 * g2;                 // regs r0..r0+3: column group 2*g2, r0+4..r0+7: group 2*g2+1
+          uint32_t ax = E::pack2(o[dj][r0] * w_blk, o[dj][r0 + 1] * w_blk);
+          uint32_t ay = E::pack2(o[dj][r0 + 2] * w_blk, o[dj][r0 + 3] * w_blk);
+          uint32_t bx = E::pack2(o[dj][r0 + 4] * w_blk, o[dj][r0 + 5] * w_blk);
+          uint32_t by = E::pack2(o[dj][r0 + 6] * w_blk, o[dj][r0 + 7] * w_blk);
+          const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+          *(u32x4*)(op + 2 * (32 * dj + 16 * g2 + 8 * hi)) = u32x4{sx[0], sy[0], sx[1], sy[1]};
         }
-        if (fin) {
-          u32x2 pk = {E::pack2(val[0], val[1]), E::pack2(val[2], val[3])};
-          *(u32x2*)(p.out + 2 * (orow + d0)) = pk;
-        } else {
-          *(f32x4*)(p.acc + arow + d0) = val;
+    } else {
+#pragma unroll
+      for (int dj = 0; dj < NDJ; ++dj) {
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d0 = 32 * dj + 8 * g4 + 4 * hi;
+          f32x4 val = {o[dj][4 * g4] * w_blk, o[dj][4 * g4 + 1] * w_blk, o[dj][4 * g4 + 2] * w_blk,
+                       o[dj][4 * g4 + 3] * w_blk};
+          if (p.merge_in) {
+            const f32x4 a = *(const f32x4*)(p.acc + arow + d0);
+            val += a * w_old;
+          }
+          if (fin) {
+            u32x2 pk = {E::pack2(val[0], val[1]), E::pack2(val[2], val[3])};
+            *(u32x2*)(p.out + 2 * (orow + d0)) = pk;
+          } else {
+            *(f32x4*)(p.acc + arow + d0) = val;
+          }
         }
       }
     }
@@ -600,6 +624,8 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   p.scale_log2 = a->softmax_scale * kLog2e;
   p.merge_in = a->merge_in ? 1 : 0;
   p.final_begin = fb; p.final_end = fe;
+  p.out_wide = (a->out.ptr && (reinterpret_cast<uintptr_t>(a->out.ptr) & 15) == 0 && a->out.stride_b % 8 == 0 &&
+                a->out.stride_s % 8 == 0 && a->out.stride_h % 8 == 0) ? 1 : 0;
   p.seq_q = a->seq_q; p.seq_k = a->seq_k;
   if (packed) p.q_sb = p.k_sb = p.v_sb = p.o_sb = p.a_sb = p.lse_sb = 0;
   hipStream_t st = (hipStream_t)stream;
