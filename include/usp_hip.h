@@ -76,6 +76,11 @@ typedef struct usp_tensor {
  * e.g. the front or back half of every sequence -- no gather copies are needed.  In this mode
  * final_begin / final_end count HALF sequences (0, 1 or 2): rows [final_begin*rows/2,
  * final_end*rows/2) of every sequence are final (2 = to the end).
+ * `sched` (packed mode only, optional): 16 int32 of device memory, ZEROED ONCE by the caller.  With it
+ * the workgroups pull work items from a dynamic queue (heaviest first, empty items of short sequences
+ * skipped), which is what balances batches of unequal sequences; without it they walk static lists,
+ * which is only balanced when all sequences are equally long.  The kernels leave the block zeroed;
+ * launches that may run concurrently (different streams) must not share one block.
  * -------------------------------------------------------------------------------------------- */
 typedef struct usp_fwd_args {
   int32_t dtype;                 /* USP_BF16 | USP_FP16: element type of q,k,v,out */
@@ -91,6 +96,7 @@ typedef struct usp_fwd_args {
   int32_t final_begin, final_end;/* row range of this call whose result is final */
   const int32_t* seq_q;          /* packed variable-length batch (both NULL = dense), see below */
   const int32_t* seq_k;
+  int32_t* sched;                /* packed mode, optional: 64-byte device control block, see below */
 } usp_fwd_args;
 
 int usp_flash_fwd(const usp_fwd_args* args, void* stream);
@@ -139,6 +145,7 @@ typedef struct usp_bwd_args {
   const int32_t* seq_q;          /* packed variable-length batch (both NULL = dense), see below */
   const int32_t* seq_k;
   int64_t total_k;               /* packed mode: rows of the k/v/dk/dv token tensors (sizes the workspace) */
+  int32_t* sched;                /* packed mode, optional: 64-byte device control block (as usp_fwd_args) */
 } usp_bwd_args;
 
 int usp_flash_bwd(const usp_bwd_args* args, void* stream);

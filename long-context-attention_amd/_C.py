@@ -36,7 +36,7 @@ class UspFwdArgs(ctypes.Structure):
                 ("lse_stride_h", ctypes.c_int64),
                 ("merge_in", ctypes.c_int32), ("final_begin", ctypes.c_int32),
                 ("final_end", ctypes.c_int32),
-                ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p)]
+                ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("sched", ctypes.c_void_p)]
 
 
 class UspBwdArgs(ctypes.Structure):
@@ -53,7 +53,8 @@ class UspBwdArgs(ctypes.Structure):
                 ("accum_dv", ctypes.c_int32),
                 ("dq16", UspTensor), ("dk16", UspTensor), ("dv16", UspTensor),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
-                ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("total_k", ctypes.c_int64)]
+                ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("total_k", ctypes.c_int64),
+                ("sched", ctypes.c_void_p)]
 
 
 EXPORTS = ("usp_flash_fwd", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
@@ -190,6 +191,20 @@ def _seq(t: torch.Tensor, n: int) -> ctypes.c_void_p:
     return ctypes.c_void_p(t.data_ptr())
 
 
+_SCHED = {}
+
+
+def sched_block(device) -> torch.Tensor:
+    """The 16-int32 control block of the packed kernels' dynamic item queue (include/usp_hip.h `sched`):
+    zeroed once, left zeroed by every launch, one per (device, stream) because launches on different
+    streams may overlap."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    blk = _SCHED.get(key)
+    if blk is None:
+        blk = _SCHED[key] = torch.zeros(16, dtype=torch.int32, device=device)
+    return blk
+
+
 def flash_fwd_packed(q, k, v, seq_q, seq_k, max_q: int, max_k: int, softmax_scale: float,
                      causal: bool, lse, out=None, acc=None, merge_in: bool = False,
                      final_begin: int = 0, final_end: int = 2):
@@ -208,6 +223,7 @@ def flash_fwd_packed(q, k, v, seq_q, seq_k, max_q: int, max_k: int, softmax_scal
     a.merge_in = 1 if merge_in else 0
     a.final_begin, a.final_end = int(final_begin), int(final_end)
     a.seq_q, a.seq_k = _seq(seq_q, n), _seq(seq_k, n)
+    a.sched = sched_block(q.device).data_ptr()
     _check(load().usp_flash_fwd(ctypes.byref(a), _stream()), "usp_flash_fwd")
 
 
@@ -232,6 +248,7 @@ def flash_bwd_packed(dout, q, k, v, lse, delta, seq_q, seq_k, max_q: int, max_k:
     a.dq16, a.dk16, a.dv16 = _t3(dq16), _t3(dk16), _t3(dv16)
     a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
     a.seq_q, a.seq_k = _seq(seq_q, n), _seq(seq_k, n)
+    a.sched = sched_block(q.device).data_ptr()
     a.total_k = k.shape[0]
     L = load()
     need = L.usp_flash_bwd_workspace_bytes(ctypes.byref(a))

@@ -152,4 +152,57 @@ struct ItemWalk {
   }
 };
 
+// Dynamic item queue, used for packed batches (sequences of unequal length defeat any static split: the
+// item list is sized by the LONGEST sequence, most items of short sequences are empty, and the heavy
+// ones cluster).  Items are (bh, t): bh = batch*heads + head, t = tile along the owned sequence, t = 0 the
+// heaviest.  XCD x (= workgroup id % 8) serves the heads bh = x (mod 8), so all sharers of one K/V still
+// sit behind one L2; its workgroups pull (t, bh) pairs t-major from an atomic counter, i.e. heaviest
+// first (dynamic LPT), skip empty items without leaving the fetch, and help the other XCDs' lists once
+// their own is drained.  sched[0..7] = counters, sched[8] = finished workgroups; the last workgroup to
+// finish zeroes the block again, so the caller zeroes it only once.  Thread 0 fetches and broadcasts
+// through two alternating LDS slots (one barrier per fetch).
+struct ItemQueue {
+  int* sched;              // device control block (16 ints)
+  const int* seq;          // (first_row, rows) table of the owned side
+  int n_bh, n_t, heads_per_b, unit;
+  int reverse;             // 1: tile index = n_t - 1 - t (late tiles are the heavy ones)
+};
+
+// Thread 0 only.  Deliberately NOT inlined: called once per item, when almost nothing is live, so the call
+// costs nothing, while its divisions and loop state inlined into the flash kernels cost 40-70 spilled VGPRs.
+// `state` = lists already drained by this workgroup; returns the item (bh * n_t + t) or -1.
+#ifdef USP_QINLINE
+USP_DEV int item_queue_fetch(
+#else
+__attribute__((noinline)) USP_DEV int item_queue_fetch(
+#endif
+    const ItemQueue& q, int& state) {
+  const int x = blockIdx.x & 7;
+  for (; state < 8; ++state) {
+    const int xq = (x + state) & 7;
+    const int nbh_x = xq < q.n_bh ? (q.n_bh - xq + 7) >> 3 : 0;
+    const int total = nbh_x * q.n_t;
+    while (total > 0) {
+      const int j = atomicAdd(&q.sched[xq], 1);
+      if (j >= total) break;
+      const int t = j / nbh_x;
+      const int bh = xq + 8 * (j - t * nbh_x);
+      const int rows = q.seq[2 * (bh / q.heads_per_b) + 1];
+      if ((q.reverse ? q.n_t - 1 - t : t) * q.unit >= rows) continue;   // empty item of a short sequence
+      return bh * q.n_t + t;
+    }
+  }
+  if (atomicAdd(&q.sched[8], 1) == (int)gridDim.x - 1) {        // every other workgroup has stopped fetching
+    for (int i = 0; i < 9; ++i) q.sched[i] = 0;
+  }
+  return -1;
+}
+
+// all threads; `slots` = 2 ints of LDS; returns the item or -1
+USP_DEV int item_queue_next(const ItemQueue& q, int& state, USP_LDS int* slots, int pass) {
+  if (threadIdx.x == 0) slots[pass & 1] = item_queue_fetch(q, state);
+  __syncthreads();
+  return slots[pass & 1];
+}
+
 }  // namespace usp

@@ -45,6 +45,8 @@ struct BwdParams {
   int64_t ws_rows;                    // key rows per head-group slab: B*Sk, packed mode: rows of k
   int split;                          // 1: one workgroup per (query head, key block)
   const int* seq_q; const int* seq_k; // packed variable-length batch: B (first row, rows) pairs, or NULL
+  int* sched;                         // packed mode: control block of the dynamic item queue, or NULL
+  int sched_lds;                      // byte offset of the queue's two LDS slots
 };
 
 // Packed variable-length batch: rebase the local copy of the parameters on the rows of sequence b (the
@@ -102,8 +104,12 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 
   // ---- work items (persistent workgroups, usp_common.hpp ItemWalk) ------------------------------------
   const ItemWalk walk(p_in.n_items);
+  ItemQueue queue{p_in.sched, MODE == 0 ? p_in.seq_q : p_in.seq_k, p_in.n_items / p_in.nblk, p_in.nblk,
+                  MODE == 0 ? p_in.Hq : p_in.Hkv * (p_in.split ? p_in.G : 1), OWN, (MODE == 0 && CAUSAL) ? 1 : 0};
+  int qstate = 0;
+  USP_LDS int* qslots = (USP_LDS int*)(smem + p_in.sched_lds);
   for (int pass = 0;; ++pass) {
-  int w = walk.at(pass);
+  int w = p_in.sched ? item_queue_next(queue, qstate, qslots, pass) : walk.at(pass);
   if (w < 0) break;
   BwdParams p = p_in;
   const int blk_r = w % p.nblk;
@@ -575,8 +581,12 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   const int hi = lane >> 5;
 
   const ItemWalk walk(p_in.n_items);             // persistent workgroups (usp_common.hpp)
+  ItemQueue queue{p_in.sched, p_in.seq_k, p_in.n_items / p_in.nblk, p_in.nblk,
+                  p_in.Hkv * (p_in.split ? p_in.G : 1), OWN, 0};
+  int qstate = 0;
+  USP_LDS int* qslots = (USP_LDS int*)(smem + p_in.sched_lds);
   for (int pass = 0;; ++pass) {
-  int w = walk.at(pass);
+  int w = p_in.sched ? item_queue_next(queue, qstate, qslots, pass) : walk.at(pass);
   if (w < 0) break;
   BwdParams p = p_in;
   const int blk = w % p.nblk;                    // early key blocks are seen by most rows: first
@@ -935,19 +945,22 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   static const bool persist = [] { const char* e = getenv("USP_BWD_PERSIST"); return !(e && e[0] == '0'); }();
   p.nblk = (p.Sk + 127) / 128;
   p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1);
-  int grid = (persist && p.n_items > cus) ? cus : p.n_items;
+  int grid = ((persist || p.sched) && p.n_items > cus) ? cus : p.n_items;
+  const size_t qx = p.sched ? 16 : 0;            // LDS for the item queue's two slots
   static const bool legacy = [] { const char* e = getenv("USP_BWD_DKDV"); return e && e[0] == 'l'; }();
+  p.sched_lds = (int)lds1;
   if (legacy) {      // single-role kernel, one wave per SIMD (kept for A/B runs: USP_BWD_DKDV=legacy)
     if (causal)
-      hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 1>), dim3(grid), dim3(256), lds1, st, p);
+      hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 1>), dim3(grid), dim3(256), lds1 + qx, st, p);
     else
-      hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 1>), dim3(grid), dim3(256), lds1, st, p);
+      hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 1>), dim3(grid), dim3(256), lds1 + qx, st, p);
   } else {
     constexpr size_t lds2 = 3 * (2 * kTile * D * 2 + 2 * kTile * 4) + 4 * 2 * 4096;
+    p.sched_lds = (int)lds2;
     if (causal)
-      hipLaunchKernelGGL((flash_bwd_dkdv_kernel<D, DT, true>), dim3(grid), dim3(512), lds2, st, p);
+      hipLaunchKernelGGL((flash_bwd_dkdv_kernel<D, DT, true>), dim3(grid), dim3(512), lds2 + qx, st, p);
     else
-      hipLaunchKernelGGL((flash_bwd_dkdv_kernel<D, DT, false>), dim3(grid), dim3(512), lds2, st, p);
+      hipLaunchKernelGGL((flash_bwd_dkdv_kernel<D, DT, false>), dim3(grid), dim3(512), lds2 + qx, st, p);
   }
   if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
   if (p.split) {
@@ -960,11 +973,12 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   // dQ
   p.nblk = (p.Sq + 255) / 256;
   p.n_items = p.B * p.Hq * p.nblk;
-  grid = (persist && p.n_items > cus) ? cus : p.n_items;
+  grid = ((persist || p.sched) && p.n_items > cus) ? cus : p.n_items;
+  p.sched_lds = (int)lds0;
   if (causal)
-    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 0>), dim3(grid), dim3(512), lds0, st, p);
+    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 0>), dim3(grid), dim3(512), lds0 + qx, st, p);
   else
-    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 0>), dim3(grid), dim3(512), lds0, st, p);
+    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 0>), dim3(grid), dim3(512), lds0 + qx, st, p);
   return hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
 }
 
@@ -1036,6 +1050,8 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   // GQA head split: with a workspace, every query head of a KV group gets its own workgroups and the
   // per-head partials are summed afterwards; without one the group's heads are looped inside a workgroup.
   p.seq_q = a->seq_q; p.seq_k = a->seq_k;
+  p.sched = packed ? a->sched : nullptr;
+  p.sched_lds = 0;
   p.ws_rows = ws_rows_of(a);
   if (packed) {
     p.do_sb = p.q_sb = p.k_sb = p.v_sb = p.lse_sb = p.dl_sb = 0;

@@ -38,6 +38,7 @@ struct FwdParams {
   int merge_in, final_begin, final_end;
   int out_wide;                   // out rows are 16-byte aligned: 16-byte epilogue stores
   const int* seq_q; const int* seq_k;   // packed variable-length batch: B (first row, rows) pairs, or NULL
+  int* sched;                           // packed mode: control block of the dynamic item queue, or NULL
 };
 
 constexpr int kBN = 64;    // keys per KV tile
@@ -74,8 +75,11 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
 
   // ---- persistent workgroups: each walks a static list of (batch, head, query tile) items (ItemWalk) --
   const ItemWalk walk(p_in.n_items);
+  ItemQueue queue{p_in.sched, p_in.seq_q, p_in.B * p_in.Hq, p_in.nq, p_in.Hq, kBM, CAUSAL ? 1 : 0};
+  int qstate = 0;
+  USP_LDS int* qslots = (USP_LDS int*)(smem + 4 * KBYTES);          // 2 ints behind the K/V buffers
   for (int pass = 0;; ++pass) {
-  int w = walk.at(pass);
+  int w = p_in.sched ? item_queue_next(queue, qstate, qslots, pass) : walk.at(pass);
   if (w < 0) break;
   FwdParams p = p_in;
   const int qt_r = w % p.nq;
@@ -294,6 +298,10 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   }
   __syncthreads();
   if (nt > 0 && wave_kv_end > 0) qk(0, sa, sb);
+  // K(0) must have been read by EVERY wave before the first loop iteration refills Kbuf[0] with K(2): a
+  // wave that skips qk(0) (no valid rows) reaches that DMA at once, and a mostly out-of-range K(2) tile
+  // (short sequences) lands immediately -- observed as rare small errors on ragged shapes.
+  __syncthreads();
 
   // ---- main loop over unmasked tiles, hand-pinned software pipeline --------------------------------
   // Per iteration j (reference max m_run already decided for tile j):
@@ -550,8 +558,8 @@ static int launch_fwd_w(FwdParams p, bool causal, hipStream_t st) {
   }();
   static const bool persist = [] { const char* e = getenv("USP_FWD_PERSIST"); return !(e && e[0] == '0'); }();
   const int slots = cus * (NWAVES == 8 ? 1 : 2);
-  const int grid = (persist && p.n_items > slots) ? slots : p.n_items;
-  const size_t lds = 2 * 2 * kBN * D * 2;
+  const int grid = ((persist || p.sched) && p.n_items > slots) ? slots : p.n_items;
+  const size_t lds = 2 * 2 * kBN * D * 2 + (p.sched ? 16 : 0);
   if (causal)
     hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
   else
@@ -627,6 +635,7 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   p.out_wide = (a->out.ptr && (reinterpret_cast<uintptr_t>(a->out.ptr) & 15) == 0 && a->out.stride_b % 8 == 0 &&
                 a->out.stride_s % 8 == 0 && a->out.stride_h % 8 == 0) ? 1 : 0;
   p.seq_q = a->seq_q; p.seq_k = a->seq_k;
+  p.sched = packed ? a->sched : nullptr;
   if (packed) p.q_sb = p.k_sb = p.v_sb = p.o_sb = p.a_sb = p.lse_sb = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool causal = a->causal != 0;

@@ -1,0 +1,40 @@
+"""Stress: packed forward, dynamic queue vs static walk, many repetitions (dev tool)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import numpy as np, torch
+import yunchang_amd
+from yunchang_amd import _C
+from oracle import usp_oracle as O
+_C.load()
+dev = torch.device("cuda:0")
+
+
+def case(lens, H, D, reps, use_sched):
+    T = sum(lens)
+    rs = np.random.RandomState(30)
+    tq, tk, tv = (torch.from_numpy(rs.standard_normal((T, H, D)).astype(np.float32)).to(torch.bfloat16).to(dev) for _ in range(3))
+    q, k, v = (t.float().cpu().numpy() for t in (tq, tk, tv))
+    first = np.concatenate([[0], np.cumsum(lens)[:-1]])
+    tb = torch.tensor(np.stack([first, lens], 1), dtype=torch.int32, device=dev)
+    ro, rl = O.varlen_attention_ref(q, k, v, np.concatenate([[0], np.cumsum(lens)]), True)
+    orig = _C.sched_block
+    if not use_sched:
+        _C.sched_block = lambda d: torch.zeros(0, dtype=torch.int32, device=d)   # data_ptr() == 0 -> static walk
+    nbad = 0
+    for rep in range(reps):
+        out = torch.full((T, H, D), float("nan"), dtype=torch.bfloat16, device=dev)
+        lse = torch.full((H, T), float("nan"), dtype=torch.float32, device=dev)
+        _C.flash_fwd_packed(tq, tk, tv, tb, tb, max(lens), max(lens), D ** -0.5, True, lse, out=out)
+        torch.cuda.synchronize()
+        err = np.abs(out.float().cpu().numpy() - ro)
+        nbad += int((~(err <= 0.02 + 0.02 * np.abs(ro))).any())
+    _C.sched_block = orig
+    print(f"STRESS lens={lens} H={H} D={D} sched={use_sched}: {nbad}/{reps} runs with errors", flush=True)
+
+
+for use in (False, True):
+    case((256, 64, 130), 4, 128, 30, use)
+    case((130,), 4, 128, 30, use)
+    case((130, 130, 130, 130), 4, 128, 30, use)
+    case((1000, 130, 70), 8, 128, 20, use)
