@@ -4,6 +4,7 @@
 //   B operand: lane l holds B[k = 8*(l>>5) + 0..7][j = l&31]
 //   C/D      : lane l, reg r holds D[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31]
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -104,6 +105,13 @@ USP_DEV u32x2 lds_read_tr16(USP_LDS const char* p) {
   s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((USP_LDS s16x4*)p);
   return __builtin_bit_cast(u32x2, v);
 }
+
+// Drain this wave's LDS-DMA before the barrier that publishes a tile to the other waves.  hipcc happens to
+// put an `s_waitcnt vmcnt(0)` in front of the first ds_read_tr16 after a DMA (it cannot tell the double
+// buffers apart) but not in front of plain ds_read_b128, so relying on it is fragile; measured cost of the
+// explicit drain: none.  (Replacing the tr16 reads by asm reads, which removes hipcc's mid-tile wait, also
+// measured no gain: by then the tile has landed.)
+USP_DEV void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // LDS-DMA: buffer_load_dwordx4 ... lds.  Each lane fetches 16 bytes at rsrc.base + voffset; the wave's
 // 64 x 16 bytes land linearly at the wave-uniform LDS address `lds_dst`.  (The builtin is unknown to

@@ -313,6 +313,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   const float c = p.scale_log2;
 
   if (n_iter > 0) { stage_setup(0); stage_all(); stage_stats(0); }
+  dma_drain();            // this wave's DMA pieces of the staged tile have landed (usp_common.hpp)
   __syncthreads();
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 
     if (it + 1 < n_iter) stage_stats(buf ^ 1);
 #ifndef USP_ABLATE_NOBARRIER
+    dma_drain();            // this wave's DMA pieces of the staged tile have landed (usp_common.hpp)
     __syncthreads();
 #endif
   }
@@ -712,6 +714,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
   if (n_iter > 0) { stage_setup(0); stage_all(); stage_stats(0); }
+  dma_drain();            // this wave's DMA pieces of the staged tile have landed (usp_common.hpp)
   __syncthreads();
 
   // The streaming loop is instantiated once per role, with ROLE a compile-time constant, and the role
@@ -844,6 +847,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
       if (prefetch) stage_stats(buf_n);
       buf_b = buf_a;
       buf_a = buf_n;
+      dma_drain();            // this wave's DMA pieces of the staged tile have landed (usp_common.hpp)
       __syncthreads();
     }
 

@@ -296,6 +296,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
     dma_k(0, 0); dma_v(0, 0);
     if (nt > 1) dma_k(1, 1);
   }
+  dma_drain();
   __syncthreads();
   if (nt > 0 && wave_kv_end > 0) qk(0, sa, sb);
   // K(0) must have been read by EVERY wave before the first loop iteration refills Kbuf[0] with K(2): a
@@ -399,6 +400,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
     // ---------------- phase B ----------------
     USP_LDS const char* vb = smem + (jj & 1) * KBYTES + v_rd;
     u32x4 va[NB];
+    float mt = USP_NEG_INF;
     auto rd_v = [&](int i) {                                  // i = ks * NDJ + dj
       const int ks = i / NDJ, dj = i % NDJ;
       USP_LDS const char* vp = vb + (4 * ks * NDJ + dj) * 256;
@@ -412,7 +414,6 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
     };
 #pragma unroll
     for (int t = 0; t < PF && t < NB; ++t) rd_v(t);
-    float mt = USP_NEG_INF;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -430,7 +431,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
     l_run += rs;
     decide(xhalf_max(mt));
 #ifndef USP_ABLATE_NOBARRIER
-    __syncthreads();
+    dma_drain();                 // this wave's pieces of K(jj+2), V(jj+1) have landed ...
+    __syncthreads();             // ... and so have everybody else's
 #endif
   };
 
@@ -469,6 +471,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       pv(j & 1, pf);
     }
     sa = na; sb = nb;
+    dma_drain();
     __syncthreads();
   }
 
