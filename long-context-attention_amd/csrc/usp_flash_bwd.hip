@@ -936,7 +936,6 @@ __global__ __launch_bounds__(256) void reduce_heads_kernel(const BwdParams p) {
 template <int D, int DT>
 static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   constexpr size_t lds0 = 2 * (2 * kTile * D * 2);
-  constexpr size_t lds1 = 2 * (2 * kTile * D * 2 + 2 * kTile * 4);
   // dK,dV
   // persistent launches: one workgroup per CU (both kernels fit once per CU), each walks n_items / grid items
   static const int cus = [] {
@@ -951,14 +950,15 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1);
   int grid = ((persist || p.sched) && p.n_items > cus) ? cus : p.n_items;
   const size_t qx = p.sched ? 16 : 0;            // LDS for the item queue's two slots
-  static const bool legacy = [] { const char* e = getenv("USP_BWD_DKDV"); return e && e[0] == 'l'; }();
+#ifdef USP_BWD_LEGACY   // A/B builds only: the single-role dK/dV formulation (MODE 1 of flash_bwd_kernel, 1.42 ms at C2)
+  constexpr size_t lds1 = 2 * (2 * kTile * D * 2 + 2 * kTile * 4);
   p.sched_lds = (int)lds1;
-  if (legacy) {      // single-role kernel, one wave per SIMD (kept for A/B runs: USP_BWD_DKDV=legacy)
-    if (causal)
-      hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 1>), dim3(grid), dim3(256), lds1 + qx, st, p);
-    else
-      hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 1>), dim3(grid), dim3(256), lds1 + qx, st, p);
-  } else {
+  if (causal)
+    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 1>), dim3(grid), dim3(256), lds1 + qx, st, p);
+  else
+    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 1>), dim3(grid), dim3(256), lds1 + qx, st, p);
+#else
+  {
     constexpr size_t lds2 = 3 * (2 * kTile * D * 2 + 2 * kTile * 4) + 4 * 2 * 4096;
     p.sched_lds = (int)lds2;
     if (causal)
@@ -966,6 +966,7 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
     else
       hipLaunchKernelGGL((flash_bwd_dkdv_kernel<D, DT, false>), dim3(grid), dim3(512), lds2 + qx, st, p);
   }
+#endif
   if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
   if (p.split) {
     const int64_t items = (int64_t)p.B * p.Sk * p.Hkv * (D / 4);
