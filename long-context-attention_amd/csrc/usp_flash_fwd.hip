@@ -574,13 +574,13 @@ template <int D, int DT>
 static int launch_fwd(const FwdParams& p, bool causal, hipStream_t st) {
   // Workgroup shape: 8 waves (256 query rows, one workgroup per CU) stage K/V once per 256 rows and win by
   // 3-4 % whenever they can give every CU work; 4 waves (128 rows, two workgroups per CU) are used only
-  // when the 8-wave item list is shorter than the CU count (measured with persistent workgroups,
-  // profiles/).  USP_FWD_WAVES=4|8 forces a shape.
+  // when the 8-wave item list is shorter than the CU count, or for short causal sequences (<= 1024 rows:
+  // +3...8 %) (measured with persistent workgroups, profiles/).  USP_FWD_WAVES=4|8 forces a shape.
   static const int forced = [] { const char* e = getenv("USP_FWD_WAVES"); return e ? atoi(e) : 0; }();
   int waves = forced;
   if (waves != 4 && waves != 8) {
     const int64_t grid8 = (int64_t)p.B * p.Hq * ((p.Sq + 255) / 256);
-    waves = grid8 < 256 ? 4 : 8;
+    waves = (grid8 < 256 || (causal && p.Sq <= 1024)) ? 4 : 8;   // short causal sequences: less diagonal waste
   }
   return waves == 4 ? launch_fwd_w<D, DT, 4>(p, causal, st) : launch_fwd_w<D, DT, 8>(p, causal, st);
 }
