@@ -131,12 +131,6 @@ USP_DEV void pin_agpr(f32x16& acc) {
 
 USP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-// XCD-aware work-item order: the dispatcher places block id on XCD id % 8; give every XCD a
-// contiguous range of the logical work list so that blocks sharing K/V share an L2.
-USP_DEV int xcd_remap(int id, int n) {
-  return ((n & 7) == 0) ? (id & 7) * (n >> 3) + (id >> 3) : id;
-}
-
 // Persistent workgroups: a launch has min(items, resident workgroup slots) workgroups and each walks a
 // static list of work items.  The dispatcher places workgroup id on XCD id % 8; every XCD owns a
 // contiguous run of the item list (all sharers of one K/V sit behind one L2) and deals it out to its
