@@ -580,7 +580,8 @@ static int launch_fwd(const FwdParams& p, bool causal, hipStream_t st) {
   int waves = forced;
   if (waves != 4 && waves != 8) {
     const int64_t grid8 = (int64_t)p.B * p.Hq * ((p.Sq + 255) / 256);
-    waves = (grid8 < 256 || (causal && p.Sq <= 1024)) ? 4 : 8;   // short causal sequences: less diagonal waste
+    // short causal sequences: less diagonal waste (dense only: in packed mode twice the items cost more to fetch)
+    waves = (grid8 < 256 || (!p.seq_q && causal && p.Sq <= 1024)) ? 4 : 8;
   }
   return waves == 4 ? launch_fwd_w<D, DT, 4>(p, causal, st) : launch_fwd_w<D, DT, 8>(p, causal, st);
 }
