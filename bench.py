@@ -121,6 +121,35 @@ def kernel_roofline(cfg, dev, iters=20):
             "kernel_ms": round(ms, 4), "traffic": pmc_traffic()}
 
 
+def reference_kernel(cfg, dev, ours_tflops, iters=10):
+    """The third-party op behind the reference's TORCH_EFFICIENT attention (yunchang/kernels/attention.py:76-86:
+    aten::_scaled_dot_product_efficient_attention on (B,H,S,D) views), timed on this GPU on the same workload,
+    equal heads (the op has no GQA).  Reported beside our kernel; never part of `value`.  None if the op does
+    not run on this box."""
+    try:
+        B, S, Hq, D = cfg["B"], cfg["S"], cfg["Hq"], cfg["D"]
+        g = torch.Generator(device=dev).manual_seed(1)
+        q, k, v = (torch.randn((B, S, Hq, D), device=dev, generator=g).to(torch.bfloat16).transpose(1, 2)
+                   for _ in range(3))
+        op = torch.ops.aten._scaled_dot_product_efficient_attention
+        f = lambda: op(q, k, v, None, True, 0.0, True, scale=D ** -0.5)
+        for _ in range(2):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            f()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        tf = fwd_flops(B, Hq, S, D) / (ms * 1e-3) / 1e12
+        return {"op": "aten::_scaled_dot_product_efficient_attention (yunchang AttnType.TORCH_EFFICIENT, "
+                      "kernels/attention.py:76-86)", "value": round(tf, 1), "unit": "TFLOP/s",
+                "kernel_ms": round(ms, 4), "our_kernel_speedup": round(ours_tflops / tf, 2)}
+    except Exception as e:                                  # informative only
+        return {"op": "aten::_scaled_dot_product_efficient_attention", "value": None, "error": repr(e)[:200]}
+
+
 def pmc_traffic():
     """HBM bytes per launch of the forward kernel from the committed rocprofv3 PMC passes
     (profiles/r01_rocprof_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
@@ -373,6 +402,7 @@ def main():
             line["smoke"] = f"backend={backend}, all ranks on cuda:0 -- NOT a measurement"
         if ws == 1:
             line["roofline"] = kernel_roofline(cfg, dev)
+            line["reference_kernel_on_this_gpu"] = reference_kernel(cfg, dev, line["roofline"]["achieved"])
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
