@@ -150,6 +150,37 @@ def reference_kernel(cfg, dev, ours_tflops, iters=10):
         return {"op": "aten::_scaled_dot_product_efficient_attention", "value": None, "error": repr(e)[:200]}
 
 
+def reference_fwdbwd(cfg, dev, ours_tflops, iters=5):
+    """torch's own scaled_dot_product_attention (the flash / efficient kernels a ROCm PyTorch ships) forward +
+    backward through autograd on the same workload and GPU: what a user of the reference gets on this box
+    without flash-attn.  Informative; None if it does not run."""
+    try:
+        import torch.nn.functional as F
+        B, S, Hq, D = cfg["B"], cfg["S"], cfg["Hq"], cfg["D"]
+        g = torch.Generator(device=dev).manual_seed(1)
+        q, k, v, do = (torch.randn((B, Hq, S, D), device=dev, generator=g).to(torch.bfloat16) for _ in range(4))
+        for t in (q, k, v):
+            t.requires_grad_(True)
+
+        def step():
+            F.scaled_dot_product_attention(q, k, v, is_causal=True).backward(do)
+            q.grad = k.grad = v.grad = None
+        for _ in range(2):
+            step()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            step()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        tf = 3.5 * fwd_flops(B, Hq, S, D) / (ms * 1e-3) / 1e12
+        return {"op": "torch.nn.functional.scaled_dot_product_attention fwd+bwd (autograd)", "value": round(tf, 1),
+                "unit": "TFLOP/s", "ms": round(ms, 4), "our_step_speedup": round(ours_tflops / tf, 2)}
+    except Exception as e:
+        return {"op": "torch sdpa fwd+bwd", "value": None, "error": repr(e)[:200]}
+
+
 def pmc_traffic():
     """HBM bytes per launch of the forward kernel from the committed rocprofv3 PMC passes
     (profiles/r01_rocprof_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate
@@ -403,6 +434,8 @@ def main():
         if ws == 1:
             line["roofline"] = kernel_roofline(cfg, dev)
             line["reference_kernel_on_this_gpu"] = reference_kernel(cfg, dev, line["roofline"]["achieved"])
+            if cfg["bwd"]:
+                line["reference_fwdbwd_on_this_gpu"] = reference_fwdbwd(cfg, dev, value)
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
