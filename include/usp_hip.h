@@ -38,6 +38,16 @@ enum {
 };
 
 /* A (batch, seq, head, dim) view: element pointer + element strides; dim stride is 1. */
+/* Launch flags (usp_fwd_args.flags / usp_bwd_args.flags).
+ * USP_LAUNCH_INTERLEAVE: other kernels -- RCCL's send/recv and all-to-all kernels on another stream -- must
+ * be able to start WHILE this launch runs.  By default the flash kernels are persistent: one workgroup per
+ * CU for the whole launch, each holding the CU's entire register file, so nothing else can be scheduled
+ * until the launch ends (fastest when the GPU does nothing else: +4 % forward).  With this flag one
+ * workgroup per work item is launched instead; CUs free up every few microseconds and a collective queued
+ * on another stream gets its workgroups resident at once.  Use it whenever a transfer is meant to overlap
+ * the kernel (ring steps, pipelined Ulysses exchange). */
+#define USP_LAUNCH_INTERLEAVE 1
+
 typedef struct usp_tensor {
   void* ptr;
   int64_t stride_b, stride_s, stride_h;
@@ -97,6 +107,7 @@ typedef struct usp_fwd_args {
   const int32_t* seq_q;          /* packed variable-length batch (both NULL = dense), see below */
   const int32_t* seq_k;
   int32_t* sched;                /* packed mode, optional: 64-byte device control block, see below */
+  int32_t flags;                 /* USP_LAUNCH_* bits */
 } usp_fwd_args;
 
 int usp_flash_fwd(const usp_fwd_args* args, void* stream);
@@ -146,6 +157,7 @@ typedef struct usp_bwd_args {
   const int32_t* seq_k;
   int64_t total_k;               /* packed mode: rows of the k/v/dk/dv token tensors (sizes the workspace) */
   int32_t* sched;                /* packed mode, optional: 64-byte device control block (as usp_fwd_args) */
+  int32_t flags;                 /* USP_LAUNCH_* bits */
 } usp_bwd_args;
 
 int usp_flash_bwd(const usp_bwd_args* args, void* stream);

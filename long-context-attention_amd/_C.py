@@ -17,6 +17,7 @@ _LIB_PATH = os.path.join(_HERE, "libusp_hip.so")
 _lib = None
 
 USP_BF16, USP_FP16 = 0, 1
+USP_LAUNCH_INTERLEAVE = 1      # include/usp_hip.h: launch so that collectives on other streams can slip in
 ABI_VERSION = 3
 
 
@@ -36,7 +37,8 @@ class UspFwdArgs(ctypes.Structure):
                 ("lse_stride_h", ctypes.c_int64),
                 ("merge_in", ctypes.c_int32), ("final_begin", ctypes.c_int32),
                 ("final_end", ctypes.c_int32),
-                ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("sched", ctypes.c_void_p)]
+                ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("sched", ctypes.c_void_p),
+                ("flags", ctypes.c_int32)]
 
 
 class UspBwdArgs(ctypes.Structure):
@@ -54,7 +56,7 @@ class UspBwdArgs(ctypes.Structure):
                 ("dq16", UspTensor), ("dk16", UspTensor), ("dv16", UspTensor),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
                 ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("total_k", ctypes.c_int64),
-                ("sched", ctypes.c_void_p)]
+                ("sched", ctypes.c_void_p), ("flags", ctypes.c_int32)]
 
 
 EXPORTS = ("usp_flash_fwd", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
@@ -146,7 +148,8 @@ def _lse3(t: torch.Tensor):
 
 
 def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=None,
-              merge_in: bool = False, final_begin: int = 0, final_end: Optional[int] = None):
+              merge_in: bool = False, final_begin: int = 0, final_end: Optional[int] = None,
+              interleave: bool = False):
     """usp_flash_fwd (include/usp_hip.h).  q (B,Sq,Hq,D); k,v (B,Sk,Hkv,D); lse (B,Hq,Sq) fp32;
     out 16-bit / acc fp32 (B,Sq,Hq,D).  All may be strided views (unit dim stride)."""
     _require_cuda(q, k, v, lse, out, acc)
@@ -162,6 +165,7 @@ def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=No
     a.merge_in = 1 if merge_in else 0
     a.final_begin = final_begin
     a.final_end = Sq if final_end is None else final_end
+    a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
     _check(load().usp_flash_fwd(ctypes.byref(a), _stream()), "usp_flash_fwd")
 
 
@@ -207,7 +211,7 @@ def sched_block(device) -> torch.Tensor:
 
 def flash_fwd_packed(q, k, v, seq_q, seq_k, max_q: int, max_k: int, softmax_scale: float,
                      causal: bool, lse, out=None, acc=None, merge_in: bool = False,
-                     final_begin: int = 0, final_end: int = 2):
+                     final_begin: int = 0, final_end: int = 2, interleave: bool = False):
     """usp_flash_fwd in packed variable-length mode.  q/out/acc (T,Hq,D), k/v (T',Hkv,D), lse (Hq,T)
     fp32; seq_q/seq_k (num_seq,2) int32 device tables of (first_row, rows); final_begin/final_end
     count half sequences (0,1,2)."""
@@ -224,12 +228,13 @@ def flash_fwd_packed(q, k, v, seq_q, seq_k, max_q: int, max_k: int, softmax_scal
     a.final_begin, a.final_end = int(final_begin), int(final_end)
     a.seq_q, a.seq_k = _seq(seq_q, n), _seq(seq_k, n)
     a.sched = sched_block(q.device).data_ptr()
+    a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
     _check(load().usp_flash_fwd(ctypes.byref(a), _stream()), "usp_flash_fwd")
 
 
 def flash_bwd_packed(dout, q, k, v, lse, delta, seq_q, seq_k, max_q: int, max_k: int, dq, dk, dv,
                      softmax_scale: float, causal: bool, accum_dq=False, accum_dk=False,
-                     accum_dv=False, dq16=None, dk16=None, dv16=None):
+                     accum_dv=False, dq16=None, dk16=None, dv16=None, interleave: bool = False):
     """usp_flash_bwd in packed variable-length mode (layouts as flash_fwd_packed; lse/delta (Hq,T))."""
     _require_cuda(dout, q, k, v, lse, delta, dq, dk, dv, dq16, dk16, dv16)
     n = seq_q.shape[0]
@@ -249,6 +254,7 @@ def flash_bwd_packed(dout, q, k, v, lse, delta, seq_q, seq_k, max_q: int, max_k:
     a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
     a.seq_q, a.seq_k = _seq(seq_q, n), _seq(seq_k, n)
     a.sched = sched_block(q.device).data_ptr()
+    a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
     a.total_k = k.shape[0]
     L = load()
     need = L.usp_flash_bwd_workspace_bytes(ctypes.byref(a))
@@ -269,7 +275,8 @@ def bwd_delta(dout, out, delta):
 
 
 def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causal: bool,
-              accum_dq=False, accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None):
+              accum_dq=False, accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None,
+              interleave: bool = False):
     """usp_flash_bwd.  dq/dk/dv are fp32 (B,S,H,D) views, written or accumulated; a 16-bit
     dq16/dk16/dv16 receives the FINAL rounded result instead (the fp32 tensor may then be None
     unless it is accumulated from)."""
@@ -290,6 +297,7 @@ def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causa
     a.dq, a.dk, a.dv = _t4(dq), _t4(dk), _t4(dv)
     a.dq16, a.dk16, a.dv16 = _t4(dq16), _t4(dk16), _t4(dv16)
     a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
+    a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
     L = load()
     need = L.usp_flash_bwd_workspace_bytes(ctypes.byref(a))     # > 0 only for GQA (head split)
     ws = None

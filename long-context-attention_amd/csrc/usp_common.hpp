@@ -161,7 +161,9 @@ struct ItemWalk {
 // sit behind one L2; its workgroups pull (t, bh) pairs t-major from an atomic counter, i.e. heaviest
 // first (dynamic LPT), skip empty items without leaving the fetch, and help the other XCDs' lists once
 // their own is drained.  sched[0..7] = counters, sched[8] = finished workgroups; the last workgroup to
-// finish zeroes the block again, so the caller zeroes it only once.  Thread 0 fetches and broadcasts
+// finish zeroes the block again, so the caller zeroes it only once.  Launch shapes: resident workgroups
+// that pull until the queue is dry (default), or -- USP_LAUNCH_INTERLEAVE -- one workgroup per potential
+// item that pulls ONE item and exits, so that other streams' kernels can become resident in between.  Thread 0 fetches and broadcasts
 // through two alternating LDS slots (one barrier per fetch).
 struct ItemQueue {
   int* sched;              // device control block (16 ints)
@@ -194,10 +196,14 @@ __attribute__((noinline)) USP_DEV int item_queue_fetch(
       return bh * q.n_t + t;
     }
   }
+  return -1;
+}
+
+// Thread 0, exactly once per workgroup, after its last fetch: the last workgroup to get here zeroes the block.
+__attribute__((noinline)) USP_DEV void item_queue_release(const ItemQueue& q) {
   if (atomicAdd(&q.sched[8], 1) == (int)gridDim.x - 1) {        // every other workgroup has stopped fetching
     for (int i = 0; i < 9; ++i) q.sched[i] = 0;
   }
-  return -1;
 }
 
 // all threads; `slots` = 2 ints of LDS; returns the item or -1

@@ -47,6 +47,7 @@ struct BwdParams {
   const int* seq_q; const int* seq_k; // packed variable-length batch: B (first row, rows) pairs, or NULL
   int* sched;                         // packed mode: control block of the dynamic item queue, or NULL
   int sched_lds;                      // byte offset of the queue's two LDS slots
+  int interleave;                     // USP_LAUNCH_INTERLEAVE: one workgroup per item (collectives can slip in)
 };
 
 // Packed variable-length batch: rebase the local copy of the parameters on the rows of sequence b (the
@@ -535,7 +536,9 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
         }
       }
   }
+  if (p_in.sched && p_in.interleave) break;   // one item per workgroup: leave room for other streams' kernels
   }  // next item
+  if (p_in.sched && threadIdx.x == 0) item_queue_release(queue);
 }
 
 // ======================================================================================================
@@ -883,7 +886,9 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
         else *(f32x4*)(o32 + d0) = v;
       }
   }
+  if (p_in.sched && p_in.interleave) break;   // one item per workgroup: leave room for other streams' kernels
   }  // next item
+  if (p_in.sched && threadIdx.x == 0) item_queue_release(queue);
 }
 
 // dst[b,s,h,:] (+)= sum_g ws[g][row][h][:]   -- combines the per-query-head dK / dV partials.
@@ -948,7 +953,8 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   static const bool persist = [] { const char* e = getenv("USP_BWD_PERSIST"); return !(e && e[0] == '0'); }();
   p.nblk = (p.Sk + 127) / 128;
   p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1);
-  int grid = ((persist || p.sched) && p.n_items > cus) ? cus : p.n_items;
+  const bool pers = (persist || p.sched) && !p.interleave;
+  int grid = (pers && p.n_items > cus) ? cus : p.n_items;
   const size_t qx = p.sched ? 16 : 0;            // LDS for the item queue's two slots
 #ifdef USP_BWD_LEGACY   // A/B builds only: the single-role dK/dV formulation (MODE 1 of flash_bwd_kernel, 1.42 ms at C2)
   constexpr size_t lds1 = 2 * (2 * kTile * D * 2 + 2 * kTile * 4);
@@ -978,7 +984,7 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   // dQ
   p.nblk = (p.Sq + 255) / 256;
   p.n_items = p.B * p.Hq * p.nblk;
-  grid = ((persist || p.sched) && p.n_items > cus) ? cus : p.n_items;
+  grid = (pers && p.n_items > cus) ? cus : p.n_items;
   p.sched_lds = (int)lds0;
   if (causal)
     hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 0>), dim3(grid), dim3(512), lds0 + qx, st, p);
@@ -1057,6 +1063,7 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   p.seq_q = a->seq_q; p.seq_k = a->seq_k;
   p.sched = packed ? a->sched : nullptr;
   p.sched_lds = 0;
+  p.interleave = (a->flags & USP_LAUNCH_INTERLEAVE) ? 1 : 0;
   p.ws_rows = ws_rows_of(a);
   if (packed) {
     p.do_sb = p.q_sb = p.k_sb = p.v_sb = p.lse_sb = p.dl_sb = 0;

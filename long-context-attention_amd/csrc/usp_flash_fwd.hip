@@ -39,6 +39,7 @@ struct FwdParams {
   int out_wide;                   // out rows are 16-byte aligned: 16-byte epilogue stores
   const int* seq_q; const int* seq_k;   // packed variable-length batch: B (first row, rows) pairs, or NULL
   int* sched;                           // packed mode: control block of the dynamic item queue, or NULL
+  int interleave;                       // USP_LAUNCH_INTERLEAVE: one workgroup per item (collectives can slip in)
 };
 
 constexpr int kBN = 64;    // keys per KV tile
@@ -544,7 +545,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       }
     }
   }
+  if (p_in.sched && p_in.interleave) break;   // one item per workgroup: leave room for other streams' kernels
   }  // next item
+  if (p_in.sched && threadIdx.x == 0) item_queue_release(queue);
 }
 
 template <int D, int DT, int NWAVES>
@@ -561,7 +564,7 @@ static int launch_fwd_w(FwdParams p, bool causal, hipStream_t st) {
   }();
   static const bool persist = [] { const char* e = getenv("USP_FWD_PERSIST"); return !(e && e[0] == '0'); }();
   const int slots = cus * (NWAVES == 8 ? 1 : 2);
-  const int grid = ((persist || p.sched) && p.n_items > slots) ? slots : p.n_items;
+  const int grid = (((persist || p.sched) && !p.interleave) && p.n_items > slots) ? slots : p.n_items;
   const size_t lds = 2 * 2 * kBN * D * 2 + (p.sched ? 16 : 0);
   if (causal)
     hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
@@ -640,6 +643,7 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
                 a->out.stride_s % 8 == 0 && a->out.stride_h % 8 == 0) ? 1 : 0;
   p.seq_q = a->seq_q; p.seq_k = a->seq_k;
   p.sched = packed ? a->sched : nullptr;
+  p.interleave = (a->flags & USP_LAUNCH_INTERLEAVE) ? 1 : 0;
   if (packed) p.q_sb = p.k_sb = p.v_sb = p.o_sb = p.a_sb = p.lse_sb = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool causal = a->causal != 0;

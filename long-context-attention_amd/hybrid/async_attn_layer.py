@@ -38,6 +38,9 @@ class _Lane:
 
     def __init__(self, ref: Tensor):
         self.cuda = ref.is_cuda
+        # the exchanges are meant to run beside the attention kernels (see KVRelay)
+        from ..kernels.attention import overlapping_transfers
+        self._overlap = overlapping_transfers().begin()
         if self.cuda:
             self.main = torch.cuda.current_stream()
             self.side = _side_stream(ref.device)
@@ -68,6 +71,9 @@ class _Lane:
     def finish(self):
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.side)
+        if self._overlap is not None:
+            self._overlap.end()
+            self._overlap = None
 
 
 _MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer workgroups per launch)

@@ -20,10 +20,15 @@ class HipBlockBackend:
     """The device backend: thin adapter over the C ABI (include/usp_hip.h)."""
 
     name = "hip"
+    # > 0 while a transfer is meant to overlap the kernels (KVRelay with ring degree > 1, the pipelined
+    # Ulysses exchange): launches then carry USP_LAUNCH_INTERLEAVE (include/usp_hip.h) so that RCCL's
+    # kernels can become resident beside them; otherwise the kernels run persistent (fastest alone).
+    overlap_depth = 0
 
     def fwd(self, q, k, v, softmax_scale, causal, lse, out=None, acc=None, merge_in=False,
             final_begin=0, final_end=None):
-        _C.flash_fwd(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end)
+        _C.flash_fwd(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end,
+                     interleave=self.overlap_depth > 0)
 
     def delta(self, dout, out, delta):
         _C.bwd_delta(dout, out, delta)
@@ -31,18 +36,19 @@ class HipBlockBackend:
     def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
             accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None):
         _C.flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq,
-                     accum_dk, accum_dv, dq16, dk16, dv16)
+                     accum_dk, accum_dv, dq16, dk16, dv16, interleave=self.overlap_depth > 0)
 
     def fwd_packed(self, q, k, v, seq_q, seq_k, max_q, max_k, softmax_scale, causal, lse, out=None,
                    acc=None, merge_in=False, final_begin=0, final_end=2):
         _C.flash_fwd_packed(q, k, v, seq_q, seq_k, max_q, max_k, softmax_scale, causal, lse, out, acc,
-                            merge_in, final_begin, final_end)
+                            merge_in, final_begin, final_end, interleave=self.overlap_depth > 0)
 
     def bwd_packed(self, dout, q, k, v, lse, delta, seq_q, seq_k, max_q, max_k, dq, dk, dv,
                    softmax_scale, causal, accum_dq=False, accum_dk=False, accum_dv=False, dq16=None,
                    dk16=None, dv16=None):
         _C.flash_bwd_packed(dout, q, k, v, lse, delta, seq_q, seq_k, max_q, max_k, dq, dk, dv,
-                            softmax_scale, causal, accum_dq, accum_dk, accum_dv, dq16, dk16, dv16)
+                            softmax_scale, causal, accum_dq, accum_dk, accum_dv, dq16, dk16, dv16,
+                            interleave=self.overlap_depth > 0)
 
     def merge(self, acc, lse, blk_out, blk_lse, first):
         _C.lse_merge(acc, lse, blk_out, blk_lse, first)
@@ -62,6 +68,31 @@ _BACKEND = HipBlockBackend()
 
 def get_block_backend():
     return _BACKEND
+
+
+class overlapping_transfers:
+    """Context / begin-end pair: kernels launched inside are meant to run beside transfers on other streams."""
+
+    def __init__(self):
+        self.be = None
+
+    def begin(self):
+        be = get_block_backend()
+        self.be = be if isinstance(getattr(be, "overlap_depth", None), int) else None   # test backends: no-op
+        if self.be is not None:
+            self.be.overlap_depth += 1
+        return self
+
+    def end(self):
+        if self.be is not None:
+            self.be.overlap_depth -= 1
+        self.be = None
+
+    __enter__ = begin
+
+    def __exit__(self, *a):
+        self.end()
+        return False
 
 
 def set_block_backend(backend):

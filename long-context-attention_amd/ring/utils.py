@@ -104,8 +104,13 @@ class KVRelay:
         self.slots: List[Tuple[torch.Tensor, torch.Tensor]] = [(k, v)]
         self.events = [None]
         self._stream = None
+        self._overlap = None
         if self.P == 1:
             return
+        # the relay (and the travelling dK/dV) must be able to run BESIDE the attention kernels: ask for
+        # launches that leave room for RCCL's kernels (persistent launches hold every CU until they end)
+        from ..kernels.attention import overlapping_transfers
+        self._overlap = overlapping_transfers().begin()
         cuda = k.is_cuda
         if cuda:
             self._main = torch.cuda.current_stream()
@@ -140,6 +145,9 @@ class KVRelay:
         back to the caching allocator cannot be reused while a hop still reads or writes them."""
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+        if self._overlap is not None:
+            self._overlap.end()
+            self._overlap = None
 
 
 class _NullCtx:

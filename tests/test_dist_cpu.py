@@ -208,3 +208,45 @@ def test_varlen_ring_on_gloo_matches_reference_golden(path):
         assert_close(res[r]["lse"], g.lse[r], atol, rtol, f"{g.name} lse rank {r}")
         for key in ("dq", "dk", "dv"):
             assert_close(res[r][key], getattr(g, key)[r], gt, gr, f"{g.name} {key} rank {r}")
+
+
+# ---- launches inside a ring (or a pipelined exchange) must ask for interleavable launches ---------------------
+def _overlap_worker(rank, ws, ud, rd, use_async):
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+
+    class Recording(OracleBlockBackend):
+        overlap_depth = 0
+
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def fwd(self, *a, **k):
+            self.seen.append(("fwd", self.overlap_depth))
+            return super().fwd(*a, **k)
+
+        def bwd(self, *a, **k):
+            self.seen.append(("bwd", self.overlap_depth))
+            return super().bwd(*a, **k)
+
+    be = Recording()
+    set_block_backend(be)
+    Y.set_seq_parallel_pg(ud, rd, rank, ws)
+    torch.manual_seed(0)
+    q, k, v = (torch.randn(1, 64, 4, 32, dtype=torch.bfloat16).requires_grad_(True) for _ in range(3))
+    layer = (Y.AsyncLongContextAttention(ring_impl_type="zigzag") if use_async
+             else Y.LongContextAttention(ring_impl_type="zigzag", attn_type=Y.AttnType.HIP))
+    layer(q, k, v, causal=True).sum().backward()
+    return be.seen, be.overlap_depth
+
+
+@pytest.mark.parametrize("ud,rd,use_async,expect", [(1, 2, False, True), (2, 1, False, False), (2, 1, True, True)])
+def test_kernels_inside_a_transfer_window_are_launched_interleavable(ud, rd, use_async, expect):
+    """Persistent launches hold every CU until they end, so a ring relay or a pipelined exchange could not
+    overlap them: HipBlockBackend.overlap_depth must be > 0 exactly while such transfers are in flight (it
+    becomes USP_LAUNCH_INTERLEAVE on the C ABI) and back to 0 afterwards."""
+    for seen, depth_after in run_distributed(_overlap_worker, 2, ud, rd, use_async):
+        assert depth_after == 0
+        assert seen and all((d > 0) == expect for _, d in seen), seen

@@ -54,7 +54,7 @@ def test_fuzz_dense(dev, seed):
     for _ in range(2):
         out = torch.full((B, Sq, Hq, D), float("nan"), dtype=tq.dtype, device=dev)
         lse = torch.full((B, Hq, Sq), float("nan"), dtype=torch.float32, device=dev)
-        _C.flash_fwd(tq, tk, tv, scale, causal, lse, out=out)
+        _C.flash_fwd(tq, tk, tv, scale, causal, lse, out=out, interleave=len(runs) == 1)
         runs.append((_f(out), _f(lse)))
     assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1]), what
     fin = np.isfinite(rl)
@@ -69,7 +69,8 @@ def test_fuzz_dense(dev, seed):
     grads = []
     for _ in range(2):
         dq, dk, dv = (torch.full_like(t, float("nan")) for t in (tq, tk, tv))
-        _C.flash_bwd(tdo, tq, tk, tv, lse_t, delta, None, None, None, scale, causal, dq16=dq, dk16=dk, dv16=dv)
+        _C.flash_bwd(tdo, tq, tk, tv, lse_t, delta, None, None, None, scale, causal, dq16=dq, dk16=dk, dv16=dv,
+                     interleave=len(grads) == 1)
         grads.append([_f(x) for x in (dq, dk, dv)])
     for a_, b_, n_ in zip(grads[0], grads[1], ("dq", "dk", "dv")):
         assert np.array_equal(a_, b_), f"{what}: {n_} differs between two launches"
@@ -115,7 +116,8 @@ def test_fuzz_packed(dev, seed):
     for _ in range(2):
         out = torch.full((Tq, Hq, D), float("nan"), dtype=tq.dtype, device=dev)
         lse = torch.full((Hq, Tq), float("nan"), dtype=torch.float32, device=dev)
-        _C.flash_fwd_packed(tq, tk, tv, sq, sk, max(lq), max(lk), scale, causal, lse, out=out)
+        # second launch: the one-item-per-workgroup shape used beside transfers (USP_LAUNCH_INTERLEAVE)
+        _C.flash_fwd_packed(tq, tk, tv, sq, sk, max(lq), max(lk), scale, causal, lse, out=out, interleave=len(runs) == 1)
         runs.append((_f(out), _f(lse)))
     assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1]), what
     fin = np.isfinite(rl)
@@ -129,7 +131,7 @@ def test_fuzz_packed(dev, seed):
     for _ in range(2):
         dq, dk, dv = (torch.full_like(t, float("nan")) for t in (tq, tk, tv))
         _C.flash_bwd_packed(tdo, tq, tk, tv, lse_t, delta, sq, sk, max(lq), max(lk), None, None, None, scale, causal,
-                            dq16=dq, dk16=dk, dv16=dv)
+                            dq16=dq, dk16=dk, dv16=dv, interleave=len(grads) == 1)
         grads.append([_f(x) for x in (dq, dk, dv)])
     for a_, b_, n_ in zip(grads[0], grads[1], ("dq", "dk", "dv")):
         assert np.array_equal(a_, b_), f"{what}: {n_} differs between two launches"
