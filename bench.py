@@ -422,6 +422,8 @@ def main():
                        "kv_heads": cfg["Hkv"], "parallelism": f"ulysses{cfg['ud']}xring{cfg['rd']}",
                        "layout": cfg["impl"], "pass": "fwd+bwd" if cfg["bwd"] else "fwd",
                        "layer": "AsyncLongContextAttention" if args.async_ulysses else "LongContextAttention",
+                       "ulysses_exchange": ("pipelined over head groups" if args.async_ulysses or (
+                           hasattr(attn, "_pipelined_exchange") and attn._pipelined_exchange(lq, lk)) else "sequential"),
                        "tokens_per_gpu": cfg["S"] * cfg["B"] // ws,
                        "assumed": "B=1 and causal=True where BASELINE.json's config string is silent"},
             "frac_of_mfma_roofline": round(value / (ws * PEAK_BF16_TFLOPS), 4),

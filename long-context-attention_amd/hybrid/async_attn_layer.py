@@ -79,14 +79,22 @@ class _Lane:
 _MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer workgroups per launch)
 
 
-def _groups(Hq, Hkv, P):
+_FILL_ITEMS = 256   # 256-row work items that give every CU of an MI355X one item
+
+
+def _groups(Hq, Hkv, P, B=None, S=None):
     """(number of head groups, kv heads per rank per group, query heads per kv head).  A group is a
-    set of whole KV heads (with their query heads) of every rank's post-exchange share."""
+    set of whole KV heads (with their query heads) of every rank's post-exchange share.  With the problem
+    size (B, S = full sequence) given, the pipeline is kept shallow enough that every group's attention
+    launch still has one 256-row work item per CU (a starved launch costs more than the exposed exchange)."""
     assert Hq % P == 0 and Hkv % P == 0, f"heads ({Hq}, {Hkv}) not divisible by ulysses degree {P}"
     per_rank = Hkv // P
     ng = 1
     if P > 1:                       # nothing to hide without an exchange
-        for cand in range(min(_MAX_GROUPS, per_rank), 0, -1):
+        cap = _MAX_GROUPS
+        if B is not None and S is not None:
+            cap = max(1, min(cap, (B * (Hq // P) * ((S + 255) // 256)) // _FILL_ITEMS))
+        for cand in range(min(cap, per_rank), 0, -1):
             if per_rank % cand == 0:
                 ng = cand
                 break
@@ -115,7 +123,7 @@ class _AsyncUSPFunc(torch.autograd.Function):
         P = dist.get_world_size(ulysses_pg)
         B, Sl, Hq, D = q.shape
         Hkv = k.shape[2]
-        ng, kvh, g = _groups(Hq, Hkv, P)
+        ng, kvh, g = _groups(Hq, Hkv, P, B, Sl * P)
         if softmax_scale is None:
             softmax_scale = D ** (-0.5)
         lane = _Lane(q)

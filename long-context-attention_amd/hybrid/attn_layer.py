@@ -2,7 +2,12 @@
 
 forward = Ulysses head all-to-all of q, k, v (attn_layer.py:111-119) -> ring attention over the
 ring group (:132-147) -> all-to-all of the output back to sequence sharding (:156-158).
+
+MI355X-first: where the exchange is the only communication (ulysses degree > 1, ring degree 1) it is
+pipelined over head groups behind the attention instead of running exposed in front of and behind it
+(LongContextAttention._pipelined_exchange); results are identical.
 """
+import os
 from typing import Any
 
 import torch
@@ -12,6 +17,8 @@ from torch import Tensor
 from ..comm.all_to_all import SeqAllToAll4D, SeqAllToAll5D
 from ..globals import PROCESS_GROUP
 from ..kernels import AttnType
+from ..ring.zigzag_ring_flash_attn import _check_hot_path_args
+from .async_attn_layer import _AsyncUSPFunc, _RING_FWD_BWD, _groups
 from .utils import RING_IMPL_DICT, RING_IMPL_QKVPACKED_DICT
 
 
@@ -45,12 +52,38 @@ class LongContextAttention(torch.nn.Module):
         self.gather_idx = gather_idx
         self.attn_processor = attn_processor
         self.ring_attn_fn = RING_IMPL_DICT[ring_impl_type]
+        self.ring_impl_type = ring_impl_type
+
+    def _pipelined_exchange(self, query: Tensor, key: Tensor) -> bool:
+        """Hide the Ulysses exchange behind the attention by pipelining over head groups (the
+        AsyncLongContextAttention schedule, hybrid/async_attn_layer.py; identical results)?  Automatic only
+        where it involves ONE communicator -- ulysses degree > 1 with ring degree 1, where the exchange is the
+        whole communication and the sequential layer leaves all of it exposed -- and when there is more than
+        one head group to pipeline.  USP_PIPELINE_ULYSSES=0 disables it, =1 also enables it beside a ring."""
+        mode = os.environ.get("USP_PIPELINE_ULYSSES", "auto")
+        if mode == "0" or not query.is_cuda or self.use_sync or self.attn_processor is not None:
+            return False
+        if (self.scatter_idx, self.gather_idx) != (2, 1) or self.ring_impl_type not in _RING_FWD_BWD:
+            return False
+        P = dist.get_world_size(self.ulysses_pg)
+        if P == 1 or (mode != "1" and dist.get_world_size(self.ring_pg) > 1):
+            return False
+        B, Sl, Hq, _ = query.shape
+        Hkv = key.shape[2]
+        if Hq % P or Hkv % P:
+            return False
+        return _groups(Hq, Hkv, P, B, Sl * P)[0] > 1
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, dropout_p=0.0, softmax_scale=None,
                 causal=False, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
                 deterministic=False, return_attn_probs=False, *args: Any) -> Tensor:
         """query (bs, seq_len/N, head_cnt, head_size); key/value (bs, seq_len/N, kv_head_cnt,
         head_size) -> context (bs, seq_len/N, head_cnt, head_size)."""
+        if self._pipelined_exchange(query, key):
+            assert alibi_slopes is None
+            _check_hot_path_args(dropout_p, window_size, softcap)
+            return _AsyncUSPFunc.apply(query, key, value, softmax_scale, causal, self.ulysses_pg, self.ring_pg,
+                                       self.ring_impl_type)
         # (bs, seq_len/N, head_cnt, head_size) -> (bs, seq_len, head_cnt/N, head_size)
         query_layer = SeqAllToAll4D.apply(self.ulysses_pg, query, self.scatter_idx, self.gather_idx,
                                           self.use_sync)

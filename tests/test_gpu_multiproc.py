@@ -35,9 +35,14 @@ def _order_p2p_like_rccl():
     U.RingComm._gloo_ordered = True
 
 
-def _usp_gpu_worker(rank, ws, path):
+def _usp_gpu_worker(rank, ws, path, pipelined=False):
     import yunchang_amd as Y
     _order_p2p_like_rccl()
+    if pipelined:        # LongContextAttention's pipelined Ulysses exchange, also beside a ring, on tiny fixtures
+        import os
+        import yunchang_amd.hybrid.async_attn_layer as AL
+        os.environ["USP_PIPELINE_ULYSSES"] = "1"
+        AL._FILL_ITEMS = 1
     from yunchang_amd.kernels import get_block_backend
     assert get_block_backend().name == "hip"
     dev = torch.device("cuda:0")
@@ -56,6 +61,7 @@ def _usp_gpu_worker(rank, ws, path):
         attn = Y.UlyssesAttention(Y.PROCESS_GROUP.ULYSSES_PG, attn_type=Y.AttnType.HIP)
     else:
         attn = Y.LongContextAttention(ring_impl_type=g.impl, attn_type=Y.AttnType.HIP)
+        assert attn._pipelined_exchange(lq, lk) == (pipelined and g.ud > 1 and g.Hkv // g.ud > 1)
     res = {}
     for it in range(2):                      # twice: buffers / streams must be reusable
         for t in (lq, lk, lv):
@@ -100,6 +106,21 @@ DENSE = [f for f in golden_files() if "_w1" not in f and "qkvpacked" not in f]
 def test_usp_multiprocess_one_gpu(gloo_cuda, path):
     g = Golden(path)
     res = run_distributed(_usp_gpu_worker, g.ws, path)
+    for r in range(g.ws):
+        assert_close(res[r]["out"], g.out[r], *TOL[g.dtype]["out"], f"{g.name} out rank {r}")
+        for key in ("dq", "dk", "dv"):
+            assert_close(res[r][key], getattr(g, key)[r], *TOL[g.dtype]["grad"], f"{g.name} {key} rank {r}")
+
+
+PIPE = [f for f in DENSE if "c3_w2_u2r1" in f or "c5_w8_u2r4_gqa_bf16" in f or "n_w4_u2r2_strip" in f]
+
+
+@pytest.mark.parametrize("path", PIPE, ids=lambda p: p.split("/")[-1][:-4])
+def test_long_context_attention_with_pipelined_exchange(gloo_cuda, path):
+    """LongContextAttention taking its head-group pipelined exchange path (side-stream all-to-all beside the
+    ring attention kernels, launched interleavable) against the reference goldens."""
+    g = Golden(path)
+    res = run_distributed(_usp_gpu_worker, g.ws, path, True)
     for r in range(g.ws):
         assert_close(res[r]["out"], g.out[r], *TOL[g.dtype]["out"], f"{g.name} out rank {r}")
         for key in ("dq", "dk", "dv"):
