@@ -4,6 +4,7 @@ update_out_and_lse :10-51), plus the side-stream relay this package's schedules 
 Transport is torch.distributed point-to-point (`batch_isend_irecv` == grouped RCCL send/recv over
 xGMI on ROCm; gloo on CPU for the orchestration tests).
 """
+import os
 from typing import List, Optional, Tuple
 
 import torch
@@ -85,14 +86,23 @@ class RingComm:
 
 
 class KVRelay:
-    """Relays K and V around the ring AHEAD of the attention kernels.
+    """Brings the K and V of every other ring rank to this rank AHEAD of the attention kernels.
 
     The reference posts the transfer for step s+1 from the compute stream at the top of step s
-    (zigzag_ring_flash_attn.py:46-49), so RCCL only starts it once attention(s-1) has finished.
-    Here the whole relay chain (P-1 hops, one receive slot per hop: HBM is not the constraint on a
-    288 GB part) is queued up-front on a side HIP stream; hop s+1 starts the moment hop s has
-    landed, independent of the attention kernels, and the compute stream only waits on the event of
-    the hop it is about to consume.  On host tensors (gloo tests) the same chain runs inline.
+    (zigzag_ring_flash_attn.py:46-49), so RCCL only starts it once attention(s-1) has finished, and it relays
+    hop by hop: the K/V of rank r-s reach rank r over s consecutive hops on ONE link per GPU.  Here everything
+    is queued up-front on a side HIP stream, with one receive slot per source rank (HBM is not the constraint
+    on a 288 GB part), and the compute stream only waits on the event of the slot it is about to consume:
+
+      * "direct" (default for ring degree > 2): every rank sends its OWN K/V straight to all P-1 peers in one
+        grouped send/recv.  xGMI is a full mesh of point-to-point links, so the P-1 transfers into a rank
+        arrive over P-1 different links in parallel: the same bytes per rank as the relay, but one transfer
+        time instead of P-1 serial ones (BASELINE's 4-GPU config moves 64 MiB per hop against 0.25 ms of
+        attention per step: a one-link relay is link-bound there).
+      * "chain" (ring degree 2, or USP_KV_RELAY=chain): the reference's hop-by-hop relay, hop s+1 starting the
+        moment hop s has landed.
+
+    Slot s holds the K/V of ring rank r-s in both modes.  On host tensors (gloo tests) the same runs inline.
     """
 
     def __init__(self, process_group, k: torch.Tensor, v: torch.Tensor):
@@ -117,6 +127,28 @@ class KVRelay:
             self._stream = _side_stream(k.device)
             self._stream.wait_stream(self._main)          # k, v are produced on the compute stream
         ctx = torch.cuda.stream(self._stream) if cuda else _NullCtx()
+        mode = os.environ.get("USP_KV_RELAY", "direct" if self.P > 2 else "chain")
+        if mode == "direct":
+            with ctx:
+                r = dist.get_rank(process_group)
+                to_global = lambda i: dist.get_global_rank(process_group, i % self.P) if process_group is not None else i % self.P
+                comm = RingComm(process_group)          # one grouped send/recv to and from every peer
+                for s in range(1, self.P):
+                    nk, nv = torch.empty_like(k), torch.empty_like(v)
+                    dst, src = to_global(r + s), to_global(r - s)
+                    comm._ops += [dist.P2POp(dist.isend, k, dst, group=process_group),
+                                  dist.P2POp(dist.irecv, nk, src, group=process_group),
+                                  dist.P2POp(dist.isend, v, dst, group=process_group),
+                                  dist.P2POp(dist.irecv, nv, src, group=process_group)]
+                    self.slots.append((nk, nv))
+                comm.commit()
+                comm.wait()
+                ev = None
+                if cuda:
+                    ev = torch.cuda.Event()
+                    ev.record(self._stream)
+                self.events += [ev] * (self.P - 1)
+            return
         with ctx:
             cur_k, cur_v = k, v
             for _ in range(self.P - 1):
