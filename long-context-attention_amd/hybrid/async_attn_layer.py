@@ -49,15 +49,12 @@ class _Lane:
         """Queue all_to_all_single(send) behind everything currently on the main stream; returns
         (recv, event).  `send` must stay referenced until `wait` (the caller keeps it)."""
         if not self.cuda:
-            recv = torch.empty_like(send)
-            dist.all_to_all_single(recv, send, group=group)
-            return recv, None
+            return A._exchange(send, group, False), None
         ready = torch.cuda.Event()
         ready.record(self.main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
-            recv = torch.empty_like(send)
-            dist.all_to_all_single(recv, send, group=group)
+            recv = A._exchange(send, group, False)       # (module attribute: bench.py's overlap probe swaps it)
             done = torch.cuda.Event()
             done.record(self.side)
         send.record_stream(self.side)
