@@ -748,3 +748,26 @@ def test_c2_full_size_vs_the_reference_third_party_op(dev):
     lim = 2e-2 + 2e-2 * ref_out.transpose(1, 2).float().abs()
     assert bool((err <= lim).all()), f"max abs err {float(err.max()):.3e}"
     assert float((lse - ref_lse.float()).abs().max()) < 2e-3
+
+
+def test_c2_full_size_backward_vs_torch_sdpa(dev):
+    """BASELINE configs[1] at full size, forward + backward, against torch's own scaled_dot_product_attention
+    autograd on this GPU (the kernels a ROCm PyTorch ships; the reference's TORCH path has no backward at all,
+    kernels/attention.py:138-159).  Stated gradient tolerance (golden_util.TOL)."""
+    import torch.nn.functional as F
+    from yunchang_amd.kernels import hip_attn_func
+    B, S, H, D = 2, 8192, 16, 128
+    g = torch.Generator(device=dev).manual_seed(11)
+    q, k, v, do = (torch.randn((B, S, H, D), device=dev, generator=g).to(torch.bfloat16) for _ in range(4))
+    ours = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    hip_attn_func(*ours, causal=True).backward(do)
+    ref = [t.transpose(1, 2).clone().requires_grad_(True) for t in (q, k, v)]
+    try:
+        F.scaled_dot_product_attention(*ref, is_causal=True).backward(do.transpose(1, 2))
+    except Exception as e:                     # pragma: no cover - depends on the torch build
+        pytest.skip(f"torch SDPA backward does not run here: {e!r}")
+    atol, rtol = TOL["bfloat16"]["grad"]
+    for a, b, name in zip(ours, ref, ("dq", "dk", "dv")):
+        ga, gb = a.grad.float(), b.grad.transpose(1, 2).float()
+        err = (ga - gb).abs()
+        assert bool((err <= atol + rtol * gb.abs()).all()), f"{name}: max abs err {float(err.max()):.3e}"
