@@ -260,6 +260,70 @@ static int run_fwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, in
   return fail;
 }
 
+// ---- overlap: can a transfer-like kernel on another stream run BESIDE the ring-step attention launches? -------
+// The stand-in for RCCL's send/recv kernel is a copy with RCCL's footprint: a handful of workgroups that stay
+// resident for the whole transfer (here: `wgs` workgroups move `mib` MiB; 8 workgroups reach roughly the
+// bandwidth of one xGMI link).  Stream A: `steps` ring-step forward launches (C5 rank block, non-causal);
+// stream B: steps-1 such copies back to back.  overlap = 1 - (t_both - t_attention) / t_copies.
+__global__ void link_like_copy(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    dst[i] = src[i];
+}
+
+static int run_overlap(int steps, int mib, int wgs) {
+  const int B = 1, Sq = 16384, Sk = 8192, Hq = 16, Hkv = 2, D = 128, dt = 0;
+  const size_t nq = (size_t)B * Sq * Hq * D, nk = (size_t)B * Sk * Hkv * D, nl = (size_t)B * Hq * Sq;
+  std::vector<uint16_t> qb, kb, vb; std::vector<float> qf, kf, vf;
+  fill(qb, qf, nq, dt, 1); fill(kb, kf, nk, dt, 2); fill(vb, vf, nk, dt, 3);
+  uint16_t *dq = dev_upload(qb), *dk = dev_upload(kb), *dv = dev_upload(vb);
+  uint16_t* dout = dev_alloc<uint16_t>(nq);
+  float* dlse = dev_alloc<float>(nl);
+  const size_t n16 = (size_t)mib * (1 << 20) / 16;
+  uint4 *csrc = dev_alloc<uint4>(n16, 0x11), *cdst = dev_alloc<uint4>(n16, 0x22);
+  usp_fwd_args a; memset(&a, 0, sizeof(a));
+  a.dtype = dt; a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.causal = 0;
+  a.softmax_scale = 1.f / sqrtf((float)D);
+  a.q = bshd(dq, Sq, Hq, D); a.k = bshd(dk, Sk, Hkv, D); a.v = bshd(dv, Sk, Hkv, D);
+  a.out = bshd(dout, Sq, Hq, D);
+  a.lse = dlse; a.lse_stride_b = (int64_t)Hq * Sq; a.lse_stride_h = Sq;
+  a.final_begin = 0; a.final_end = Sq;
+  hipStream_t sa, sb; HIP_OK(hipStreamCreate(&sa)); HIP_OK(hipStreamCreate(&sb));
+  hipEvent_t e0, ea, eb; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&ea)); HIP_OK(hipEventCreate(&eb));
+  auto attention = [&] { for (int i = 0; i < steps; ++i) usp_flash_fwd(&a, sa); };
+  auto copies = [&] {
+    for (int i = 0; i + 1 < steps; ++i)
+      hipLaunchKernelGGL(link_like_copy, dim3(wgs), dim3(256), 0, sb, csrc, cdst, n16);
+  };
+  auto measure = [&](bool do_a, bool do_b) {          // wall time from a common start to both streams idle
+    float best = 1e30f;
+    for (int rep = 0; rep < 5; ++rep) {
+      HIP_OK(hipDeviceSynchronize());
+      HIP_OK(hipEventRecord(e0, sa));
+      HIP_OK(hipStreamWaitEvent(sb, e0, 0));
+      if (do_b) copies();                             // queued first, as KVRelay queues the transfers up-front
+      if (do_a) attention();
+      HIP_OK(hipEventRecord(ea, sa)); HIP_OK(hipEventRecord(eb, sb));
+      HIP_OK(hipEventSynchronize(ea)); HIP_OK(hipEventSynchronize(eb));
+      float ta, tb; HIP_OK(hipEventElapsedTime(&ta, e0, ea)); HIP_OK(hipEventElapsedTime(&tb, e0, eb));
+      const float t = ta > tb ? ta : tb;
+      best = t < best ? t : best;
+    }
+    return best;
+  };
+  warm_up([&] { usp_flash_fwd(&a, sa); });
+  const float t_copy = measure(false, true);
+  printf("OVERLAP copies alone: %d x %d MiB on %d workgroups: %.3f ms (%.0f GB/s each way)\n", steps - 1, mib, wgs,
+         t_copy, (steps - 1) * (double)mib * 1.048576 / t_copy);
+  for (int inter = 0; inter < 2; ++inter) {
+    a.flags = inter ? USP_LAUNCH_INTERLEAVE : 0;
+    const float t_att = measure(true, false), t_both = measure(true, true);
+    printf("OVERLAP %-26s attention alone %.3f ms | with copies %.3f ms | overlap = %.3f\n",
+           inter ? "USP_LAUNCH_INTERLEAVE" : "persistent launches", t_att, t_both, 1.f - (t_both - t_att) / t_copy);
+  }
+  hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); hipFree(dlse); hipFree(csrc); hipFree(cdst);
+  return 0;
+}
+
 // fused merge: KV split in two halves, two calls (acc write, then merge_in + final) == one full call.
 // Also exercises the row-range logic: rows [0, Sq/2) are declared final already in call 1 when
 // `partial_final` is set (they then must NOT be touched by call 2, which only covers rows Sq/2..).
@@ -404,13 +468,14 @@ static int suite(bool with_bwd) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: kbench probe|fwd|fwdmerge|bwd|suite ...\n"); return 64; }
+  if (argc < 2) { fprintf(stderr, "usage: kbench probe|fwd|fwdmerge|bwd|suite|overlap [steps MiB workgroups] ...\n"); return 64; }
   std::string cmd = argv[1];
   auto I = [&](int i) { return atoi(argv[i]); };
   if (cmd == "probe") return run_probe();
   if (cmd == "suite") return suite(argc > 2 && std::string(argv[2]) == "bwd");
   if (cmd == "fwd" && argc >= 12) return run_fwd(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
   if (cmd == "bwd" && argc >= 12) return run_bwd(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
+  if (cmd == "overlap") return run_overlap(argc > 2 ? I(2) : 4, argc > 3 ? I(3) : 16, argc > 4 ? I(4) : 8);
   if (cmd == "fwdmerge" && argc >= 9) return run_fwdmerge(I(2), I(3), I(4), I(5), I(6), I(7), I(8));
   fprintf(stderr, "bad arguments\n");
   return 64;
