@@ -11,6 +11,10 @@ from oracle import usp_oracle as O
 
 pytestmark = pytest.mark.gpu
 
+import os
+_N_DENSE = int(os.environ.get("USP_FUZZ_DENSE", "40"))      # larger sweeps: USP_FUZZ_DENSE=400 USP_FUZZ_PACKED=200
+_N_PACKED = int(os.environ.get("USP_FUZZ_PACKED", "20"))
+
 
 @pytest.fixture(scope="module")
 def dev():
@@ -39,7 +43,7 @@ def _dense_case(rs):
     return B, Sq, Sk, Hq, Hkv, D, causal, dt
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(_N_DENSE))
 def test_fuzz_dense(dev, seed):
     from yunchang_amd import _C
     rs = np.random.RandomState(1000 + seed)
@@ -78,7 +82,7 @@ def test_fuzz_dense(dev, seed):
         assert_close(g_, r_, *TOL[dt]["grad"], f"{what} {n_}")
 
 
-@pytest.mark.parametrize("seed", range(20))
+@pytest.mark.parametrize("seed", range(_N_PACKED))
 def test_fuzz_packed(dev, seed):
     from yunchang_amd import _C
     rs = np.random.RandomState(2000 + seed)
