@@ -1,13 +1,6 @@
-"""String -> ring function registries: same keys as yunchang/hybrid/utils.py:14-28 (note the key is
-"strip", not "stripe").  Variants outside the scope of this package raise when called."""
-from ..ring import (
-    ring_flash_attn_func,
-    ring_flash_attn_qkvpacked_func,
-    stripe_flash_attn_func,
-    stripe_flash_attn_qkvpacked_func,
-    zigzag_ring_flash_attn_func,
-    zigzag_ring_flash_attn_qkvpacked_func,
-)
+"""String -> ring function registries: same keys as yunchang/hybrid/utils.py:14-28 (note the key is "strip",
+not "stripe").  Variants outside the scope of this package raise when called."""
+from .. import ring as _ring
 
 
 def _out_of_scope(name):
@@ -19,18 +12,12 @@ def _out_of_scope(name):
     return fn
 
 
-RING_IMPL_DICT = {
-    "basic": ring_flash_attn_func,
-    "zigzag": zigzag_ring_flash_attn_func,
-    "strip": stripe_flash_attn_func,
-    "basic_pytorch": ring_flash_attn_func,
-    "basic_flashinfer": _out_of_scope("basic_flashinfer"),
-    "basic_npu": _out_of_scope("basic_npu"),
-}
+# key -> stem of the implementing functions in yunchang_amd.ring (<stem>_func / <stem>_qkvpacked_func)
+_STEMS = {"basic": "ring_flash_attn", "zigzag": "zigzag_ring_flash_attn", "strip": "stripe_flash_attn"}
 
-RING_IMPL_QKVPACKED_DICT = {
-    "basic": ring_flash_attn_qkvpacked_func,
-    "zigzag": zigzag_ring_flash_attn_qkvpacked_func,
-    "strip": stripe_flash_attn_qkvpacked_func,
-    "basic_flashinfer": _out_of_scope("basic_flashinfer"),
-}
+RING_IMPL_DICT = {key: getattr(_ring, f"{stem}_func") for key, stem in _STEMS.items()}
+RING_IMPL_DICT["basic_pytorch"] = RING_IMPL_DICT["basic"]          # every dense backend is the HIP kernel here
+RING_IMPL_DICT.update({key: _out_of_scope(key) for key in ("basic_flashinfer", "basic_npu")})
+
+RING_IMPL_QKVPACKED_DICT = {key: getattr(_ring, f"{stem}_qkvpacked_func") for key, stem in _STEMS.items()}
+RING_IMPL_QKVPACKED_DICT["basic_flashinfer"] = _out_of_scope("basic_flashinfer")
