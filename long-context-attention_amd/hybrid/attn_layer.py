@@ -22,13 +22,34 @@ from .async_attn_layer import _AsyncUSPFunc, _RING_FWD_BWD, _groups
 from .utils import RING_IMPL_DICT, RING_IMPL_QKVPACKED_DICT
 
 
-class LongContextAttention(torch.nn.Module):
-    """Unified sequence parallel attention (ulysses x ring).
+def _first(result):
+    """Ring functions return `out` or `(out, lse, None)`; the layers only hand `out` on."""
+    return result[0] if isinstance(result, tuple) else result
 
-    Arguments (identical to the reference):
-        scatter_idx (int): scatter_idx for all2all comm (2 = heads)
-        gather_idx (int): gather_idx for all2all comm (1 = sequence)
-        ring_impl_type (str): key of RING_IMPL_DICT ("basic" | "zigzag")
+
+class _USPLayer(torch.nn.Module):
+    """What both layers share: the 2-D process grid of set_seq_parallel_pg and the two exchanges."""
+
+    def __init__(self, scatter_idx: int, gather_idx: int, use_sync: bool, attn_type: AttnType) -> None:
+        super().__init__()
+        self.ring_pg, self.ulysses_pg = PROCESS_GROUP.RING_PG, PROCESS_GROUP.ULYSSES_PG
+        assert (
+            self.ulysses_pg is not None or self.ring_pg is not None
+        ), f"use set_seq_parallel_pg() first. Now ulysses pg {self.ulysses_pg} and ring pg {self.ring_pg}"
+        self.scatter_idx, self.gather_idx = scatter_idx, gather_idx
+        self.use_sync, self.attn_type = use_sync, attn_type
+
+    def _ring_options(self, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
+                      return_attn_probs):
+        return dict(dropout_p=dropout_p, softmax_scale=softmax_scale, causal=causal, window_size=window_size,
+                    softcap=softcap, alibi_slopes=alibi_slopes, deterministic=deterministic,
+                    return_attn_probs=return_attn_probs, group=self.ring_pg, attn_type=self.attn_type)
+
+
+class LongContextAttention(_USPLayer):
+    """Unified sequence parallel attention (ulysses x ring), arguments as in the reference:
+        scatter_idx / gather_idx (int): dims of the all-to-all (2 = heads, 1 = sequence)
+        ring_impl_type (str): key of RING_IMPL_DICT ("basic" | "zigzag" | "strip")
         use_pack_qkv (bool): accepted for compatibility; q, k, v are always exchanged separately
             (the reference's packed branch is dead code: `.continous()` typo at attn_layer.py:88,
             and it cannot express GQA)
@@ -39,17 +60,8 @@ class LongContextAttention(torch.nn.Module):
     def __init__(self, scatter_idx: int = 2, gather_idx: int = 1, ring_impl_type: str = "basic",
                  use_pack_qkv: bool = False, use_sync: bool = False,
                  attn_type: AttnType = AttnType.FA, attn_processor: torch.nn.Module = None) -> None:
-        super(LongContextAttention, self).__init__()
-        self.ring_pg = PROCESS_GROUP.RING_PG
-        self.ulysses_pg = PROCESS_GROUP.ULYSSES_PG
+        super().__init__(scatter_idx, gather_idx, use_sync, attn_type)
         self.use_pack_qkv = use_pack_qkv
-        self.use_sync = use_sync
-        self.attn_type = attn_type
-        assert (
-            self.ulysses_pg is not None or self.ring_pg is not None
-        ), f"use set_seq_parallel_pg() first. Now ulysses pg {self.ulysses_pg} and ring pg {self.ring_pg}"
-        self.scatter_idx = scatter_idx
-        self.gather_idx = gather_idx
         self.attn_processor = attn_processor
         self.ring_attn_fn = RING_IMPL_DICT[ring_impl_type]
         self.ring_impl_type = ring_impl_type
@@ -84,29 +96,17 @@ class LongContextAttention(torch.nn.Module):
             _check_hot_path_args(dropout_p, window_size, softcap)
             return _AsyncUSPFunc.apply(query, key, value, softmax_scale, causal, self.ulysses_pg, self.ring_pg,
                                        self.ring_impl_type)
-        # (bs, seq_len/N, head_cnt, head_size) -> (bs, seq_len, head_cnt/N, head_size)
-        query_layer = SeqAllToAll4D.apply(self.ulysses_pg, query, self.scatter_idx, self.gather_idx,
-                                          self.use_sync)
-        key_layer = SeqAllToAll4D.apply(self.ulysses_pg, key, self.scatter_idx, self.gather_idx,
-                                        self.use_sync)
-        value_layer = SeqAllToAll4D.apply(self.ulysses_pg, value, self.scatter_idx, self.gather_idx,
-                                          self.use_sync)
-        out = self.ring_attn_fn(
-            query_layer, key_layer, value_layer, dropout_p=dropout_p, softmax_scale=softmax_scale,
-            causal=causal, window_size=window_size, softcap=softcap, alibi_slopes=alibi_slopes,
-            deterministic=deterministic, return_attn_probs=return_attn_probs, group=self.ring_pg,
-            attn_type=self.attn_type, attn_processor=self.attn_processor)
-        if type(out) == tuple:
-            context_layer, _, _ = out
-        else:
-            context_layer = out
-        # (bs, seq_len, head_cnt/N, head_size) -> (bs, seq_len/N, head_cnt, head_size)
-        output = SeqAllToAll4D.apply(self.ulysses_pg, context_layer, self.gather_idx,
-                                     self.scatter_idx, self.use_sync)
-        return output
+        # sequence shards -> head shards: (bs, seq_len/N, heads, d) -> (bs, seq_len, heads/N, d)
+        q, k, v = (SeqAllToAll4D.apply(self.ulysses_pg, t, self.scatter_idx, self.gather_idx, self.use_sync)
+                   for t in (query, key, value))
+        options = self._ring_options(dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                                     deterministic, return_attn_probs)
+        context = _first(self.ring_attn_fn(q, k, v, attn_processor=self.attn_processor, **options))
+        # ... and back: (bs, seq_len, heads/N, d) -> (bs, seq_len/N, heads, d)
+        return SeqAllToAll4D.apply(self.ulysses_pg, context, self.gather_idx, self.scatter_idx, self.use_sync)
 
 
-class LongContextAttentionQKVPacked(torch.nn.Module):
+class LongContextAttentionQKVPacked(_USPLayer):
     """Same surface as yunchang/hybrid/attn_layer.py:164-259: packed
     qkv (bs, seq_len/N, 3, head_cnt, head_size) -> ONE head all-to-all (instead of three) -> ring
     attention on the packed views -> all-to-all of the output back.  Equal head counts only
@@ -114,31 +114,19 @@ class LongContextAttentionQKVPacked(torch.nn.Module):
 
     def __init__(self, scatter_idx: int = 3, gather_idx: int = 1, ring_impl_type: str = "basic",
                  use_sync: bool = False, attn_type: AttnType = AttnType.FA) -> None:
-        super(LongContextAttentionQKVPacked, self).__init__()
-        self.ring_pg = PROCESS_GROUP.RING_PG
-        self.ulysses_pg = PROCESS_GROUP.ULYSSES_PG
-        assert (
-            self.ulysses_pg is not None or self.ring_pg is not None
-        ), f"use set_seq_parallel_pg() first. Now ulysses pg {self.ulysses_pg} and ring pg {self.ring_pg}"
-        self.scatter_idx = scatter_idx
-        self.gather_idx = gather_idx
-        self.use_sync = use_sync
+        super().__init__(scatter_idx, gather_idx, use_sync, attn_type)
         self.ring_attn_fn = RING_IMPL_QKVPACKED_DICT[ring_impl_type]
-        self.attn_type = attn_type
 
     def forward(self, qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
                 softcap=0.0, alibi_slopes=None, deterministic=False, return_attn_probs=False,
                 *args: Any) -> Tensor:
-        world_size = dist.get_world_size(self.ulysses_pg)
-        if world_size > 1:   # scatter 3 (heads), gather 1 (sequence)
+        exchange = dist.get_world_size(self.ulysses_pg) > 1
+        if exchange:         # scatter 3 (heads), gather 1 (sequence)
             qkv = SeqAllToAll5D.apply(self.ulysses_pg, qkv, self.scatter_idx, self.gather_idx, self.use_sync)
-        out = self.ring_attn_fn(qkv, dropout_p=dropout_p, softmax_scale=softmax_scale, causal=causal,
-                                window_size=window_size, softcap=softcap, alibi_slopes=alibi_slopes,
-                                deterministic=deterministic, return_attn_probs=return_attn_probs,
-                                group=self.ring_pg, attn_type=self.attn_type)
-        if type(out) == tuple:
-            out = out[0]
-        if world_size > 1:   # (bs, seq_len, head_cnt/N, head_size) -> (bs, seq_len/N, head_cnt, head_size)
+        out = _first(self.ring_attn_fn(qkv, **self._ring_options(dropout_p, softmax_scale, causal, window_size,
+                                                                  softcap, alibi_slopes, deterministic,
+                                                                  return_attn_probs)))
+        if exchange:         # (bs, seq_len, head_cnt/N, head_size) -> (bs, seq_len/N, head_cnt, head_size)
             out = SeqAllToAll4D.apply(self.ulysses_pg, out, self.gather_idx, self.scatter_idx - 1,
                                       self.use_sync)
         return out

@@ -1,38 +1,20 @@
-from .ring_flash_attn import (
-    ring_flash_attn_func,
-    ring_flash_attn_kvpacked_func,
-    ring_flash_attn_qkvpacked_func,
-)
-from .zigzag_ring_flash_attn import (
-    zigzag_ring_flash_attn_func,
-    zigzag_ring_flash_attn_kvpacked_func,
-    zigzag_ring_flash_attn_qkvpacked_func,
-)
-from .stripe_flash_attn import (
-    stripe_flash_attn_func,
-    stripe_flash_attn_kvpacked_func,
-    stripe_flash_attn_qkvpacked_func,
-)
-from .ring_flash_attn_varlen import (
-    ring_flash_attn_varlen_func,
-    ring_flash_attn_varlen_kvpacked_func,
-    ring_flash_attn_varlen_qkvpacked_func,
-)
-from .zigzag_ring_flash_attn_varlen import (
-    zigzag_ring_flash_attn_varlen_func,
-    zigzag_ring_flash_attn_varlen_kvpacked_func,
-    zigzag_ring_flash_attn_varlen_qkvpacked_func,
-)
-from .varlen_utils import extract_local_varlen, flatten_lse, unflatten_lse
-from .utils import RingComm, KVRelay, update_out_and_lse
+"""Ring attention schedules (yunchang.ring): contiguous ("basic"), zigzag and stripe layouts, dense and packed
+variable-length, each as *_func / *_kvpacked_func / *_qkvpacked_func, plus the ring plumbing."""
+from . import (ring_flash_attn, ring_flash_attn_varlen, stripe_flash_attn, utils, varlen_utils,
+               zigzag_ring_flash_attn, zigzag_ring_flash_attn_varlen)
 
-__all__ = [
-    "ring_flash_attn_func", "ring_flash_attn_kvpacked_func", "ring_flash_attn_qkvpacked_func",
-    "zigzag_ring_flash_attn_func", "zigzag_ring_flash_attn_kvpacked_func",
-    "zigzag_ring_flash_attn_qkvpacked_func", "stripe_flash_attn_func",
-    "stripe_flash_attn_kvpacked_func", "stripe_flash_attn_qkvpacked_func", "RingComm", "KVRelay",
-    "update_out_and_lse", "ring_flash_attn_varlen_func", "ring_flash_attn_varlen_kvpacked_func",
-    "ring_flash_attn_varlen_qkvpacked_func", "zigzag_ring_flash_attn_varlen_func",
-    "zigzag_ring_flash_attn_varlen_kvpacked_func", "zigzag_ring_flash_attn_varlen_qkvpacked_func",
-    "extract_local_varlen", "flatten_lse", "unflatten_lse",
-]
+__all__ = []
+
+
+def _export(module, names):
+    for name in names:
+        globals()[name] = getattr(module, name)
+        __all__.append(name)
+
+
+for _module, _stem in ((ring_flash_attn, "ring_flash_attn"), (zigzag_ring_flash_attn, "zigzag_ring_flash_attn"),
+                       (stripe_flash_attn, "stripe_flash_attn"), (ring_flash_attn_varlen, "ring_flash_attn_varlen"),
+                       (zigzag_ring_flash_attn_varlen, "zigzag_ring_flash_attn_varlen")):
+    _export(_module, [f"{_stem}{suffix}" for suffix in ("_func", "_kvpacked_func", "_qkvpacked_func")])
+_export(utils, ["RingComm", "KVRelay", "update_out_and_lse"])
+_export(varlen_utils, ["extract_local_varlen", "flatten_lse", "unflatten_lse"])
