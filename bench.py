@@ -279,6 +279,9 @@ class _NoCompute:
     """comm-only run: every kernel of the block backend is skipped (buffers stay uninitialised)."""
     name = "none"
 
+    def beside_transfers(self):
+        return self
+
     def __getattr__(self, _):
         return lambda *a, **k: None
 

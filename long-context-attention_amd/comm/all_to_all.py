@@ -66,26 +66,46 @@ def pack_heads(x: Tensor, P: int) -> Tensor:
     return send
 
 
-def pack_head_group(x5: Tensor) -> Tensor:
+def pack_head_group(x5: Tensor, send: Tensor = None, h0: int = 0) -> Tensor:
     """x5: a (B, S/P, P, h, D) VIEW (any strides on the first three dims, (h, D) contiguous) selecting
-    h heads per destination rank -> send buffer (P, S/P, B, h, D).  Used by the head-group pipeline."""
+    h heads per destination rank -> heads [h0, h0+h) of the send buffer (P, S/P, B, Ht, D) (allocated with
+    Ht = h when not given).  Used by the head-group pipeline; q, k and v of a group share ONE send buffer
+    (Ht = hq + 2 hkv per rank and group), i.e. one collective instead of three."""
     B, Sl, P, h, D = x5.shape
     assert x5.stride(4) == 1 and x5.stride(3) == D
-    send = torch.empty((P, Sl, B, h, D), dtype=x5.dtype, device=x5.device)
+    if send is None:
+        send = torch.empty((P, Sl, B, h, D), dtype=x5.dtype, device=x5.device)
+    Ht = send.shape[3]
+    assert send.shape == (P, Sl, B, Ht, D) and send.is_contiguous() and h0 + h <= Ht
     base = x5.as_strided((1,), (1,), x5.storage_offset())          # element pointer of the view
-    _copy_rows(send, base, h * D, (P, Sl, B), (Sl * B * h * D, B * h * D, h * D),
+    dst = send.as_strided((1,), (1,), send.storage_offset() + h0 * D)
+    _copy_rows(dst, base, h * D, (P, Sl, B), (Sl * B * Ht * D, B * Ht * D, Ht * D),
                (x5.stride(2), x5.stride(1), x5.stride(0)))
     return send
 
 
-def unpack_head_group(recv: Tensor, dst5: Tensor) -> None:
-    """receive buffer (P, S/P, B, h, D) [chunk p = head group of rank p] -> dst5, a (B, S/P, P, h, D)
-    VIEW into the full (B, S/P, H, D) result."""
-    P, Sl, B, h, D = recv.shape
-    assert dst5.stride(4) == 1 and dst5.stride(3) == D
+def unpack_head_group(recv: Tensor, dst5: Tensor, h0: int = 0) -> None:
+    """heads [h0, h0+h) of the receive buffer (P, S/P, B, Ht, D) [chunk p = head group of rank p] -> dst5, a
+    (B, S/P, P, h, D) VIEW into the full (B, S/P, H, D) result."""
+    P, Sl, B, Ht, D = recv.shape
+    h = dst5.shape[3]
+    assert dst5.stride(4) == 1 and dst5.stride(3) == D and h0 + h <= Ht
     base = dst5.as_strided((1,), (1,), dst5.storage_offset())
-    _copy_rows(base, recv, h * D, (P, Sl, B), (dst5.stride(2), dst5.stride(1), dst5.stride(0)),
-               (Sl * B * h * D, B * h * D, h * D))
+    src = recv.as_strided((1,), (1,), recv.storage_offset() + h0 * D)
+    _copy_rows(base, src, h * D, (P, Sl, B), (dst5.stride(2), dst5.stride(1), dst5.stride(0)),
+               (Sl * B * Ht * D, B * Ht * D, Ht * D))
+
+
+def pack_seq_into(send: Tensor, h0: int, x: Tensor) -> None:
+    """(B, S, h, D) -> heads [h0, h0+h) of the sequence-scatter send buffer (P, S/P, B, Ht, D)."""
+    P, Sl, B, Ht, D = send.shape
+    h = x.shape[2]
+    assert x.shape == (B, P * Sl, h, D) and h0 + h <= Ht and send.is_contiguous()
+    if x.stride(3) != 1 or x.stride(2) != D:
+        x = x.contiguous()
+    dst = send.as_strided((1,), (1,), send.storage_offset() + h0 * D)
+    base = x.as_strided((1,), (1,), x.storage_offset())
+    _copy_rows(dst, base, h * D, (P * Sl, B), (B * Ht * D, Ht * D), (x.stride(1), x.stride(0)))
 
 
 def view_seq(recv: Tensor) -> Tensor:

@@ -129,6 +129,10 @@ USP_DEV void pin_agpr(f32x16& acc) {
 #endif
 }
 
+// The value must have been computed by this point of the instruction stream (an opaque use: no instruction is
+// emitted).  Keeps pure arithmetic from being sunk across basic blocks into the block of its first real use.
+USP_DEV void pin_here(uint32_t& w) { asm volatile("" : "+v"(w)); }
+
 USP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 // Persistent workgroups: a launch has min(items, resident workgroup slots) workgroups and each walks a

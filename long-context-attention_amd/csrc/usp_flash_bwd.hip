@@ -390,8 +390,16 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 #endif
         float pr, ds;
         if (MODE == 0) {
+#if defined(USP_ABLATE_NOTRANS)      // A/B builds: what does the transcendental cost / what do the two dS operations cost
+          pr = __builtin_fmaf(sS[h][r], c, -lse2_l);
+#else
           pr = fast_exp2(__builtin_fmaf(sS[h][r], c, -lse2_l));
+#endif
+#if defined(USP_ABLATE_NODS)
+          ds = sT[h][r];
+#else
           ds = pr * (sT[h][r] - delta_l);
+#endif
         } else {
           if ((r & 3) == 0) load_stats(h, r >> 2);
           pr = fast_exp2(__builtin_fmaf(sS[h][r], c, -stl[r & 3]));
@@ -400,8 +408,17 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
         sS[h][r] = pr;
         sT[h][r] = ds;
         if (r & 1) {
-          pk_ds[h][r >> 3][(r & 7) >> 1] = E::pack2(sT[h][r - 1], sT[h][r]);
-          if (MODE == 1) pk_p[h][r >> 3][(r & 7) >> 1] = E::pack2(sS[h][r - 1], sS[h][r]);
+          // pin_here: hipcc otherwise SINKS the whole element block of half 0 out of the S/T phase it is meant to
+          // hide behind, into the block of its first use (the gradient phase) -- ~110 VALU in front of the
+          // first gradient MFMA (seen in the .s; sched_barrier only pins the machine scheduler inside a block)
+          uint32_t w = E::pack2(sT[h][r - 1], sT[h][r]);
+          pin_here(w);
+          pk_ds[h][r >> 3][(r & 7) >> 1] = w;
+          if (MODE == 1) {
+            uint32_t wp = E::pack2(sS[h][r - 1], sS[h][r]);
+            pin_here(wp);
+            pk_p[h][r >> 3][(r & 7) >> 1] = wp;
+          }
         }
       };
       // S/T phase of half h; `vh` >= 0: interleave the element work of half vh

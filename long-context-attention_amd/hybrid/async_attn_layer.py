@@ -34,16 +34,15 @@ _RING_FWD_BWD = {
 
 
 class _Lane:
-    """The side stream the exchanges run on (no-op on host tensors: gloo tests)."""
+    """The side stream the Ulysses exchanges run on (no-op on host tensors: gloo tests).  Its own lane
+    (`_side_stream(device, "ulysses")`): a ring hop queued by KVRelay never waits behind the exchanges of
+    later head groups."""
 
     def __init__(self, ref: Tensor):
         self.cuda = ref.is_cuda
-        # the exchanges are meant to run beside the attention kernels (see KVRelay)
-        from ..kernels.attention import overlapping_transfers
-        self._overlap = overlapping_transfers().begin()
         if self.cuda:
             self.main = torch.cuda.current_stream()
-            self.side = _side_stream(ref.device)
+            self.side = _side_stream(ref.device, "ulysses")
 
     def exchange(self, send: Tensor, group) -> tuple:
         """Queue all_to_all_single(send) behind everything currently on the main stream; returns
@@ -68,9 +67,13 @@ class _Lane:
     def finish(self):
         if self.cuda:
             torch.cuda.current_stream().wait_stream(self.side)
-        if self._overlap is not None:
-            self._overlap.end()
-            self._overlap = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.finish()
+        return False
 
 
 _MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer workgroups per launch)
@@ -79,7 +82,7 @@ _MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer 
 _FILL_ITEMS = 256   # 256-row work items that give every CU of an MI355X one item
 
 
-def _groups(Hq, Hkv, P, B=None, S=None):
+def _groups(Hq, Hkv, P, B=None, S=None, max_groups=None):
     """(number of head groups, kv heads per rank per group, query heads per kv head).  A group is a
     set of whole KV heads (with their query heads) of every rank's post-exchange share.  With the problem
     size (B, S = full sequence) given, the pipeline is kept shallow enough that every group's attention
@@ -88,7 +91,7 @@ def _groups(Hq, Hkv, P, B=None, S=None):
     per_rank = Hkv // P
     ng = 1
     if P > 1:                       # nothing to hide without an exchange
-        cap = _MAX_GROUPS
+        cap = _MAX_GROUPS if max_groups is None else min(_MAX_GROUPS, max_groups)
         if B is not None and S is not None:
             cap = max(1, min(cap, (B * (Hq // P) * ((S + 255) // 256)) // _FILL_ITEMS))
         for cand in range(min(cap, per_rank), 0, -1):
@@ -96,6 +99,26 @@ def _groups(Hq, Hkv, P, B=None, S=None):
                 ng = cand
                 break
     return ng, per_rank // ng, Hq // Hkv
+
+
+def _qkv_to_seq(lane, q, k, v, P, ng, kvh, g, i, group):
+    """ONE exchange for head group i of q, k and v (B, S/P, H{q,kv}, D): the send buffer is
+    (P, S/P, B, kvh*g + 2*kvh, D) = [q heads | k heads | v heads] of (destination rank, group i) -- the
+    GQA-capable form of the reference's packed exchange (async_attn_layer.py:100-128 stacks q|k|v of one head
+    per rank, which needs Hkv == Hq).  Returns ((q, k, v) as (B, S, h, D) strided views of the receive buffer,
+    event)."""
+    hq = kvh * g
+    send = None
+    for x, h, h0 in ((q, hq, 0), (k, kvh, hq), (v, kvh, hq + kvh)):
+        B, Sl, _, D = x.shape
+        if x.stride(3) != 1 or x.stride(2) != D:
+            x = x.contiguous()
+        if send is None:
+            send = torch.empty((P, Sl, B, hq + 2 * kvh, D), dtype=x.dtype, device=x.device)
+        A.pack_head_group(x.view(B, Sl, P, ng, h, D)[:, :, :, i], send, h0)    # heads p*(ng*h) + i*h + (0..h)
+    recv, ev = lane.exchange(send, group)
+    full = A.view_seq(recv)                                        # (B, S, hq + 2 kvh, D)
+    return (full[:, :, :hq], full[:, :, hq:hq + kvh], full[:, :, hq + kvh:]), ev
 
 
 def _to_seq(lane, x, P, ng, h, i, group):
@@ -108,40 +131,50 @@ def _to_seq(lane, x, P, ng, h, i, group):
     return A.view_seq(recv), ev
 
 
-def _to_heads_issue(lane, x, P, group):
-    """Queue the exchange of (B, S, h, D) back to sequence sharding; returns (recv, event)."""
-    return lane.exchange(A.pack_seq(x, P), group)
+def _to_heads_issue(lane, xs, P, group):
+    """Queue ONE exchange of the (B, S, h_j, D) tensors `xs` back to sequence sharding (heads stacked in one
+    send buffer); returns (recv (P, S/P, B, sum h_j, D), event)."""
+    if len(xs) == 1:
+        return lane.exchange(A.pack_seq(xs[0], P), group)
+    B, S, _, D = xs[0].shape
+    Ht = sum(x.shape[2] for x in xs)
+    send = torch.empty((P, S // P, B, Ht, D), dtype=xs[0].dtype, device=xs[0].device)
+    h0 = 0
+    for x in xs:
+        A.pack_seq_into(send, h0, x)
+        h0 += x.shape[2]
+    return lane.exchange(send, group)
 
 
 class _AsyncUSPFunc(torch.autograd.Function):
+    """forward/backward of the USP layer with packed, optionally pipelined exchanges.  `ng_cap` = 1 keeps the
+    sequential order (one packed exchange in, attention, one exchange out)."""
+
     @staticmethod
-    def forward(ctx, q, k, v, softmax_scale, causal, ulysses_pg, ring_pg, impl):
+    def forward(ctx, q, k, v, softmax_scale, causal, ulysses_pg, ring_pg, impl, ng_cap=None):
         fwd, _ = _RING_FWD_BWD[impl]
         P = dist.get_world_size(ulysses_pg)
         B, Sl, Hq, D = q.shape
         Hkv = k.shape[2]
-        ng, kvh, g = _groups(Hq, Hkv, P, B, Sl * P)
+        ng, kvh, g = _groups(Hq, Hkv, P, B, Sl * P, max_groups=ng_cap)
         if softmax_scale is None:
             softmax_scale = D ** (-0.5)
-        lane = _Lane(q)
-        ins = []
-        for i in range(ng):          # every input exchange is queued before any attention runs
-            ins.append((_to_seq(lane, q, P, ng, kvh * g, i, ulysses_pg),
-                        _to_seq(lane, k, P, ng, kvh, i, ulysses_pg), _to_seq(lane, v, P, ng, kvh, i, ulysses_pg)))
+        overlap = ng > 1                # kernels run beside later groups' exchanges
         saved, outs = [], []
-        for i in range(ng):
-            (qi, eq), (ki, ek), (vi, evv) = ins[i]
-            for e in (eq, ek, evv):
-                lane.wait(e)
-            oi, lse_i = fwd(ring_pg, qi, ki, vi, softmax_scale=softmax_scale, causal=causal)
-            saved += [qi, ki, vi, oi, lse_i]
-            outs.append(_to_heads_issue(lane, oi, P, ulysses_pg))
-        out = torch.empty((B, Sl, Hq, D), dtype=q.dtype, device=q.device)
-        o5 = out.view(B, Sl, P, ng, kvh * g, D)
-        for i, (recv, ev) in enumerate(outs):
-            lane.wait(ev)
-            A.unpack_head_group(recv, o5[:, :, :, i])
-        lane.finish()
+        with _Lane(q) as lane:
+            # every input exchange is queued before any attention runs
+            ins = [_qkv_to_seq(lane, q, k, v, P, ng, kvh, g, i, ulysses_pg) for i in range(ng)]
+            for i in range(ng):
+                (qi, ki, vi), ev = ins[i]
+                lane.wait(ev)
+                oi, lse_i = fwd(ring_pg, qi, ki, vi, softmax_scale=softmax_scale, causal=causal, overlap=overlap)
+                saved += [qi, ki, vi, oi, lse_i]
+                outs.append(_to_heads_issue(lane, [oi], P, ulysses_pg))
+            out = torch.empty((B, Sl, Hq, D), dtype=q.dtype, device=q.device)
+            o5 = out.view(B, Sl, P, ng, kvh * g, D)
+            for i, (recv, ev) in enumerate(outs):
+                lane.wait(ev)
+                A.unpack_head_group(recv, o5[:, :, :, i])
         ctx.save_for_backward(*saved)
         ctx.meta = (softmax_scale, causal, ulysses_pg, ring_pg, impl, P, ng, kvh, g, Hq, Hkv)
         return out
@@ -152,29 +185,29 @@ class _AsyncUSPFunc(torch.autograd.Function):
         _, bwd = _RING_FWD_BWD[impl]
         saved = ctx.saved_tensors
         B, Sl, _, D = dout.shape
-        lane = _Lane(dout)
-        douts = [_to_seq(lane, dout, P, ng, kvh * g, i, ulysses_pg) for i in range(ng)]
-        pend = []
-        for i in range(ng):
-            qi, ki, vi, oi, lse_i = saved[5 * i:5 * i + 5]
-            doi, ev = douts[i]
-            lane.wait(ev)
-            dqi, dki, dvi = bwd(ring_pg, doi, qi, ki, vi, oi, lse_i, softmax_scale=softmax_scale, causal=causal)
-            pend.append((_to_heads_issue(lane, dqi, P, ulysses_pg), _to_heads_issue(lane, dki, P, ulysses_pg),
-                         _to_heads_issue(lane, dvi, P, ulysses_pg)))
-        dq = torch.empty((B, Sl, Hq, D), dtype=dout.dtype, device=dout.device)
-        dk = torch.empty((B, Sl, Hkv, D), dtype=dout.dtype, device=dout.device)
-        dv = torch.empty_like(dk)
-        q5 = dq.view(B, Sl, P, ng, kvh * g, D)
-        k5, v5 = dk.view(B, Sl, P, ng, kvh, D), dv.view(B, Sl, P, ng, kvh, D)
-        for i, ((rq, e1), (rk, e2), (rv, e3)) in enumerate(pend):
-            for e in (e1, e2, e3):
-                lane.wait(e)
-            A.unpack_head_group(rq, q5[:, :, :, i])
-            A.unpack_head_group(rk, k5[:, :, :, i])
-            A.unpack_head_group(rv, v5[:, :, :, i])
-        lane.finish()
-        return dq, dk, dv, None, None, None, None, None
+        overlap = ng > 1
+        with _Lane(dout) as lane:
+            douts = [_to_seq(lane, dout, P, ng, kvh * g, i, ulysses_pg) for i in range(ng)]
+            pend = []
+            for i in range(ng):
+                qi, ki, vi, oi, lse_i = saved[5 * i:5 * i + 5]
+                doi, ev = douts[i]
+                lane.wait(ev)
+                dqi, dki, dvi = bwd(ring_pg, doi, qi, ki, vi, oi, lse_i, softmax_scale=softmax_scale,
+                                    causal=causal, overlap=overlap)
+                pend.append(_to_heads_issue(lane, [dqi, dki, dvi], P, ulysses_pg))   # ONE exchange: dq | dk | dv
+            dq = torch.empty((B, Sl, Hq, D), dtype=dout.dtype, device=dout.device)
+            dk = torch.empty((B, Sl, Hkv, D), dtype=dout.dtype, device=dout.device)
+            dv = torch.empty_like(dk)
+            q5 = dq.view(B, Sl, P, ng, kvh * g, D)
+            k5, v5 = dk.view(B, Sl, P, ng, kvh, D), dv.view(B, Sl, P, ng, kvh, D)
+            hq = kvh * g
+            for i, (recv, ev) in enumerate(pend):
+                lane.wait(ev)
+                A.unpack_head_group(recv, q5[:, :, :, i], 0)
+                A.unpack_head_group(recv, k5[:, :, :, i], hq)
+                A.unpack_head_group(recv, v5[:, :, :, i], hq + kvh)
+        return dq, dk, dv, None, None, None, None, None, None
 
 
 class AsyncLongContextAttention(torch.nn.Module):

@@ -3,9 +3,9 @@
 forward = Ulysses head all-to-all of q, k, v (attn_layer.py:111-119) -> ring attention over the
 ring group (:132-147) -> all-to-all of the output back to sequence sharding (:156-158).
 
-MI355X-first: where the exchange is the only communication (ulysses degree > 1, ring degree 1) it is
-pipelined over head groups behind the attention instead of running exposed in front of and behind it
-(LongContextAttention._pipelined_exchange); results are identical.
+MI355X-first: q, k and v travel in ONE packed head all-to-all (GQA-capable), and the exchanges are pipelined over
+head groups on a side HIP stream behind the attention kernels instead of running exposed in front of and behind
+them (LongContextAttention._packed_exchange); results are identical.
 """
 import os
 from typing import Any
@@ -18,7 +18,7 @@ from ..comm.all_to_all import SeqAllToAll4D, SeqAllToAll5D
 from ..globals import PROCESS_GROUP
 from ..kernels import AttnType
 from ..ring.zigzag_ring_flash_attn import _check_hot_path_args
-from .async_attn_layer import _AsyncUSPFunc, _RING_FWD_BWD, _groups
+from .async_attn_layer import _AsyncUSPFunc, _MAX_GROUPS, _RING_FWD_BWD
 from .utils import RING_IMPL_DICT, RING_IMPL_QKVPACKED_DICT
 
 
@@ -50,11 +50,17 @@ class LongContextAttention(_USPLayer):
     """Unified sequence parallel attention (ulysses x ring), arguments as in the reference:
         scatter_idx / gather_idx (int): dims of the all-to-all (2 = heads, 1 = sequence)
         ring_impl_type (str): key of RING_IMPL_DICT ("basic" | "zigzag" | "strip")
-        use_pack_qkv (bool): accepted for compatibility; q, k, v are always exchanged separately
-            (the reference's packed branch is dead code: `.continous()` typo at attn_layer.py:88,
-            and it cannot express GQA)
-        use_sync (bool): synchronise the device after each all-to-all
+        use_pack_qkv (bool): q, k and v travel in ONE head all-to-all instead of three.  This layer ALWAYS
+            packs (GQA-capable buffer (P, S/P, B, hq + 2 hkv, D), hybrid/async_attn_layer.py:_qkv_to_seq) --
+            the flag is accepted and changes nothing; results are identical either way.  (The reference's
+            packed branch is dead code: `.continous()` typo at attn_layer.py:88, and it cannot express GQA.)
+            USP_PACK_QKV=0 restores the reference's three-exchange structure (an A/B switch for multi-GPU
+            measurements).
+        use_sync (bool): synchronise the device after each all-to-all (three blocking exchanges, as the
+            reference)
         attn_type (AttnType): any dense type; all are served by the gfx950 kernel
+    Beside packing, the exchange is PIPELINED over head groups on a side HIP stream behind the attention
+    kernels whenever there is more than one group to pipeline (USP_PIPELINE_ULYSSES=0 disables it).
     """
 
     def __init__(self, scatter_idx: int = 2, gather_idx: int = 1, ring_impl_type: str = "basic",
@@ -66,36 +72,32 @@ class LongContextAttention(_USPLayer):
         self.ring_attn_fn = RING_IMPL_DICT[ring_impl_type]
         self.ring_impl_type = ring_impl_type
 
-    def _pipelined_exchange(self, query: Tensor, key: Tensor) -> bool:
-        """Hide the Ulysses exchange behind the attention by pipelining over head groups (the
-        AsyncLongContextAttention schedule, hybrid/async_attn_layer.py; identical results)?  Automatic only
-        where it involves ONE communicator -- ulysses degree > 1 with ring degree 1, where the exchange is the
-        whole communication and the sequential layer leaves all of it exposed -- and when there is more than
-        one head group to pipeline.  USP_PIPELINE_ULYSSES=0 disables it, =1 also enables it beside a ring."""
-        mode = os.environ.get("USP_PIPELINE_ULYSSES", "auto")
-        if mode == "0" or not query.is_cuda or self.use_sync or self.attn_processor is not None:
-            return False
+    def _packed_exchange(self, query: Tensor, key: Tensor):
+        """None: exchange q, k, v separately (the reference's structure); otherwise the cap on the number of
+        head groups of the packed exchange (1 = one packed exchange in front of the attention and one behind
+        it; more = pipelined over head groups on the side stream, hybrid/async_attn_layer.py -- identical
+        results).  Pipelining is the default also beside a ring (two communicators in flight, each on its own
+        side stream); USP_PIPELINE_ULYSSES=0 keeps the exchange sequential."""
+        if os.environ.get("USP_PACK_QKV", "1") == "0" or self.use_sync or self.attn_processor is not None:
+            return None
         if (self.scatter_idx, self.gather_idx) != (2, 1) or self.ring_impl_type not in _RING_FWD_BWD:
-            return False
+            return None
         P = dist.get_world_size(self.ulysses_pg)
-        if P == 1 or (mode != "1" and dist.get_world_size(self.ring_pg) > 1):
-            return False
-        B, Sl, Hq, _ = query.shape
-        Hkv = key.shape[2]
-        if Hq % P or Hkv % P:
-            return False
-        return _groups(Hq, Hkv, P, B, Sl * P)[0] > 1
+        if P == 1 or query.shape[2] % P or key.shape[2] % P:
+            return None
+        return 1 if os.environ.get("USP_PIPELINE_ULYSSES", "auto") == "0" else _MAX_GROUPS
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, dropout_p=0.0, softmax_scale=None,
                 causal=False, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
                 deterministic=False, return_attn_probs=False, *args: Any) -> Tensor:
         """query (bs, seq_len/N, head_cnt, head_size); key/value (bs, seq_len/N, kv_head_cnt,
         head_size) -> context (bs, seq_len/N, head_cnt, head_size)."""
-        if self._pipelined_exchange(query, key):
+        ng_cap = self._packed_exchange(query, key)
+        if ng_cap is not None:
             assert alibi_slopes is None
             _check_hot_path_args(dropout_p, window_size, softcap)
             return _AsyncUSPFunc.apply(query, key, value, softmax_scale, causal, self.ulysses_pg, self.ring_pg,
-                                       self.ring_impl_type)
+                                       self.ring_impl_type, ng_cap)
         # sequence shards -> head shards: (bs, seq_len/N, heads, d) -> (bs, seq_len, heads/N, d)
         q, k, v = (SeqAllToAll4D.apply(self.ulysses_pg, t, self.scatter_idx, self.gather_idx, self.use_sync)
                    for t in (query, key, value))

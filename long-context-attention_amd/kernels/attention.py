@@ -17,18 +17,29 @@ from .. import _C
 
 
 class HipBlockBackend:
-    """The device backend: thin adapter over the C ABI (include/usp_hip.h)."""
+    """The device backend: thin adapter over the C ABI (include/usp_hip.h).  Immutable: `interleave` is fixed
+    at construction, so concurrent callers (the autograd thread running one layer's backward while the main
+    thread runs another layer's forward) cannot disturb each other's launch mode."""
 
     name = "hip"
-    # > 0 while a transfer is meant to overlap the kernels (KVRelay with ring degree > 1, the pipelined
-    # Ulysses exchange): launches then carry USP_LAUNCH_INTERLEAVE (include/usp_hip.h) so that RCCL's
-    # kernels can become resident beside them; otherwise the kernels run persistent (fastest alone).
-    overlap_depth = 0
+
+    def __init__(self, interleave: bool = False):
+        # True: every flash launch carries USP_LAUNCH_INTERLEAVE (include/usp_hip.h) so that RCCL's kernels can
+        # become resident beside it; False: persistent launches (fastest when the GPU does nothing else).
+        self.interleave = bool(interleave)
+        self._beside = self if interleave else None
+
+    def beside_transfers(self) -> "HipBlockBackend":
+        """The same backend for launches that are meant to run beside transfers on other streams (ring
+        degree > 1, pipelined Ulysses exchange)."""
+        if self._beside is None:
+            self._beside = HipBlockBackend(interleave=True)
+        return self._beside
 
     def fwd(self, q, k, v, softmax_scale, causal, lse, out=None, acc=None, merge_in=False,
             final_begin=0, final_end=None):
         _C.flash_fwd(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end,
-                     interleave=self.overlap_depth > 0)
+                     interleave=self.interleave)
 
     def delta(self, dout, out, delta):
         _C.bwd_delta(dout, out, delta)
@@ -36,19 +47,19 @@ class HipBlockBackend:
     def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
             accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None):
         _C.flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq,
-                     accum_dk, accum_dv, dq16, dk16, dv16, interleave=self.overlap_depth > 0)
+                     accum_dk, accum_dv, dq16, dk16, dv16, interleave=self.interleave)
 
     def fwd_packed(self, q, k, v, seq_q, seq_k, max_q, max_k, softmax_scale, causal, lse, out=None,
                    acc=None, merge_in=False, final_begin=0, final_end=2):
         _C.flash_fwd_packed(q, k, v, seq_q, seq_k, max_q, max_k, softmax_scale, causal, lse, out, acc,
-                            merge_in, final_begin, final_end, interleave=self.overlap_depth > 0)
+                            merge_in, final_begin, final_end, interleave=self.interleave)
 
     def bwd_packed(self, dout, q, k, v, lse, delta, seq_q, seq_k, max_q, max_k, dq, dk, dv,
                    softmax_scale, causal, accum_dq=False, accum_dk=False, accum_dv=False, dq16=None,
                    dk16=None, dv16=None):
         _C.flash_bwd_packed(dout, q, k, v, lse, delta, seq_q, seq_k, max_q, max_k, dq, dk, dv,
                             softmax_scale, causal, accum_dq, accum_dk, accum_dv, dq16, dk16, dv16,
-                            interleave=self.overlap_depth > 0)
+                            interleave=self.interleave)
 
     def merge(self, acc, lse, blk_out, blk_lse, first):
         _C.lse_merge(acc, lse, blk_out, blk_lse, first)
@@ -66,33 +77,14 @@ class HipBlockBackend:
 _BACKEND = HipBlockBackend()
 
 
-def get_block_backend():
-    return _BACKEND
-
-
-class overlapping_transfers:
-    """Context / begin-end pair: kernels launched inside are meant to run beside transfers on other streams."""
-
-    def __init__(self):
-        self.be = None
-
-    def begin(self):
-        be = get_block_backend()
-        self.be = be if isinstance(getattr(be, "overlap_depth", None), int) else None   # test backends: no-op
-        if self.be is not None:
-            self.be.overlap_depth += 1
-        return self
-
-    def end(self):
-        if self.be is not None:
-            self.be.overlap_depth -= 1
-        self.be = None
-
-    __enter__ = begin
-
-    def __exit__(self, *a):
-        self.end()
-        return False
+def get_block_backend(beside_transfers: bool = False):
+    """The block backend; `beside_transfers=True` asks for launches that leave room for collectives queued on
+    other streams (a persistent flash launch holds every CU until it ends: DESIGN.md section 5).  Test
+    backends without that notion are returned as they are."""
+    be = _BACKEND
+    if beside_transfers and hasattr(be, "beside_transfers"):
+        return be.beside_transfers()
+    return be
 
 
 def set_block_backend(backend):

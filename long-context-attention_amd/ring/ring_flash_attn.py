@@ -11,8 +11,8 @@ import torch.distributed as dist
 
 from ..kernels import AttnType
 from ..kernels.attention import get_block_backend
-from .utils import KVRelay, RingComm
-from .zigzag_ring_flash_attn import _cast, _check_hot_path_args
+from .utils import KVRelay, final_grads, travel_dkdv
+from .zigzag_ring_flash_attn import _check_hot_path_args
 
 
 
@@ -38,81 +38,51 @@ def basic_bwd_block(be, r, P, step, causal, dout, q, kk, vv, lse, delta, softmax
 
 def ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, causal=True,
                             window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
-                            attn_type: AttnType = AttnType.HIP, attn_processor=None):
-    be = get_block_backend()
+                            attn_type: AttnType = AttnType.HIP, attn_processor=None, overlap=False):
     P = dist.get_world_size(process_group)
     r = dist.get_rank(process_group)
+    be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S, H, D = q.shape
     dev = q.device
     out = torch.empty((B, S, H, D), dtype=q.dtype, device=dev)
     lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
     last_compute = r if causal else P - 1
     acc = torch.empty((B, S, H, D), dtype=torch.float32, device=dev) if last_compute > 0 else None
-
-    relay = KVRelay(process_group, k, v)
-    for step in range(P):
-        kk, vv = relay.get(step)
-        basic_fwd_step(be, r, P, step, causal, q, kk, vv, softmax_scale, lse, out, acc)
-    relay.finish()
+    with KVRelay(process_group, k, v) as relay:
+        for step in range(P):
+            kk, vv = relay.get(step)
+            basic_fwd_step(be, r, P, step, causal, q, kk, vv, softmax_scale, lse, out, acc)
     return out, lse
 
 
 def ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, softmax_scale,
                              dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
                              alibi_slopes=None, deterministic=False,
-                             attn_type: AttnType = AttnType.HIP):
-    be = get_block_backend()
+                             attn_type: AttnType = AttnType.HIP, overlap=False):
     P = dist.get_world_size(process_group)
     r = dist.get_rank(process_group)
+    be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S, H, D = q.shape
     dev = q.device
-    f32 = torch.float32
-    delta = torch.empty((B, H, S), dtype=f32, device=dev)
+    delta = torch.empty((B, H, S), dtype=torch.float32, device=dev)
     be.delta(dout, out, delta)
     if P == 1:   # one block: the kernels round the gradients to q.dtype in their epilogues
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         be.bwd(dout, q, k, v, softmax_lse, delta, None, None, None, softmax_scale, bool(causal),
                dq16=dq, dk16=dk, dv16=dv)
         return dq, dk, dv
-    dq_acc = torch.empty((B, S, H, D), dtype=f32, device=dev)
-    dk_blk = dv_blk = None
-    if P > 1:
-        dk_blk = torch.empty(k.shape, dtype=f32, device=dev)
-        dv_blk = torch.empty(v.shape, dtype=f32, device=dev)
+    dq_acc = torch.empty((B, S, H, D), dtype=torch.float32, device=dev)
 
-    relay = KVRelay(process_group, k, v)
-    d_comm = None
-    dk_acc = dv_acc = next_dk = next_dv = None
-    for step in range(P):
-        kk, vv = relay.get(step)
-        if step == 0:
-            dk_acc = torch.empty(k.shape, dtype=f32, device=dev)
-            dv_acc = torch.empty(v.shape, dtype=f32, device=dev)
-            basic_bwd_block(be, r, P, 0, causal, dout, q, kk, vv, softmax_lse, delta, softmax_scale,
-                            dq_acc, dk_acc, dv_acc)
-        else:
-            computed = basic_bwd_block(be, r, P, step, causal, dout, q, kk, vv, softmax_lse, delta,
-                                       softmax_scale, dq_acc, dk_blk, dv_blk)
-            d_comm.wait()
-            dk_acc, dv_acc = next_dk, next_dv
-            if computed:
-                be.add(dk_acc, dk_acc, dk_blk)
-                be.add(dv_acc, dv_acc, dv_blk)
-        if P > 1:
-            d_comm = RingComm(process_group)
-            next_dk = d_comm.send_recv(dk_acc)
-            next_dv = d_comm.send_recv(dv_acc)
-            d_comm.commit()
-    if P > 1:
-        d_comm.wait()
-        dk_acc, dv_acc = next_dk, next_dv
-    relay.finish()
+    def block(step, kk, vv, dk_dst, dv_dst):
+        return basic_bwd_block(be, r, P, step, causal, dout, q, kk, vv, softmax_lse, delta, softmax_scale,
+                               dq_acc, dk_dst, dv_dst)
 
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    _cast(be, dq, dq_acc)
-    _cast(be, dk, dk_acc)
-    _cast(be, dv, dv_acc)
-    return dq, dk, dv
+    def fold(step, dk_acc, dv_acc, dk_blk, dv_blk):
+        be.add(dk_acc, dk_acc, dk_blk)
+        be.add(dv_acc, dv_acc, dv_blk)
+
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold)
+    return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 
 
 class RingFlashAttnFunc(torch.autograd.Function):

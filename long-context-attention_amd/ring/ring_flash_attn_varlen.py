@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
-from .utils import KVRelay, RingComm
+from .utils import KVRelay, final_grads, travel_dkdv
 from .varlen_utils import SeqTables, unflatten_lse
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
@@ -39,20 +39,19 @@ def ring_flash_attn_varlen_forward(process_group, q, k, v, cu_seqlens, max_seqle
                                    dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
                                    alibi_slopes=None, deterministic=False):
     """Returns (out (T,H,D), lse (H,T) fp32)."""
-    be = get_block_backend()
     P = dist.get_world_size(process_group)
     r = dist.get_rank(process_group)
+    be = get_block_backend(beside_transfers=P > 1)
     T, H, D = q.shape
     tb = SeqTables(cu_seqlens, max_seqlen, q.device)
     out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((H, T), dtype=torch.float32, device=q.device)
     last_compute = r if causal else P - 1
     acc = torch.empty((T, H, D), dtype=torch.float32, device=q.device) if last_compute > 0 else None
-    relay = KVRelay(process_group, k, v)
-    for step in range(P):
-        kk, vv = relay.get(step)
-        basic_varlen_fwd_step(be, r, P, step, causal, tb, q, kk, vv, softmax_scale, lse, out, acc)
-    relay.finish()
+    with KVRelay(process_group, k, v) as relay:
+        for step in range(P):
+            kk, vv = relay.get(step)
+            basic_varlen_fwd_step(be, r, P, step, causal, tb, q, kk, vv, softmax_scale, lse, out, acc)
     return out, lse
 
 
@@ -60,9 +59,9 @@ def ring_flash_attn_varlen_backward(process_group, dout, q, k, v, out, softmax_l
                                     max_seqlen, softmax_scale, dropout_p=0, causal=True,
                                     window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
                                     deterministic=False):
-    be = get_block_backend()
     P = dist.get_world_size(process_group)
     r = dist.get_rank(process_group)
+    be = get_block_backend(beside_transfers=P > 1)
     T, H, D = q.shape
     dev, f32 = q.device, torch.float32
     tb = SeqTables(cu_seqlens, max_seqlen, dev)
@@ -70,45 +69,23 @@ def ring_flash_attn_varlen_backward(process_group, dout, q, k, v, out, softmax_l
     delta = torch.empty((H, T), dtype=f32, device=dev)
     be.delta(dout[None], out[None], delta[None])
     if P == 1:
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        # zeros: the kernels do not touch rows outside every sequence's range (padding tokens after cu_seqlens[-1])
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
         be.bwd_packed(dout, q, k, v, softmax_lse, delta, tb.full, tb.full, tb.max_full, tb.max_full,
                       None, None, None, softmax_scale, bool(causal), dq16=dq, dk16=dk, dv16=dv)
         return dq, dk, dv
-    dq_acc = torch.empty((T, H, D), dtype=f32, device=dev)
-    dk_blk = torch.empty(k.shape, dtype=f32, device=dev)
-    dv_blk = torch.empty(v.shape, dtype=f32, device=dev)
+    dq_acc = torch.zeros((T, H, D), dtype=f32, device=dev)
 
-    relay = KVRelay(process_group, k, v)
-    d_comm = None
-    dk_acc = dv_acc = next_dk = next_dv = None
-    for step in range(P):
-        kk, vv = relay.get(step)
-        if step == 0:
-            dk_acc = torch.empty(k.shape, dtype=f32, device=dev)
-            dv_acc = torch.empty(v.shape, dtype=f32, device=dev)
-            basic_varlen_bwd_block(be, r, P, 0, causal, tb, dout, q, kk, vv, softmax_lse, delta,
-                                   softmax_scale, dq_acc, dk_acc, dv_acc)
-        else:
-            computed = basic_varlen_bwd_block(be, r, P, step, causal, tb, dout, q, kk, vv, softmax_lse,
-                                              delta, softmax_scale, dq_acc, dk_blk, dv_blk)
-            d_comm.wait()
-            dk_acc, dv_acc = next_dk, next_dv
-            if computed:
-                be.add(dk_acc, dk_acc, dk_blk)
-                be.add(dv_acc, dv_acc, dv_blk)
-        d_comm = RingComm(process_group)
-        next_dk = d_comm.send_recv(dk_acc)
-        next_dv = d_comm.send_recv(dv_acc)
-        d_comm.commit()
-    d_comm.wait()
-    dk_acc, dv_acc = next_dk, next_dv
-    relay.finish()
+    def block(step, kk, vv, dk_dst, dv_dst):
+        return basic_varlen_bwd_block(be, r, P, step, causal, tb, dout, q, kk, vv, softmax_lse, delta,
+                                      softmax_scale, dq_acc, dk_dst, dv_dst)
 
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    be.cast(dq, dq_acc)
-    be.cast(dk, dk_acc)
-    be.cast(dv, dv_acc)
-    return dq, dk, dv
+    def fold(step, dk_acc, dv_acc, dk_blk, dv_blk):
+        be.add(dk_acc, dk_acc, dk_blk)
+        be.add(dv_acc, dv_acc, dv_blk)
+
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, zero=True)
+    return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 
 
 class RingFlashAttnVarlenFunc(torch.autograd.Function):

@@ -12,7 +12,7 @@ import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
 
-__all__ = ["update_out_and_lse", "RingComm", "KVRelay"]
+__all__ = ["update_out_and_lse", "RingComm", "KVRelay", "travel_dkdv", "final_grads"]
 
 
 def update_out_and_lse(out: Optional[torch.Tensor], lse: Optional[torch.Tensor],
@@ -91,19 +91,29 @@ class KVRelay:
     The reference posts the transfer for step s+1 from the compute stream at the top of step s
     (zigzag_ring_flash_attn.py:46-49), so RCCL only starts it once attention(s-1) has finished, and it relays
     hop by hop: the K/V of rank r-s reach rank r over s consecutive hops on ONE link per GPU.  Here everything
-    is queued up-front on a side HIP stream, with one receive slot per source rank (HBM is not the constraint
-    on a 288 GB part), and the compute stream only waits on the event of the slot it is about to consume:
+    is queued up-front on a side HIP stream (`_side_stream(device, "ring")`), with one receive slot per source
+    rank, and the compute stream only waits on the event of the slot it is about to consume:
 
-      * "direct" (default for ring degree > 2): every rank sends its OWN K/V straight to all P-1 peers in one
+      * "direct" (default for ring degree > 2): every rank sends its OWN K/V straight to all P-1 peers in ONE
         grouped send/recv.  xGMI is a full mesh of point-to-point links, so the P-1 transfers into a rank
         arrive over P-1 different links in parallel: the same bytes per rank as the relay, but one transfer
         time instead of P-1 serial ones (BASELINE's 4-GPU config moves 64 MiB per hop against 0.25 ms of
-        attention per step: a one-link relay is link-bound there).
+        attention per step: a one-link relay is link-bound there).  The transfers of one group run
+        concurrently and land together, so all slots share ONE event (ProcessGroupNCCL serialises separate
+        batches on its internal stream: per-peer batches would give per-slot events at the price of
+        serialising the links again).
       * "chain" (ring degree 2, or USP_KV_RELAY=chain): the reference's hop-by-hop relay, hop s+1 starting the
-        moment hop s has landed.
+        moment hop s has landed; one event per slot.
 
-    Slot s holds the K/V of ring rank r-s in both modes.  On host tensors (gloo tests) the same runs inline.
+    Slot s holds the K/V of ring rank r-s in both modes.  The receive slots are persistent per (shape, dtype,
+    device, ring degree): the side stream is ordered behind the compute stream at the start of every relay and
+    the compute stream behind the side stream at its end (`finish`), so a slot is never rewritten while a
+    kernel of the previous call still reads it.  On host tensors (gloo tests) the same runs inline.
+
+    Use as a context manager: `finish` must run on every exit path (it re-joins the side stream).
     """
+
+    _SLOTS = {}          # (shape, dtype, device, P) -> [(k_slot, v_slot)] * (P-1), device tensors only
 
     def __init__(self, process_group, k: torch.Tensor, v: torch.Tensor):
         self.P = dist.get_world_size(process_group)
@@ -114,18 +124,14 @@ class KVRelay:
         self.slots: List[Tuple[torch.Tensor, torch.Tensor]] = [(k, v)]
         self.events = [None]
         self._stream = None
-        self._overlap = None
         if self.P == 1:
             return
-        # the relay (and the travelling dK/dV) must be able to run BESIDE the attention kernels: ask for
-        # launches that leave room for RCCL's kernels (persistent launches hold every CU until they end)
-        from ..kernels.attention import overlapping_transfers
-        self._overlap = overlapping_transfers().begin()
         cuda = k.is_cuda
         if cuda:
             self._main = torch.cuda.current_stream()
-            self._stream = _side_stream(k.device)
+            self._stream = _side_stream(k.device, "ring")
             self._stream.wait_stream(self._main)          # k, v are produced on the compute stream
+        recv = self._recv_slots(k, v)
         ctx = torch.cuda.stream(self._stream) if cuda else _NullCtx()
         mode = os.environ.get("USP_KV_RELAY", "direct" if self.P > 2 else "chain")
         if mode == "direct":
@@ -134,7 +140,7 @@ class KVRelay:
                 to_global = lambda i: dist.get_global_rank(process_group, i % self.P) if process_group is not None else i % self.P
                 comm = RingComm(process_group)          # one grouped send/recv to and from every peer
                 for s in range(1, self.P):
-                    nk, nv = torch.empty_like(k), torch.empty_like(v)
+                    nk, nv = recv[s - 1]
                     dst, src = to_global(r + s), to_global(r - s)
                     comm._ops += [dist.P2POp(dist.isend, k, dst, group=process_group),
                                   dist.P2POp(dist.irecv, nk, src, group=process_group),
@@ -151,10 +157,10 @@ class KVRelay:
             return
         with ctx:
             cur_k, cur_v = k, v
-            for _ in range(self.P - 1):
+            for s in range(1, self.P):
                 comm = RingComm(process_group)
-                nk = comm.send_recv(cur_k)
-                nv = comm.send_recv(cur_v)
+                nk = comm.send_recv(cur_k, recv[s - 1][0])
+                nv = comm.send_recv(cur_v, recv[s - 1][1])
                 comm.commit()
                 comm.wait()
                 ev = None
@@ -165,6 +171,15 @@ class KVRelay:
                 self.events.append(ev)
                 cur_k, cur_v = nk, nv
 
+    def _recv_slots(self, k, v):
+        if not k.is_cuda:
+            return [(torch.empty_like(k), torch.empty_like(v)) for _ in range(self.P - 1)]
+        key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index, self.P)
+        slots = KVRelay._SLOTS.get(key)
+        if slots is None:
+            slots = KVRelay._SLOTS[key] = [(torch.empty_like(k), torch.empty_like(v)) for _ in range(self.P - 1)]
+        return slots
+
     def get(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """K, V held after `step` hops; makes the current stream wait for that hop."""
         ev = self.events[step]
@@ -173,13 +188,71 @@ class KVRelay:
         return self.slots[step]
 
     def finish(self):
-        """Order the side stream before anything the compute stream does next, so buffers handed
-        back to the caching allocator cannot be reused while a hop still reads or writes them."""
+        """Order the side stream before anything the compute stream does next, so the receive slots (and
+        buffers handed back to the caching allocator) cannot be reused while a hop still reads or writes them."""
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
-        if self._overlap is not None:
-            self._overlap.end()
-            self._overlap = None
+            self._stream = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.finish()
+        return False
+
+
+def travel_dkdv(process_group, k, v, block, fold, zero: bool = False):
+    """The travelling dK/dV of every ring backward (zigzag_ring_flash_attn.py:139-183, ring_flash_attn.py:
+    86-147): the fp32 accumulators of K/V block j visit every rank that attends to it, one hop per step,
+    each rank adding its block result; after P hops they are back home.
+
+        block(step, kk, vv, dk_dst, dv_dst) -> False if the step computes nothing
+            runs the block backward of `step` against the K/V that arrived after `step` hops, writing the
+            dK/dV block into dk_dst/dv_dst (at step 0 these ARE the travelling accumulators);
+        fold(step, dk_acc, dv_acc, dk_blk, dv_blk)
+            adds the block into the accumulators that just arrived.
+
+    The hop of step s is posted from the compute stream right after the kernels of step s, and runs beside
+    the kernels of step s+1.  `zero`: start every buffer from zeros (packed batches: the kernels do not touch
+    rows outside every sequence's range, which would otherwise travel -- and be summed -- uninitialised).
+    Returns the final (dk, dv) fp32 accumulators."""
+    P = dist.get_world_size(process_group)
+    new = (lambda t: torch.zeros(t.shape, dtype=torch.float32, device=t.device)) if zero else \
+          (lambda t: torch.empty(t.shape, dtype=torch.float32, device=t.device))
+    dk_blk, dv_blk = new(k), new(v)
+    d_comm = None
+    dk_acc = dv_acc = next_dk = next_dv = None
+    with KVRelay(process_group, k, v) as relay:
+        for step in range(P):
+            kk, vv = relay.get(step)
+            if step == 0:
+                dk_acc, dv_acc = new(k), new(v)
+                block(0, kk, vv, dk_acc, dv_acc)
+            else:
+                computed = block(step, kk, vv, dk_blk, dv_blk)
+                d_comm.wait()                       # the travelling accumulators of step-1 have landed
+                dk_acc, dv_acc = next_dk, next_dv
+                if computed is not False:
+                    fold(step, dk_acc, dv_acc, dk_blk, dv_blk)
+            d_comm = RingComm(process_group)
+            next_dk = d_comm.send_recv(dk_acc)
+            next_dv = d_comm.send_recv(dv_acc)
+            d_comm.commit()
+        d_comm.wait()
+    return next_dk, next_dv
+
+
+def final_grads(be, refs, accs):
+    """16-bit gradients from the fp32 accumulators of a ring backward: fresh CONTIGUOUS tensors (the cast
+    kernel takes rows; `empty_like` would inherit the seq-major strides the Ulysses exchange hands the ring
+    for batch > 1)."""
+    out = []
+    for ref, acc in zip(refs, accs):
+        g = torch.empty(ref.shape, dtype=ref.dtype, device=ref.device)
+        be.cast(g, acc)
+        out.append(g)
+    return tuple(out)
 
 
 class _NullCtx:
@@ -193,8 +266,10 @@ class _NullCtx:
 _SIDE_STREAMS = {}
 
 
-def _side_stream(device) -> "torch.cuda.Stream":
-    key = (device.type, device.index)
+def _side_stream(device, lane: str = "ring") -> "torch.cuda.Stream":
+    """One side HIP stream per device and lane: "ring" carries the K/V relay, "ulysses" the pipelined head
+    exchange -- two lanes, so a ring hop never queues behind the exchanges of later head groups."""
+    key = (device.type, device.index, lane)
     if key not in _SIDE_STREAMS:
         _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
     return _SIDE_STREAMS[key]

@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 from ..kernels import AttnType
 from ..kernels.attention import get_block_backend
-from .utils import KVRelay, RingComm
+from .utils import KVRelay, final_grads, travel_dkdv
 
 
 
@@ -72,88 +72,57 @@ def zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk):
 
 def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, causal=True,
                                    window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
-                                   deterministic=False, attn_type: AttnType = AttnType.HIP):
+                                   deterministic=False, attn_type: AttnType = AttnType.HIP, overlap=False):
+    """`overlap`: the caller has transfers of its own in flight (pipelined Ulysses exchange), so the kernels are
+    launched so that collectives can run beside them even at ring degree 1."""
     assert causal == True, "zigzag ring is meaningless for causal=False"
-    be = get_block_backend()
     P = dist.get_world_size(process_group)
     r = dist.get_rank(process_group)
+    be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S2, H, D = q.shape
     assert S2 % 2 == 0, "zigzag layout needs an even local sequence length"
-    c = S2 // 2
     dev = q.device
     out = torch.empty((B, S2, H, D), dtype=q.dtype, device=dev)
     lse = torch.empty((B, H, S2), dtype=torch.float32, device=dev)
-    acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev) if P > 1 else None
-
-    relay = KVRelay(process_group, k, v)
-    for step in range(P):
-        kk, vv = relay.get(step)
-        zigzag_fwd_step(be, r, P, step, q, kk, vv, softmax_scale, lse, out, acc)
-    relay.finish()
+    if P == 1:           # one block, no relay, no running accumulator
+        be.fwd(q, k, v, softmax_scale, True, lse, out)
+        return out, lse
+    acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev)
+    with KVRelay(process_group, k, v) as relay:
+        for step in range(P):
+            kk, vv = relay.get(step)
+            zigzag_fwd_step(be, r, P, step, q, kk, vv, softmax_scale, lse, out, acc)
     return out, lse
 
 
 def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, softmax_scale,
                                     dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
                                     alibi_slopes=None, deterministic=False,
-                                    attn_type: AttnType = AttnType.HIP):
+                                    attn_type: AttnType = AttnType.HIP, overlap=False):
     assert causal == True, "zigzag ring is meaningless for causal=False"
-    be = get_block_backend()
     P = dist.get_world_size(process_group)
     r = dist.get_rank(process_group)
+    be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S2, H, D = q.shape
     c = S2 // 2
     dev = q.device
-    f32 = torch.float32
     lse = softmax_lse
-    delta = torch.empty((B, H, S2), dtype=f32, device=dev)
+    delta = torch.empty((B, H, S2), dtype=torch.float32, device=dev)
     be.delta(dout, out, delta)
     if P == 1:   # one block: the kernels round the gradients to q.dtype in their epilogues
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         be.bwd(dout, q, k, v, lse, delta, None, None, None, softmax_scale, True, dq16=dq, dk16=dk, dv16=dv)
         return dq, dk, dv
-    dq_acc = torch.empty((B, S2, H, D), dtype=f32, device=dev)
-    dk_blk = dv_blk = None
-    if P > 1:
-        dk_blk = torch.empty(k.shape, dtype=f32, device=dev)
-        dv_blk = torch.empty(v.shape, dtype=f32, device=dev)
+    dq_acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev)
 
-    relay = KVRelay(process_group, k, v)
-    d_comm = None
-    dk_acc = dv_acc = next_dk = next_dv = None
-    for step in range(P):
-        kk, vv = relay.get(step)
-        if step == 0:
-            dk_acc = torch.empty(k.shape, dtype=f32, device=dev)
-            dv_acc = torch.empty(v.shape, dtype=f32, device=dev)
-            zigzag_bwd_block(be, r, P, 0, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, dk_acc,
-                             dv_acc)
-        else:
-            zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc,
-                             dk_blk, dv_blk)
-            d_comm.wait()                       # the travelling accumulators of step-1 have landed
-            dk_acc, dv_acc = next_dk, next_dv
-            zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk)
-        if P > 1:
-            d_comm = RingComm(process_group)
-            next_dk = d_comm.send_recv(dk_acc)
-            next_dv = d_comm.send_recv(dv_acc)
-            d_comm.commit()
-    if P > 1:
-        d_comm.wait()
-        dk_acc, dv_acc = next_dk, next_dv
-    relay.finish()
+    def block(step, kk, vv, dk_dst, dv_dst):
+        zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, dk_dst, dv_dst)
 
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    _cast(be, dq, dq_acc)
-    _cast(be, dk, dk_acc)
-    _cast(be, dv, dv_acc)
-    return dq, dk, dv
+    def fold(step, dk_acc, dv_acc, dk_blk, dv_blk):
+        zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk)
 
-
-def _cast(be, dst16, src32):
-    """fp32 (B,S,H,D) contiguous -> 16-bit contiguous."""
-    be.cast(dst16, src32)
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold)
+    return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 
 
 class ZigZagRingFlashAttnFunc(torch.autograd.Function):

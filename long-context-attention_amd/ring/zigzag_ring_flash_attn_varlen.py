@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
-from .utils import KVRelay, RingComm
+from .utils import KVRelay, final_grads, travel_dkdv
 from .varlen_utils import SeqTables, unflatten_lse
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
@@ -65,19 +65,18 @@ def zigzag_ring_flash_attn_varlen_forward(process_group, q, k, v, cu_seqlens, ma
                                           alibi_slopes=None, deterministic=False):
     """Returns (out (T,H,D), lse (H,T) fp32)."""
     assert causal == True, "zigzag ring is meaningless for causal=False"
-    be = get_block_backend()
     P = dist.get_world_size(process_group)
     r = dist.get_rank(process_group)
+    be = get_block_backend(beside_transfers=P > 1)
     T, H, D = q.shape
     tb = SeqTables(cu_seqlens, max_seqlen, q.device)
     out = torch.empty((T, H, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((H, T), dtype=torch.float32, device=q.device)
     acc = torch.empty((T, H, D), dtype=torch.float32, device=q.device) if P > 1 else None
-    relay = KVRelay(process_group, k, v)
-    for step in range(P):
-        kk, vv = relay.get(step)
-        zigzag_varlen_fwd_step(be, r, P, step, tb, q, kk, vv, softmax_scale, lse, out, acc)
-    relay.finish()
+    with KVRelay(process_group, k, v) as relay:
+        for step in range(P):
+            kk, vv = relay.get(step)
+            zigzag_varlen_fwd_step(be, r, P, step, tb, q, kk, vv, softmax_scale, lse, out, acc)
     return out, lse
 
 
@@ -87,9 +86,9 @@ def zigzag_ring_flash_attn_varlen_backward(process_group, dout, q, k, v, out, so
                                            deterministic=False):
     """`softmax_lse` is the flattened (H,T) fp32 LSE of the forward."""
     assert causal == True, "zigzag ring is meaningless for causal=False"
-    be = get_block_backend()
     P = dist.get_world_size(process_group)
     r = dist.get_rank(process_group)
+    be = get_block_backend(beside_transfers=P > 1)
     T, H, D = q.shape
     dev, f32 = q.device, torch.float32
     tb = SeqTables(cu_seqlens, max_seqlen, dev)
@@ -97,46 +96,25 @@ def zigzag_ring_flash_attn_varlen_backward(process_group, dout, q, k, v, out, so
     delta = torch.empty((H, T), dtype=f32, device=dev)
     be.delta(dout[None], out[None], delta[None])
     if P == 1:   # one block: the kernels round the gradients to q.dtype in their epilogues
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        # zeros: the kernels do not touch rows outside every sequence's range (padding tokens after cu_seqlens[-1])
+        dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
         be.bwd_packed(dout, q, k, v, softmax_lse, delta, tb.full, tb.full, tb.max_full, tb.max_full,
                       None, None, None, softmax_scale, True, dq16=dq, dk16=dk, dv16=dv)
         return dq, dk, dv
-    dq_acc = torch.empty((T, H, D), dtype=f32, device=dev)
-    dk_blk = torch.empty(k.shape, dtype=f32, device=dev)
-    dv_blk = torch.empty(v.shape, dtype=f32, device=dev)
+    dq_acc = torch.zeros((T, H, D), dtype=f32, device=dev)
 
-    relay = KVRelay(process_group, k, v)
-    d_comm = None
-    dk_acc = dv_acc = next_dk = next_dv = None
-    for step in range(P):
-        kk, vv = relay.get(step)
-        if step == 0:
-            dk_acc = torch.empty(k.shape, dtype=f32, device=dev)
-            dv_acc = torch.empty(v.shape, dtype=f32, device=dev)
-            zigzag_varlen_bwd_block(be, r, P, 0, tb, dout, q, kk, vv, softmax_lse, delta, softmax_scale,
-                                    dq_acc, dk_acc, dv_acc)
-        else:
-            if step <= r:      # only front-half rows are produced: the rest must add as zero (:254-256)
-                dk_blk.zero_(); dv_blk.zero_()
-            zigzag_varlen_bwd_block(be, r, P, step, tb, dout, q, kk, vv, softmax_lse, delta,
-                                    softmax_scale, dq_acc, dk_blk, dv_blk)
-            d_comm.wait()                       # the travelling accumulators of step-1 have landed
-            dk_acc, dv_acc = next_dk, next_dv
-            be.add(dk_acc, dk_acc, dk_blk)
-            be.add(dv_acc, dv_acc, dv_blk)
-        d_comm = RingComm(process_group)
-        next_dk = d_comm.send_recv(dk_acc)
-        next_dv = d_comm.send_recv(dv_acc)
-        d_comm.commit()
-    d_comm.wait()
-    dk_acc, dv_acc = next_dk, next_dv
-    relay.finish()
+    def block(step, kk, vv, dk_dst, dv_dst):
+        if 0 < step <= r:  # only front-half rows are produced: the rest must add as zero (:254-256)
+            dk_dst.zero_(); dv_dst.zero_()
+        zigzag_varlen_bwd_block(be, r, P, step, tb, dout, q, kk, vv, softmax_lse, delta, softmax_scale,
+                                dq_acc, dk_dst, dv_dst)
 
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-    be.cast(dq, dq_acc)
-    be.cast(dk, dk_acc)
-    be.cast(dv, dv_acc)
-    return dq, dk, dv
+    def fold(step, dk_acc, dv_acc, dk_blk, dv_blk):
+        be.add(dk_acc, dk_acc, dk_blk)
+        be.add(dv_acc, dv_acc, dv_blk)
+
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, zero=True)
+    return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 
 
 class ZigZagRingFlashAttnVarlenFunc(torch.autograd.Function):

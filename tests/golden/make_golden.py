@@ -62,6 +62,11 @@ CASES = [
     ("n_w4_u2r2_strip_bf16", 4, 2, 2, "strip", 1, 256, 4, 4, 64, "bfloat16", True),
     ("n_w2_ulysses_bf16:ulysses", 2, 2, 1, "basic", 2, 256, 4, 2, 64, "bfloat16", True),
     ("n_w4_u2r2_qkvpacked_bf16:qkvpacked", 4, 2, 2, "zigzag", 1, 256, 4, 4, 64, "bfloat16", True),
+    # NON-causal basic ring with ring degree > 1 (every step computes: ring_flash_attn.py:35 `if not causal or
+    # step <= comm.rank`; an optional 13th field = causal), the second one with batch 2 and GQA on a
+    # ulysses x ring grid (seq-major views with a real batch stride reach the ring)
+    ("f_w4_u1r4_full_bf16", 4, 1, 4, "basic", 1, 512, 2, 2, 64, "bfloat16", True, False),
+    ("f_w4_u2r2_full_b2_gqa_bf16", 4, 2, 2, "basic", 2, 256, 4, 2, 64, "bfloat16", True, False),
 ]
 SEED = 0
 
@@ -140,7 +145,8 @@ def _bits(t: torch.Tensor) -> np.ndarray:
 
 
 def _worker(rank, ws, case, port, ret):
-    name, _, ud, rd, impl, B, S, Hq, Hkv, D, dtype_s, bwd = case
+    name, _, ud, rd, impl, B, S, Hq, Hkv, D, dtype_s, bwd = case[:12]
+    causal = case[12] if len(case) > 12 else True
     layer = name.split(":")[1] if ":" in name else "hybrid"
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -161,7 +167,7 @@ def _worker(rank, ws, case, port, ret):
                        for t in (q, k, v, dout))
     if bwd:
         lq.requires_grad_(True); lk.requires_grad_(True); lv.requires_grad_(True)
-    kw = dict(dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+    kw = dict(dropout_p=0, causal=causal, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
               deterministic=False, return_attn_probs=True)
     if layer == "hybrid":
         attn = LongContextAttention(ring_impl_type=impl, attn_type=AttnType.TORCH_EFFICIENT)
@@ -211,11 +217,12 @@ def main():
         mgr = mp.Manager()
         ret = mgr.dict()
         mp.spawn(_worker, args=(ws, case, 29650 + i, ret), nprocs=ws, join=True)
-        _, _, ud, rd, impl, B, S, Hq, Hkv, D, dtype_s, bwd = case
+        _, _, ud, rd, impl, B, S, Hq, Hkv, D, dtype_s, bwd = case[:12]
+        causal = case[12] if len(case) > 12 else True
         layer = name.split(":")[1] if ":" in name else "hybrid"
         name = name.split(":")[0]
         blob = dict(ws=ws, ud=ud, rd=rd, impl=impl, B=B, S=S, Hq=Hq, Hkv=Hkv, D=D,
-                    dtype=dtype_s, bwd=bwd, causal=True, seed=SEED, layer=layer)
+                    dtype=dtype_s, bwd=bwd, causal=causal, seed=SEED, layer=layer)
         for r in range(ws):
             for key in ("out", "dq", "dk", "dv"):
                 if key in ret[r]:

@@ -19,6 +19,16 @@ TOL = {
 }
 
 
+def grad_tol(dtype: str, heads_summed: int = 1):
+    """(atol, rtol) for a gradient.  TOL[...]["grad"] is the envelope of ONE attention head's gradient on
+    N(0,1) inputs.  dK / dV of a GQA group are sums over the group's G query heads; each head's contribution
+    carries its own independent 16-bit rounding noise (P, dS and dO are rounded per head before the MFMAs), so
+    the absolute error of the sum grows like sqrt(G) -- as does the magnitude of the gradient itself, which is
+    why rtol stays.  G = 1 returns the stated MHA tolerance unchanged."""
+    atol, rtol = TOL[dtype]["grad"]
+    return atol * float(np.sqrt(heads_summed)), rtol
+
+
 def golden_files():
     """Dense fixtures (make_golden.py); the packed variable-length ones are varlen_golden_files()."""
     return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))

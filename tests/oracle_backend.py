@@ -104,10 +104,20 @@ class OracleBlockBackend:
         o_new, l_new = O.update_out_and_lse(_np(acc), l_run, _np(blk_out), _np(blk_lse))
         _put(acc, o_new); _put(lse, np.swapaxes(l_new[..., 0], 1, 2))
 
+    @staticmethod
+    def _rows(t):
+        """The layout constraint of the device kernels (yunchang_amd/_C.py:_rows2d): contiguous, or a batch of
+        contiguous slices.  Asserted here too, so the CPU orchestration tests fail where the HIP path would."""
+        assert t.is_contiguous() or (t.dim() == 4 and t[0].is_contiguous()), \
+            f"usp_cast_from_f32 / usp_add_f32 need contiguous rows, got shape {tuple(t.shape)} strides {t.stride()}"
+
     def cast(self, dst16, src32):
+        self._rows(dst16); self._rows(src32)
         dst16.copy_(src32.to(dst16.dtype))
 
     def add(self, dst, a, b):
+        for t in (dst, a, b):
+            self._rows(t)
         torch.add(a, b, out=dst)
 
     def copy_rows(self, dst, src, row_bytes, sizes, dst_strides, src_strides):

@@ -38,10 +38,10 @@ def _order_p2p_like_rccl():
 def _usp_gpu_worker(rank, ws, path, pipelined=False):
     import yunchang_amd as Y
     _order_p2p_like_rccl()
-    if pipelined:        # LongContextAttention's pipelined Ulysses exchange, also beside a ring, on tiny fixtures
-        import os
+    if pipelined:        # the DEFAULT exchange mode (USP_PIPELINE_ULYSSES unset): head groups pipelined on the side
+        import os        # stream, also beside a ring; the fixtures are tiny, so let the groups form anyway
         import yunchang_amd.hybrid.async_attn_layer as AL
-        os.environ["USP_PIPELINE_ULYSSES"] = "1"
+        assert "USP_PIPELINE_ULYSSES" not in os.environ and "USP_PACK_QKV" not in os.environ
         AL._FILL_ITEMS = 1
     from yunchang_amd.kernels import get_block_backend
     assert get_block_backend().name == "hip"
@@ -53,25 +53,64 @@ def _usp_gpu_worker(rank, ws, path, pipelined=False):
     ext = Y.EXTRACT_FUNC_DICT[g.impl]
     glob = [torch.from_numpy(t).to(dtype) for t in (g.q, g.k, g.v, g.dout)]
     lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=g.rd, ud=g.ud).detach().clone().to(dev) for t in glob)
-    for t in (lq, lk, lv):
-        t.requires_grad_(True)
-    kw = dict(dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+    kw = dict(dropout_p=0, causal=g.causal, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
               deterministic=False, return_attn_probs=True)
+    qkv = None
     if g.layer == "ulysses":
         attn = Y.UlyssesAttention(Y.PROCESS_GROUP.ULYSSES_PG, attn_type=Y.AttnType.HIP)
-    else:
+    elif g.layer == "hybrid":
         attn = Y.LongContextAttention(ring_impl_type=g.impl, attn_type=Y.AttnType.HIP)
-        assert attn._pipelined_exchange(lq, lk) == (pipelined and g.ud > 1 and g.Hkv // g.ud > 1)
+        assert (attn._packed_exchange(lq, lk) is not None) == (g.ud > 1)      # one packed q|k|v exchange
+    else:                # LongContextAttentionQKVPacked + SeqAllToAll5D
+        attn = Y.LongContextAttentionQKVPacked(ring_impl_type=g.impl, attn_type=Y.AttnType.HIP)
+        qkv = torch.stack([lq, lk, lv], dim=2).requires_grad_(True)
     res = {}
     for it in range(2):                      # twice: buffers / streams must be reusable
-        for t in (lq, lk, lv):
-            t.grad = None
-        out = attn(lq, lk, lv, **kw)
+        if qkv is not None:
+            qkv.grad = None
+            out = attn(qkv, **kw)
+        else:
+            for t in (lq, lk, lv):
+                t.requires_grad_(True)
+                t.grad = None
+            out = attn(lq, lk, lv, **kw)
         out.backward(ldo)
         torch.cuda.synchronize()
-        res = dict(out=out.detach().float().cpu().numpy(), dq=lq.grad.float().cpu().numpy(),
-                   dk=lk.grad.float().cpu().numpy(), dv=lv.grad.float().cpu().numpy())
+        grads = (qkv.grad[:, :, 0], qkv.grad[:, :, 1], qkv.grad[:, :, 2]) if qkv is not None else \
+                (lq.grad, lk.grad, lv.grad)
+        res = dict(out=out.detach().float().cpu().numpy(), dq=grads[0].float().cpu().numpy(),
+                   dk=grads[1].float().cpu().numpy(), dv=grads[2].float().cpu().numpy())
     return res
+
+
+def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D):
+    """No fixture has batch > 1 on a ulysses x ring grid: exact attention (fp64 oracle) on the unsharded
+    tensors is the reference here.  Batch 2 is what gives the seq-major views the exchange hands the ring a
+    real batch stride (the P > 1 gradient cast used to reject them)."""
+    import yunchang_amd as Y
+    import yunchang_amd.hybrid.async_attn_layer as AL
+    from oracle import usp_oracle as O
+    _order_p2p_like_rccl()
+    AL._FILL_ITEMS = 1
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    Y.set_seq_parallel_pg(ud, rd, rank, ws)
+    torch.manual_seed(0)
+    B, S = 2, 64 * ws
+    q, k, v, do = (torch.randn(B, S, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
+    ext = Y.EXTRACT_FUNC_DICT[impl]
+    qn, kn, vn, don = (t.float().numpy().astype(np.float64) for t in (q, k, v, do))
+    ro, rl = O.attention_ref(qn, kn, vn, causal=True)
+    truth = [ext(torch.from_numpy(np.ascontiguousarray(t)), rank, world_size=ws, rd=rd, ud=ud).float().numpy()
+             for t in (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, True))]
+    lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=rd, ud=ud).detach().clone().to(dev) for t in (q, k, v, do))
+    for t in (lq, lk, lv):
+        t.requires_grad_(True)
+    out = Y.LongContextAttention(ring_impl_type=impl, attn_type=Y.AttnType.HIP)(lq, lk, lv, causal=True)
+    out.backward(ldo)
+    torch.cuda.synchronize()
+    got = [t.detach().float().cpu().numpy() for t in (out, lq.grad, lk.grad, lv.grad)]
+    return got, truth
 
 
 def _probe_worker(rank, ws):
@@ -99,7 +138,7 @@ def gloo_cuda():
         pytest.skip("gloo cannot move device tensors in this build")
 
 
-DENSE = [f for f in golden_files() if "_w1" not in f and "qkvpacked" not in f]
+DENSE = [f for f in golden_files() if "_w1" not in f]
 
 
 @pytest.mark.parametrize("path", DENSE, ids=lambda p: p.split("/")[-1][:-4])
@@ -117,14 +156,23 @@ PIPE = [f for f in DENSE if "c3_w2_u2r1" in f or "c5_w8_u2r4_gqa_bf16" in f or "
 
 @pytest.mark.parametrize("path", PIPE, ids=lambda p: p.split("/")[-1][:-4])
 def test_long_context_attention_with_pipelined_exchange(gloo_cuda, path):
-    """LongContextAttention taking its head-group pipelined exchange path (side-stream all-to-all beside the
-    ring attention kernels, launched interleavable) against the reference goldens."""
+    """LongContextAttention in its DEFAULT mode -- packed q|k|v exchange pipelined over head groups on the
+    "ulysses" side stream, beside the ring relay on the "ring" side stream, kernels launched interleavable --
+    with USP_PIPELINE_ULYSSES unset, against the reference goldens (incl. ulysses 2 x ring 4, GQA)."""
     g = Golden(path)
     res = run_distributed(_usp_gpu_worker, g.ws, path, True)
     for r in range(g.ws):
         assert_close(res[r]["out"], g.out[r], *TOL[g.dtype]["out"], f"{g.name} out rank {r}")
         for key in ("dq", "dk", "dv"):
             assert_close(res[r][key], getattr(g, key)[r], *TOL[g.dtype]["grad"], f"{g.name} {key} rank {r}")
+
+
+@pytest.mark.parametrize("ws,ud,rd,impl,Hq,Hkv,D", [(4, 2, 2, "zigzag", 8, 4, 128), (4, 2, 2, "basic", 4, 4, 64),
+                                                    (4, 2, 2, "strip", 8, 2, 128)])
+def test_batch2_on_a_ulysses_x_ring_grid(gloo_cuda, ws, ud, rd, impl, Hq, Hkv, D):
+    for got, truth in run_distributed(_batch2_worker, ws, ud, rd, impl, Hq, Hkv, D):
+        for a, t, key in zip(got, truth, ("out", "dq", "dk", "dv")):
+            assert_close(a, t, *TOL["bfloat16"]["out" if key == "out" else "grad"], f"B=2 {impl} {key}")
 
 
 def _varlen_gpu_worker(rank, ws, path):

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_util import Golden, TOL, assert_close, golden_files, round_to
+from golden_util import Golden, TOL, assert_close, golden_files, grad_tol, round_to
 from oracle import usp_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -240,7 +240,7 @@ def test_async_layer_on_gpu_streams(dev, single_rank_pg):
     import yunchang_amd.hybrid.async_attn_layer as AL
     B, S, Hq, Hkv, D = 2, 1024, 8, 4, 128
     groups = AL._groups
-    AL._groups = lambda hq, hkv, P, B=None, S=None: (4, hkv // P // 4, hq // hkv)      # force 4 groups at P = 1
+    AL._groups = lambda hq, hkv, P, B=None, S=None, max_groups=None: (4, hkv // P // 4, hq // hkv)   # 4 groups at P = 1
     request_restore = groups
     gen = torch.Generator(device="cpu").manual_seed(5)
     q, k, v, do = (torch.randn(B, S, h, D, generator=gen).to(torch.bfloat16).to(dev) for h in (Hq, Hkv, Hkv, Hq))
@@ -256,6 +256,13 @@ def test_async_layer_on_gpu_streams(dev, single_rank_pg):
     AL._groups = request_restore
     for a, b, n in zip(res[0], res[1], ("out", "dq", "dk", "dv")):
         assert torch.allclose(a.float(), b.float(), atol=4e-3, rtol=4e-3), n
+    # ... and against exact attention (fp64 oracle), not only against the sibling layer
+    qn, kn, vn, don = (_f(t).astype(np.float64) for t in (q, k, v, do))
+    ro, rl = O.attention_ref(qn, kn, vn, causal=True)
+    truth = (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, True))
+    for layer_res in res:
+        for a, t, n in zip(layer_res, truth, ("out", "dq", "dk", "dv")):
+            assert_close(_f(a), t, *TOL["bfloat16"]["out" if n == "out" else "grad"], f"async lane {n} vs oracle")
 
 
 def test_c1_fp32_fixture_is_matched_by_bf16_kernel(dev, single_rank_pg):
@@ -272,9 +279,7 @@ def test_c1_fp32_fixture_is_matched_by_bf16_kernel(dev, single_rank_pg):
 # golden fixtures from the reference: multi-rank grids emulated with VIRTUAL RANKS on one GPU
 # (the package's real pack/unpack kernels and ring step functions; only the wire is emulated)
 # ------------------------------------------------------------------------------------------------
-# the packed-qkv fixture is the hybrid maths on stacked tensors: its 5-D exchange kernels are unit
-# tested above, the rest is shared with the hybrid path
-MULTI = [f for f in golden_files() if "_w1_" not in f and "qkvpacked" not in f]
+MULTI = [f for f in golden_files() if "_w1_" not in f]
 
 
 def _virtual_usp(g, dev, with_bwd):
@@ -317,7 +322,24 @@ def _virtual_usp(g, dev, with_bwd):
                 res[r] = A.unpack_heads(recv)
         return res
 
-    hq, hk, hv = exchange_heads(loc["q"]), exchange_heads(loc["k"]), exchange_heads(loc["v"])
+    def exchange_5d(xs, pack, unpack):   # packed qkv (B,*,3,H,D): SeqAllToAll5D's kernels
+        res = [None] * ws
+        for grp in ulysses:
+            P = len(grp)
+            if P == 1:
+                res[grp[0]] = xs[grp[0]]
+                continue
+            sends = [pack(xs[r], P) for r in grp]
+            for i, r in enumerate(grp):
+                res[r] = unpack(torch.stack([sends[j][i] for j in range(P)]))
+        return res
+
+    if g.layer == "qkvpacked":           # ONE exchange of the stacked tensor; q, k, v are views of its result
+        qkv = [torch.stack([loc["q"][r], loc["k"][r], loc["v"][r]], dim=2) for r in range(ws)]
+        h5 = exchange_5d(qkv, A.pack_heads_5d, A.view_seq_5d)
+        hq, hk, hv = ([t[:, :, i] for t in h5] for i in range(3))
+    else:
+        hq, hk, hv = exchange_heads(loc["q"]), exchange_heads(loc["k"]), exchange_heads(loc["v"])
     outs, lses = [None] * ws, [None] * ws
     for grp in ring:
         P = len(grp)
@@ -335,7 +357,7 @@ def _virtual_usp(g, dev, with_bwd):
                     RS.stripe_fwd_step(be, r, P, step, q, hk[src].contiguous(), hv[src].contiguous(), scale,
                                        lse, out, acc)
                 else:
-                    RB.basic_fwd_step(be, r, P, step, True, q, hk[src], hv[src], scale, lse, out, acc)
+                    RB.basic_fwd_step(be, r, P, step, g.causal, q, hk[src], hv[src], scale, lse, out, acc)
             outs[rank], lses[rank] = out, lse
     final = exchange_seq(outs)
     if not with_bwd:
@@ -377,7 +399,7 @@ def _virtual_usp(g, dev, with_bwd):
                     if step > 0:
                         RS.stripe_bwd_fold(be, r, step, s["dk"], s["dv"], s["bk"], s["bv"])
                 else:
-                    did = RB.basic_bwd_block(be, r, P, step, True, hdo[rank], hq[rank], hk[src], hv[src],
+                    did = RB.basic_bwd_block(be, r, P, step, g.causal, hdo[rank], hq[rank], hk[src], hv[src],
                                              lses[rank], s["delta"], scale, s["dq"], dst_k, dst_v)
                     if step > 0 and did:
                         be.add(s["dk"], s["dk"], s["bk"])
@@ -387,6 +409,10 @@ def _virtual_usp(g, dev, with_bwd):
             hdq[rank] = st[r]["dq"].to(tdt)
             hdk[rank] = dks[(r - 1) % P].to(tdt) if P > 1 else dks[r].to(tdt)
             hdv[rank] = dvs[(r - 1) % P].to(tdt) if P > 1 else dvs[r].to(tdt)
+    if g.layer == "qkvpacked":           # the gradient of the packed exchange is the inverse packed exchange
+        g5 = exchange_5d([torch.stack([hdq[r], hdk[r], hdv[r]], dim=2) for r in range(ws)],
+                         A.pack_seq_5d, A.unpack_heads_5d)
+        return final, tuple([t[:, :, i] for t in g5] for i in range(3))
     return final, (exchange_seq(hdq), exchange_seq(hdk), exchange_seq(hdv))
 
 
@@ -478,8 +504,23 @@ def test_c5_rank_block_gqa_backward_sampled(dev):
                                 _f(out)[:, :, sl], _f(lse)[:, sl], None, True)
     assert_close(_f(out)[:, :, sl], ro, *TOL[dt]["out"], "out")
     assert_close(_f(dq)[:, :, sl], rdq, *TOL[dt]["grad"], "dq")
-    assert_close(_f(dk)[:, :, 1:2], rdk, 8e-2, 5e-2, "dk (sum over 8 query heads)")
-    assert_close(_f(dv)[:, :, 1:2], rdv, 8e-2, 5e-2, "dv (sum over 8 query heads)")
+    # dK / dV sum 8 query heads: absolute tolerance scaled by sqrt(8) (golden_util.grad_tol has the derivation) ...
+    assert_close(_f(dk)[:, :, 1:2], rdk, *grad_tol(dt, g), "dk (sum over 8 query heads)")
+    assert_close(_f(dv)[:, :, 1:2], rdv, *grad_tol(dt, g), "dv (sum over 8 query heads)")
+    # ... and the scale-free criterion of SURVEY 8(c): our error against the fp64 truth is at most twice the error
+    # of the 16-bit third-party path the reference would run here (torch SDPA autograd, K/V heads expanded)
+    import torch.nn.functional as F
+    ref = [tq[:, :, sl].transpose(1, 2).clone().requires_grad_(True),
+           tk[:, :, 1:2].expand(B, S, g, D).transpose(1, 2).clone().requires_grad_(True),
+           tv[:, :, 1:2].expand(B, S, g, D).transpose(1, 2).clone().requires_grad_(True)]
+    try:
+        F.scaled_dot_product_attention(*ref, is_causal=True).backward(tdo[:, :, sl].transpose(1, 2))
+    except Exception as e:                     # pragma: no cover - depends on the torch build
+        pytest.skip(f"torch SDPA backward does not run here: {e!r}")
+    for name, ours, theirs, truth in (("dk", _f(dk)[:, :, 1], _f(ref[1].grad.float().sum(1)), rdk[:, :, 0]),
+                                      ("dv", _f(dv)[:, :, 1], _f(ref[2].grad.float().sum(1)), rdv[:, :, 0])):
+        e_ours, e_ref = np.abs(ours - truth).max(), np.abs(theirs - truth).max()
+        assert e_ours <= 2 * e_ref + 1e-3, f"{name}: our max err {e_ours:.3e} vs reference path {e_ref:.3e}"
 
 
 # ------------------------------------------------------------------------------------------------
