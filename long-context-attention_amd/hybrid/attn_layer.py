@@ -38,6 +38,9 @@ class _USPLayer(torch.nn.Module):
         ), f"use set_seq_parallel_pg() first. Now ulysses pg {self.ulysses_pg} and ring pg {self.ring_pg}"
         self.scatter_idx, self.gather_idx = scatter_idx, gather_idx
         self.use_sync, self.attn_type = use_sync, attn_type
+        # the grid is fixed once the groups exist: no torch.distributed queries on the per-step path
+        self.ulysses_size = dist.get_world_size(self.ulysses_pg)
+        self.ring_size = dist.get_world_size(self.ring_pg)
 
     def _ring_options(self, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
                       return_attn_probs):
@@ -78,12 +81,14 @@ class LongContextAttention(_USPLayer):
         it; more = pipelined over head groups on the side stream, hybrid/async_attn_layer.py -- identical
         results).  Pipelining is the default also beside a ring (two communicators in flight, each on its own
         side stream); USP_PIPELINE_ULYSSES=0 keeps the exchange sequential."""
+        if self.ulysses_size == 1:
+            return None
         if os.environ.get("USP_PACK_QKV", "1") == "0" or self.use_sync or self.attn_processor is not None:
             return None
         if (self.scatter_idx, self.gather_idx) != (2, 1) or self.ring_impl_type not in _RING_FWD_BWD:
             return None
-        P = dist.get_world_size(self.ulysses_pg)
-        if P == 1 or query.shape[2] % P or key.shape[2] % P:
+        P = self.ulysses_size
+        if query.shape[2] % P or key.shape[2] % P:
             return None
         return 1 if os.environ.get("USP_PIPELINE_ULYSSES", "auto") == "0" else _MAX_GROUPS
 
@@ -98,11 +103,13 @@ class LongContextAttention(_USPLayer):
             _check_hot_path_args(dropout_p, window_size, softcap)
             return _AsyncUSPFunc.apply(query, key, value, softmax_scale, causal, self.ulysses_pg, self.ring_pg,
                                        self.ring_impl_type, ng_cap)
+        options = self._ring_options(dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
+                                     deterministic, return_attn_probs)
+        if self.ulysses_size == 1:      # nothing to exchange (the reference still makes 8 layout copies here)
+            return _first(self.ring_attn_fn(query, key, value, attn_processor=self.attn_processor, **options))
         # sequence shards -> head shards: (bs, seq_len/N, heads, d) -> (bs, seq_len, heads/N, d)
         q, k, v = (SeqAllToAll4D.apply(self.ulysses_pg, t, self.scatter_idx, self.gather_idx, self.use_sync)
                    for t in (query, key, value))
-        options = self._ring_options(dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes,
-                                     deterministic, return_attn_probs)
         context = _first(self.ring_attn_fn(q, k, v, attn_processor=self.attn_processor, **options))
         # ... and back: (bs, seq_len, heads/N, d) -> (bs, seq_len/N, heads, d)
         return SeqAllToAll4D.apply(self.ulysses_pg, context, self.gather_idx, self.scatter_idx, self.use_sync)
@@ -122,7 +129,7 @@ class LongContextAttentionQKVPacked(_USPLayer):
     def forward(self, qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
                 softcap=0.0, alibi_slopes=None, deterministic=False, return_attn_probs=False,
                 *args: Any) -> Tensor:
-        exchange = dist.get_world_size(self.ulysses_pg) > 1
+        exchange = self.ulysses_size > 1
         if exchange:         # scatter 3 (heads), gather 1 (sequence)
             qkv = SeqAllToAll5D.apply(self.ulysses_pg, qkv, self.scatter_idx, self.gather_idx, self.use_sync)
         out = _first(self.ring_attn_fn(qkv, **self._ring_options(dropout_p, softmax_scale, causal, window_size,

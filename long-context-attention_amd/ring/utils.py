@@ -131,7 +131,7 @@ class KVRelay:
             self._main = torch.cuda.current_stream()
             self._stream = _side_stream(k.device, "ring")
             self._stream.wait_stream(self._main)          # k, v are produced on the compute stream
-        recv = self._recv_slots(k, v)
+        recv = self._recv_slots(k, v, dist.get_rank(process_group))
         ctx = torch.cuda.stream(self._stream) if cuda else _NullCtx()
         mode = os.environ.get("USP_KV_RELAY", "direct" if self.P > 2 else "chain")
         if mode == "direct":
@@ -171,10 +171,10 @@ class KVRelay:
                 self.events.append(ev)
                 cur_k, cur_v = nk, nv
 
-    def _recv_slots(self, k, v):
+    def _recv_slots(self, k, v, rank):
         if not k.is_cuda:
             return [(torch.empty_like(k), torch.empty_like(v)) for _ in range(self.P - 1)]
-        key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index, self.P)
+        key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index, self.P, rank)
         slots = KVRelay._SLOTS.get(key)
         if slots is None:
             slots = KVRelay._SLOTS[key] = [(torch.empty_like(k), torch.empty_like(v)) for _ in range(self.P - 1)]

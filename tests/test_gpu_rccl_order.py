@@ -1,0 +1,166 @@
+"""Compute stream -> RCCL point-to-point ordering, on ONE GPU, through REAL RCCL.
+
+The multi-process tests (test_gpu_multiproc.py) have to use gloo (RCCL refuses two ranks per device) and insert a
+device synchronise in front of every RingComm.commit, which hides exactly the ordering that matters on real
+hardware: a send posted right behind the kernel that produces its payload (the travelling fp32 dK/dV accumulators
+of the ring backward, ring/utils.py:travel_dkdv) and a kernel launched right behind the receive it consumes.
+
+Here a ring of P VIRTUAL ranks lives in one process: every virtual rank is a thread with its own HIP stream that
+runs the package's real zigzag ring forward / backward (HIP kernels, KVRelay in chain mode on the side stream,
+RingComm); the wire is a 1-rank NCCL group, i.e. RCCL self send/recv (each hop's P sends and P receives are one
+grouped call, matched first-in first-out).  No host synchronisation anywhere: a rank's sends are ordered behind
+its compute by stream events, as ProcessGroupNCCL orders its internal stream behind the caller's current stream,
+and its next kernels behind the receive.  50 iterations must be bit-identical and match the reference golden."""
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import Golden, TOL, assert_close, golden_files
+
+pytestmark = pytest.mark.gpu
+
+
+class _VirtualRing:
+    """torch.distributed stand-in for P virtual ranks (threads) of one ring, backed by a real 1-rank NCCL group."""
+
+    def __init__(self, P, real_dist):
+        self.P, self.d = P, real_dist
+        self.tls = threading.local()
+        self.barrier = threading.Barrier(P, timeout=120)
+        self.pending = [None] * P            # per rank: (ops, event recorded on the rank's current stream)
+        self.done = None                     # event: the grouped call of this round has completed
+        self.group = object()                # the handle the schedules pass around as `process_group`
+
+    # --- what ring/utils.py and the ring schedules ask torch.distributed -------------------------------------
+    def get_world_size(self, group=None):
+        return self.P if group is self.group else self.d.get_world_size(group)
+
+    def get_rank(self, group=None):
+        return self.tls.rank if group is self.group else self.d.get_rank(group)
+
+    def get_global_rank(self, group, r):
+        return r if group is self.group else self.d.get_global_rank(group, r)
+
+    def P2POp(self, op, tensor, peer, group=None):
+        assert op in ("send", "recv")
+        return (op, tensor, peer)
+
+    isend, irecv = "send", "recv"            # markers: RingComm only ever hands them to P2POp
+
+    def batch_isend_irecv(self, ops):
+        me = self.tls.rank
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream())            # this rank's payloads are produced by here
+        self.pending[me] = (ops, ready)
+        i = self.barrier.wait()
+        if i == 0:                                            # one thread issues the grouped call for everyone
+            real_ops = []
+            for src in range(self.P):                         # message order = (source rank, its send order)
+                sends = [o for o in self.pending[src][0] if o[0] == "send"]
+                nth = {}
+                for _, tensor, dst in sends:
+                    j = nth.get(dst, 0); nth[dst] = j + 1
+                    recvs = [o for o in self.pending[dst][0] if o[0] == "recv" and o[2] == src]
+                    real_ops.append(self.d.P2POp(self.d.isend, tensor, 0))
+                    real_ops.append(self.d.P2POp(self.d.irecv, recvs[j][1], 0))
+            cur = torch.cuda.current_stream()
+            for _, ev in self.pending:                        # RCCL runs behind EVERY rank's compute ...
+                cur.wait_event(ev)
+            for req in self.d.batch_isend_irecv(real_ops):
+                req.wait()                                    # stream-wise: `cur` waits for the transfer
+            self.done = torch.cuda.Event()
+            self.done.record(cur)
+        self.barrier.wait()
+        done = self.done
+        self.barrier.wait()                                   # everyone has picked up `done` before it is replaced
+        return [_Req(done)]
+
+
+class _Req:
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):                                           # ... and every rank's next kernels behind the transfer
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+@pytest.fixture(scope="module")
+def nccl_single():
+    import torch.distributed as dist
+    import yunchang_amd  # noqa: F401
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29733")
+    own = not dist.is_initialized()
+    if own:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    yield dist
+    if own:
+        dist.destroy_process_group()
+
+
+def test_ring_backward_ordering_through_rccl_self_sendrecv(nccl_single, monkeypatch):
+    import yunchang_amd.ring.utils as U
+    import yunchang_amd.ring.zigzag_ring_flash_attn as Z
+    real = nccl_single
+    dev = torch.device("cuda:0")
+    # can this RCCL build send to itself at all?
+    a, b = torch.arange(8, device=dev, dtype=torch.float32), torch.zeros(8, device=dev)
+    try:
+        for req in real.batch_isend_irecv([real.P2POp(real.isend, a, 0), real.P2POp(real.irecv, b, 0)]):
+            req.wait()
+        torch.cuda.synchronize()
+    except Exception as e:                                    # pragma: no cover - depends on the RCCL build
+        pytest.skip(f"RCCL self send/recv not available: {e!r}")
+    assert torch.equal(a, b)
+
+    g = Golden([f for f in golden_files() if "c4_w4_u1r4" in f][0])          # ring 4, zigzag, forward + backward
+    P = g.rd
+    ring = _VirtualRing(P, real)
+    for mod in (U, Z):
+        monkeypatch.setattr(mod, "dist", ring)
+    monkeypatch.setenv("USP_KV_RELAY", "chain")               # hop-by-hop relay: one event per slot, P-1 grouped calls
+    dtype = getattr(torch, g.dtype)
+    loc = [[torch.from_numpy(np.ascontiguousarray(g.shard(x, r))).to(dtype).to(dev) for x in (g.q, g.k, g.v, g.dout)]
+           for r in range(P)]
+    scale = g.D ** -0.5
+    streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
+    torch.cuda.synchronize()
+
+    def run_rank(r, res, errs):
+        try:
+            ring.tls.rank = r
+            torch.cuda.set_device(dev)
+            q, k, v, do = loc[r]
+            with torch.cuda.stream(streams[r]):
+                out, lse = Z.zigzag_ring_flash_attn_forward(ring.group, q, k, v, scale)
+                dq, dk, dv = Z.zigzag_ring_flash_attn_backward(ring.group, do, q, k, v, out, lse, scale)
+            res[r] = (out, dq, dk, dv)
+        except BaseException as e:                            # noqa: BLE001 - report, and release the others
+            errs.append((r, repr(e)))
+            ring.barrier.abort()
+
+    first = None
+    for it in range(50):
+        res, errs = [None] * P, []
+        threads = [threading.Thread(target=run_rank, args=(r, res, errs)) for r in range(P)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(300)
+        assert not errs, errs
+        torch.cuda.synchronize()
+        got = [[t.clone() for t in res[r]] for r in range(P)]
+        if first is None:
+            first = got
+            for r in range(P):
+                for t, name in zip(got[r], ("out", "dq", "dk", "dv")):
+                    tol = TOL[g.dtype]["out" if name == "out" else "grad"]
+                    assert_close(t.float().cpu().numpy(), getattr(g, name)[r], *tol, f"{g.name} {name} rank {r}")
+        else:
+            for r in range(P):
+                for t, t0, name in zip(got[r], first[r], ("out", "dq", "dk", "dv")):
+                    assert torch.equal(t, t0), f"iteration {it}: {name} of rank {r} differs from iteration 0"

@@ -117,3 +117,73 @@ def test_grid_matches_reference_layout():
     assert u == [[0, 1], [2, 3], [4, 5], [6, 7]] and r == [[0, 2, 4, 6], [1, 3, 5, 7]]
     u, r = O.seq_parallel_groups(2, 2, 8)           # dp = 2
     assert u == [[0, 1], [2, 3], [4, 5], [6, 7]] and r == [[0, 2], [1, 3], [4, 6], [5, 7]]
+
+
+# ---- ABI: header == ctypes binding == INTEGRATION.md stub == compiled layout -----------------------------------
+_CTYPE = {"int32_t": "c_int", "int64_t": "c_long", "float": "c_float", "void*": "c_void_p", "float*": "c_void_p",
+          "const float*": "c_void_p", "const int32_t*": "c_void_p", "int32_t*": "c_void_p", "usp_tensor": "T"}
+
+
+def _header_structs():
+    """{struct name: [(C type, field name), ...]} parsed from include/usp_hip.h."""
+    import re
+    text = open(os.path.join(ROOT, "include", "usp_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef struct \w+ \{(.*?)\} (\w+);", text, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            ctype, names = decl.rsplit(" ", 1)[0], decl
+            m = re.match(r"(const )?(\w+)( ?\*)? (.+)", decl)
+            ctype = (m.group(1) or "") + m.group(2) + ("*" if m.group(3) else "")
+            for n in m.group(4).split(","):
+                fields.append((ctype, n.strip()))
+        out[name] = fields
+    return out
+
+
+def _ctypes_fields(cls):
+    return [(n, getattr(t, "__name__")) for n, t in cls._fields_]
+
+
+def test_abi_structs_match_the_header(tmp_path):
+    """One field list, four places: include/usp_hip.h, the ctypes binding (_C.py), the stub INTEGRATION.md shows a
+    maintainer of the reference, and the layout gcc gives the header (sizeof / offsetof)."""
+    import ctypes
+    import re
+    import subprocess
+    from yunchang_amd import _C
+    H = _header_structs()
+    assert set(H) == {"usp_tensor", "usp_fwd_args", "usp_bwd_args"}
+    # (1) the stub in INTEGRATION.md: exec its struct definitions
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    a, b = md.index("i32, i64, f32, vp ="), md.index("assert _L.usp_abi_version()")
+    ns = {"ctypes": ctypes}
+    exec(md[a:b], ns)
+    pairs = {"usp_tensor": (_C.UspTensor, ns["T"]), "usp_fwd_args": (_C.UspFwdArgs, ns["FwdArgs"]),
+             "usp_bwd_args": (_C.UspBwdArgs, ns["BwdArgs"])}
+    # (2) a compiled probe of the header
+    src = tmp_path / "probe.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "usp_hip.h"', 'int main(void) {']
+    for sname, fields in H.items():
+        lines.append(f'  printf("{sname} %zu\\n", sizeof({sname}));')
+        lines += [f'  printf("{sname}.{n} %zu\\n", offsetof({sname}, {n}));' for _, n in fields]
+    lines += ['  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    layout = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for sname, fields in H.items():
+        for cls in pairs[sname]:
+            got = _ctypes_fields(cls)
+            assert [n for n, _ in got] == [n for _, n in fields], f"{sname}: field names of {cls.__name__} differ"
+            for (n, tname), (ctype, _) in zip(got, fields):
+                want = _CTYPE[ctype]
+                assert tname == want or (want == "T" and tname in ("T", "UspTensor")), f"{sname}.{n}: {tname} vs {ctype}"
+                assert getattr(cls, n).offset == int(layout[f"{sname}.{n}"]), f"{sname}.{n}: offset"
+            assert ctypes.sizeof(cls) == int(layout[sname]), f"sizeof({sname}) vs {cls.__name__}"
+    assert _C.ABI_VERSION == int(re.search(r"#define USP_ABI_VERSION (\d+)", open(
+        os.path.join(ROOT, "include", "usp_hip.h")).read()).group(1))

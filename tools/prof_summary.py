@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 rocpd databases (gpurun_out/prof_*/**.db) into small text files for profiles/.
 
-usage: tools/prof_summary.py <prof_dir> <out.txt>
+usage: tools/prof_summary.py <prof_dir> <out.txt> [B S H D]      (shape of the profiled launches, default C2)
+  * a DERIVED table per flash kernel, combining the separate PMC passes: MFMA-pipe utilisation, sustained
+    clock, HBM GB/s against the 8 TB/s peak, executed and algorithmic TFLOP/s against the 2.5 PFLOP/s roof;
   * every *_results.db: per-kernel call count / total / average duration (the --stats view);
   * databases with PMC events: per kernel, counter values summed over instances per dispatch and
     averaged over dispatches; HBM bytes derived as the MI355X guide prescribes
@@ -14,14 +16,78 @@ import sys
 from collections import defaultdict
 
 
+def ev_db(c):
+    try:
+        return c.execute("select count(*) from pmc_events").fetchone()[0] > 0
+    except sqlite3.Error:
+        return False
+
+
 def short(name):
     name = name.replace("void ", "")
     return name if len(name) < 90 else name[:87] + "..."
 
 
+SIMDS, XCDS, PEAK_TF, PEAK_HBM = 1024, 8, 2500.0, 8000.0      # MI355X: 256 CUs x 4 SIMDs; dense bf16; GB/s
+
+# (substring of the kernel name, label, matmuls the kernel EXECUTES, matmuls it is credited with algorithmically)
+# in units of one S x S x D matmul pair: forward = 2 matmuls = 4 B H S^2 D / 2 FLOPs (causal)
+FLASH = [("flash_fwd_kernel", "forward", 2, 2), ("flash_bwd_dkdv_kernel", "backward dK/dV", 4, None),
+         ("flash_bwd_kernel", "backward dQ", 3, None)]
+
+
+def derived(merged, shape):
+    """merged: {kernel name: {counter or 'dur_us': average}} over all passes of the profile directory."""
+    B, S, H, D = shape
+    mm = 2.0 * B * H * S * S * D * 0.5                           # one causal matmul, FLOPs
+    out = ["==== DERIVED (per launch; counters from separate rocprofv3 passes of the same command)",
+           f"  shape B={B} S={S} H={H} D={D} causal bf16; peaks: {PEAK_TF:.0f} TFLOP/s dense bf16 MFMA at 2.4 GHz, "
+           f"{PEAK_HBM:.0f} GB/s HBM"]
+    bwd_us = 0.0
+    for key, label, executed, _ in FLASH:
+        names = [n for n in merged if key in n and "dur_us" in merged[n]]
+        if not names:
+            continue
+        cv = merged[max(names, key=lambda n: merged[n].get("n_dur", 0))]
+        us = cv["dur_us"]
+        line = f"  {label:16s} {us:9.1f} us | executed MFMA {executed * mm / us / 1e6:7.1f} TFLOP/s = " \
+               f"{executed * mm / us / 1e6 / PEAK_TF * 100:4.1f} % of roof"
+        if "GRBM_GUI_ACTIVE" in cv:                              # every ratio uses the duration of its OWN pass
+            clk = cv["GRBM_GUI_ACTIVE"] / XCDS / cv["us:GRBM_GUI_ACTIVE"] / 1e3          # GHz
+            line += f" | sustained clock {clk:4.2f} GHz"
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in cv:
+                util = cv["SQ_VALU_MFMA_BUSY_CYCLES"] / (SIMDS * clk * 1e3 * cv["us:SQ_VALU_MFMA_BUSY_CYCLES"])
+                line += f" | MFMA pipe busy {util * 100:4.1f} % of cycles"
+        if "FETCH_SIZE" in cv and "WRITE_SIZE" in cv:
+            mb = (cv["FETCH_SIZE"] * 2 + cv["WRITE_SIZE"]) * 1024 / 1e6
+            gbs = (cv["FETCH_SIZE"] * 2 * 1024 / cv["us:FETCH_SIZE"] + cv["WRITE_SIZE"] * 1024 / cv["us:WRITE_SIZE"]) / 1e3
+            line += f" | HBM {mb:7.1f} MB -> {gbs:6.0f} GB/s = {gbs / PEAK_HBM * 100:4.1f} % of peak"
+            out_lines_hbm = (cv["FETCH_SIZE"] * 2 * 1024 / 1e6, cv["WRITE_SIZE"] * 1024 / 1e6)
+            out.append(line)
+            out.append(f"  {'':16s} {key}: HBM read bytes/launch  = {out_lines_hbm[0]:.1f} MB (FETCH_SIZE KiB x2 gfx950 correction)")
+            out.append(f"  {'':16s} {key}: HBM write bytes/launch = {out_lines_hbm[1]:.1f} MB (WRITE_SIZE KiB, uncalibrated)")
+            line = None
+        if line:
+            out.append(line)
+        if key == "flash_fwd_kernel":
+            out.append(f"  {'':16s} algorithmic {2 * mm / us / 1e6:7.1f} TFLOP/s = roofline fraction "
+                       f"{2 * mm / us / 1e6 / PEAK_TF:.4f}")
+        else:
+            bwd_us += us
+    extra = [merged[n]["dur_us"] for n in merged if ("delta_kernel" in n or "reduce_heads" in n) and "dur_us" in merged[n]]
+    if bwd_us:
+        tot = bwd_us + sum(extra)
+        out.append(f"  {'backward, all':16s} {tot:9.1f} us | algorithmic (5 matmuls) {5 * mm / tot / 1e6:7.1f} TFLOP/s = "
+                   f"roofline fraction {5 * mm / tot / 1e6 / PEAK_TF:.4f}; executed (7 matmuls) "
+                   f"{7 * mm / bwd_us / 1e6:7.1f} TFLOP/s")
+    return out
+
+
 def main():
     prof_dir, out_path = sys.argv[1], sys.argv[2]
+    shape = tuple(int(x) for x in sys.argv[3:7]) if len(sys.argv) >= 7 else (2, 8192, 16, 128)
     lines = []
+    merged = defaultdict(dict)
     for db in sorted(glob.glob(os.path.join(prof_dir, "**", "*_results.db"), recursive=True)):
         rel = os.path.relpath(db, prof_dir)
         c = sqlite3.connect(db)
@@ -34,6 +100,8 @@ def main():
         lines.append(f"  {'kernel':90s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'%':>6s}")
         for n, calls, tot, avg, pct in rows[:8]:
             lines.append(f"  {short(n):90s} {calls:6d} {tot:12.1f} {avg:10.2f} {pct:6.2f}")
+            if not ev_db(c) and calls > merged[n].get("n_dur", 0):      # durations from un-instrumented passes only
+                merged[n]["dur_us"], merged[n]["n_dur"] = avg, calls
         try:
             ev = c.execute("select name, dispatch_id, counter_name, sum(counter_value), max(duration) "
                            "from pmc_events group by name, dispatch_id, counter_name").fetchall()
@@ -51,6 +119,9 @@ def main():
                 lines.append(f"  PMC {short(n)}  (dispatches {len(next(iter(agg[n].values())))}, avg dur "
                              f"{sum(dur[n]) / len(dur[n]) / 1e3:.1f} us)")
                 cv = {cn: sum(v) / len(v) for cn, v in agg[n].items()}
+                for cn, val in cv.items():
+                    if cn not in merged[n]:                    # the pass's own duration goes with its counter
+                        merged[n][cn], merged[n]["us:" + cn] = val, sum(dur[n]) / len(dur[n]) / 1e3
                 for cn in sorted(cv):
                     lines.append(f"      {cn:28s} {cv[cn]:18.1f}")
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in cv and "SQ_BUSY_CYCLES" in cv and cv["SQ_BUSY_CYCLES"]:
@@ -67,6 +138,11 @@ def main():
                                  f"(FETCH_SIZE KiB x2 gfx950 correction; raw {cv['FETCH_SIZE'] * 1024 / 1e6:.1f} MB)")
                 if "WRITE_SIZE" in cv:
                     lines.append(f"      -> HBM write bytes/launch = {cv['WRITE_SIZE'] * 1024 / 1e6:.1f} MB (WRITE_SIZE KiB, uncalibrated)")
+    head = []
+    sha = os.environ.get("USP_KERNEL_SRC_SHA16")
+    if sha:
+        head.append(f"kernel_src_sha16: {sha}")
+    lines = head + derived(merged, shape) + lines
     open(out_path, "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
 
