@@ -38,9 +38,15 @@ class _USPLayer(torch.nn.Module):
         ), f"use set_seq_parallel_pg() first. Now ulysses pg {self.ulysses_pg} and ring pg {self.ring_pg}"
         self.scatter_idx, self.gather_idx = scatter_idx, gather_idx
         self.use_sync, self.attn_type = use_sync, attn_type
-        # the grid is fixed once the groups exist: no torch.distributed queries on the per-step path
-        self.ulysses_size = dist.get_world_size(self.ulysses_pg)
-        self.ring_size = dist.get_world_size(self.ring_pg)
+        self._ulysses_size = None
+
+    @property
+    def ulysses_size(self) -> int:
+        """Ulysses degree; the grid is fixed once the groups exist, so torch.distributed is asked once (on the
+        first forward -- the constructor, like the reference's, only checks that a group is set)."""
+        if self._ulysses_size is None:
+            self._ulysses_size = dist.get_world_size(self.ulysses_pg)
+        return self._ulysses_size
 
     def _ring_options(self, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
                       return_attn_probs):
