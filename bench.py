@@ -170,7 +170,8 @@ def kernel_roofline(cfg, dev, iters=20):
     the kernel is launched on, plus the forward+backward kernels of the same shape and of the metric's own
     sequence length on one GPU (S = 65536, BASELINE.json configs[4]'s global shape: it fits one MI355X)."""
     B, S, Hq, Hkv, D = cfg["B"], cfg["S"], cfg["Hq"], cfg["Hkv"], cfg["D"]
-    t = _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, iters)
+    _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, 300)                # ~0.5 s of work first: measure at sustained clocks,
+    t = _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, iters)          # not on the DVFS ramp of a device that was idle
     frac = lambda x: round(x / PEAK_BF16_TFLOPS, 4)
     roof = {"bound": "mfma", "kernel": "usp::flash_fwd_kernel<128,bf16,causal>", "achieved": round(t["fwd"], 1),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": frac(t["fwd"]),

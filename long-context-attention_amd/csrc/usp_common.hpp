@@ -178,6 +178,9 @@ struct ItemQueue {
 
 // Thread 0 only.  Deliberately NOT inlined: called once per item, when almost nothing is live, so the call
 // costs nothing, while its divisions and loop state inlined into the flash kernels cost 40-70 spilled VGPRs.
+// The queue is passed BY REFERENCE on purpose: that is the 48-byte private segment (4 scratch stores, once, at
+// kernel entry, none in any loop) the kernels report.  By value the call pins the struct in argument registers
+// across the whole kernel and the flash kernels spill 37-70 VGPRs instead (tried in round 2).
 // `state` = lists already drained by this workgroup; returns the item (bh * n_t + t) or -1.
 #ifdef USP_QINLINE
 USP_DEV int item_queue_fetch(

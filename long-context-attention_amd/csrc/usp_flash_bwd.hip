@@ -74,6 +74,10 @@ USP_DEV bool bind_sequence(BwdParams& p, int b, int64_t* ws_row0) {
 
 constexpr int kTile = 64;           // streamed rows per LDS tile
 
+#ifndef USP_BWD_G      // MFMA slots per pinned scheduling group (A/B builds; 1 = every slot fenced)
+#define USP_BWD_G 1
+#endif
+
 // Swizzle of the 16-byte slot index inside a row-major [rows][D] 16-bit tile.
 template <int D> USP_DEV int tile_swz(int row) {
   if (D == 128) return ((row & 3) << 2) | ((row >> 2) & 3);
@@ -455,7 +459,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 #pragma unroll
             for (int pi = sl * 2 * CPW / NST; pi < (sl + 1) * 2 * CPW / NST; ++pi) stage_piece(pi);
           }
-          __builtin_amdgcn_sched_barrier(0);
+          if (sl % USP_BWD_G == USP_BWD_G - 1) __builtin_amdgcn_sched_barrier(0);
         }
       };
       // gradient phase of half h; `vh` >= 0: interleave the element work of half vh
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 #pragma unroll
             for (int e = i * 16 / NGR; e < (i + 1) * 16 / NGR; ++e) elem(vh, e);
           }
-          __builtin_amdgcn_sched_barrier(0);
+          if (i % USP_BWD_G == USP_BWD_G - 1) __builtin_amdgcn_sched_barrier(0);
         }
       };
 
@@ -821,7 +825,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
 #pragma unroll
                 for (int e = kt * 16 / NKT; e < (kt + 1) * 16 / NKT; ++e) elem(vh, e);
               }
-              __builtin_amdgcn_sched_barrier(0);
+              if (kt % USP_BWD_G == USP_BWD_G - 1) __builtin_amdgcn_sched_barrier(0);
             }
           };
           auto grad_phase = [&](int h, int vh) {
@@ -845,7 +849,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
 #pragma unroll
                 for (int e = i * 16 / NGR; e < (i + 1) * 16 / NGR; ++e) elem(vh, e);
               }
-              __builtin_amdgcn_sched_barrier(0);
+              if (i % USP_BWD_G == USP_BWD_G - 1) __builtin_amdgcn_sched_barrier(0);
             }
           };
           auto apply_mask = [&](int h) {                         // role A only: query row i sees key j iff j <= i + off

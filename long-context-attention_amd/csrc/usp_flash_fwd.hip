@@ -359,6 +359,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
 #ifndef USP_PF
 #define USP_PF 2
 #endif
+#ifndef USP_FWD_G      // MFMA slots per pinned scheduling group (A/B builds; 1 = every slot fenced)
+#define USP_FWD_G 1
+#endif
     constexpr int PF = USP_PF;                                  // LDS fragment prefetch distance (k-steps / MFMAs)
 #pragma unroll
     for (int t = 0; t < PF && t < NKT; ++t) rd_k(t);
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       }
 #pragma unroll
       for (int e = sl * 24 / NA; e < (sl + 1) * 24 / NA; ++e) exp_elem(e);
-      __builtin_amdgcn_sched_barrier(0);
+      if (sl % USP_FWD_G == USP_FWD_G - 1) __builtin_amdgcn_sched_barrier(0);
     }
     // ---------------- phase B ----------------
     USP_LDS const char* vb = smem + (jj & 1) * KBYTES + v_rd;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
 #pragma unroll
       for (int e = i * 32 / NB; e < (i + 1) * 32 / NB; ++e)   // row-max chain of S(jj+1)
         mt = fmaxf(mt, e < 16 ? na[e] : nb[e - 16]);
-      __builtin_amdgcn_sched_barrier(0);
+      if (i % USP_FWD_G == USP_FWD_G - 1) __builtin_amdgcn_sched_barrier(0);
     }
     l_run += rs;
     decide(xhalf_max(mt));

@@ -160,23 +160,31 @@ class _HipAttnFunc(torch.autograd.Function):
     yunchang/ulysses/attn_layer.py:48,101-113)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, softmax_scale, causal):
+    def forward(ctx, q, k, v, softmax_scale, causal, return_lse):
         scale = _default_scale(q, softmax_scale)
         out, lse = hip_attn_forward(q, k, v, softmax_scale=scale, causal=causal)
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.scale, ctx.causal = scale, bool(causal)
+        if return_lse:
+            ctx.mark_non_differentiable(lse)
+            return out, lse
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, *_):
         q, k, v, out, lse = ctx.saved_tensors
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         hip_attn_backward(dout, q, k, v, out, lse, dq, dk, dv, 0.0, ctx.scale, ctx.causal)
-        return dq, dk, dv, None, None
+        return dq, dk, dv, None, None, None
 
 
 def hip_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
                   softcap=0.0, alibi_slopes=None, deterministic=False, return_attn_probs=False,
                   *args, **kwargs):
+    """`fwd-bwd` contract (flash_attn_func's signature): `out`, or `(out, softmax_lse, None)` with
+    return_attn_probs (the probabilities themselves are never materialised: dropout is 0)."""
     _check_plain(dropout_p, window_size, softcap, alibi_slopes)
-    return _HipAttnFunc.apply(q, k, v, softmax_scale, causal)
+    if return_attn_probs:
+        out, lse = _HipAttnFunc.apply(q, k, v, softmax_scale, causal, True)
+        return out, lse, None
+    return _HipAttnFunc.apply(q, k, v, softmax_scale, causal, False)
