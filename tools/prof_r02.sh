@@ -8,8 +8,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
-KBF="$R/long-context-attention_amd/kbench fwd 2 8192 8192 16 16 128 1 0 0 20"
-KBB="$R/long-context-attention_amd/kbench bwd 2 8192 8192 16 16 128 1 0 0 5"
+KBF="$R/long-context-attention_amd/kbench fwd 2 8192 8192 16 16 128 1 0 0 60"
+KBB="$R/long-context-attention_amd/kbench bwd 2 8192 8192 16 16 128 1 0 0 12"
 rocprofv3 --kernel-trace --stats -d $OUT/bench -o bench -- python $R/bench.py --no-cpu-baseline > $OUT/bench_stdout.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/fwd -o fwd -- $KBF > $OUT/fwd.log 2>&1
 rocprofv3 --kernel-trace --stats -d $OUT/bwd -o bwd -- $KBB > $OUT/bwd.log 2>&1

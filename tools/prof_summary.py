@@ -100,7 +100,9 @@ def main():
         lines.append(f"  {'kernel':90s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'%':>6s}")
         for n, calls, tot, avg, pct in rows[:8]:
             lines.append(f"  {short(n):90s} {calls:6d} {tot:12.1f} {avg:10.2f} {pct:6.2f}")
-            if not ev_db(c) and calls > merged[n].get("n_dur", 0):      # durations from un-instrumented passes only
+            # durations: un-instrumented passes of the fixed-shape harness only (the bench pass also launches
+            # the same kernels at other shapes)
+            if not ev_db(c) and not rel.startswith("bench") and calls > merged[n].get("n_dur", 0):
                 merged[n]["dur_us"], merged[n]["n_dur"] = avg, calls
         try:
             ev = c.execute("select name, dispatch_id, counter_name, sum(counter_value), max(duration) "
