@@ -45,6 +45,24 @@ def test_local_row_ranges_match_extract_layout(n):
         assert np.array_equal(got, want), (rank, got, want)
 
 
+@pytest.mark.parametrize("n", [1, 8])
+def test_parity_check_finds_a_wrong_row(n):
+    """bench.parity_check on host tensors (no aten efficient op there -> None for that leg): an exact shard passes
+    the sampled fp64 rows, a shard with one corrupted sampled row (the last owned row is always sampled) does not."""
+    b = _bench()
+    cfg = dict(b.WORKLOADS[n]); cfg.update(S=32 * n, B=1, Hq=4, Hkv=2, D=16)
+    g = torch.Generator().manual_seed(3)
+    q, k, v = (torch.randn((1, cfg["S"], h, 16), generator=g) for h in (4, 2, 2))
+    full, _ = O.attention_ref(*(t.numpy().astype(np.float64) for t in (q, k, v)), causal=True)
+    rank = n - 1
+    shard = torch.from_numpy(O.EXTRACT[cfg["impl"]](full, rank, n, cfg["rd"], cfg["ud"])).float()
+    op_err, row_err = b.parity_check(cfg, rank, n, shard, q, k, v)
+    assert op_err is None and row_err < 1e-5
+    bad = shard.clone(); bad[:, -1] += 0.5
+    assert b.parity_check(cfg, rank, n, bad, q, k, v)[1] > 0.4
+    assert len(b.kernel_source_sha16()) == 16 and b.pmc_traffic() in (None, b.pmc_traffic())
+
+
 def _probe_worker(rank, ws):
     import torch.distributed as dist
     import yunchang_amd as Y
