@@ -2,10 +2,11 @@
 
 MI355X-first differences (results identical):
   * one HBM pass per exchange instead of two: the reference copies before AND after
-    `all_to_all_single` (all_to_all.py:45-49 and :62-65 / :76-84 and :98-100).  Here the receive
-    buffer of the head-scatter exchange is returned as a strided (B,S,H/P,D) VIEW of its natural
+    `all_to_all_single` (all_to_all.py:45-49 and :62-65 / :76-84 and :98-100).  Inside this package the
+    receive buffer of the head-scatter exchange is used as a strided (B,S,H/P,D) VIEW of its natural
     (S,B,H/P,D) layout -- the attention kernels take strides -- and the send buffer of the
-    sequence-scatter exchange is that same layout, which the kernels write directly;
+    sequence-scatter exchange is that same layout, which the kernels write directly (the PUBLIC
+    functions and autograd Functions return contiguous tensors like the reference's unless asked not to);
   * the remaining pack / unpack is one `usp_copy_rows` launch (16-byte lanes, rows of H/P*D);
   * P == 1 moves no bytes at all (the reference still makes two copies).
 The collective itself is `torch.distributed.all_to_all_single` == RCCL over xGMI on ROCm.
@@ -167,27 +168,31 @@ def all_to_all_4D(input: torch.Tensor, scatter_idx: int = 2, gather_idx: int = 1
 
 
 class SeqAllToAll4D(torch.autograd.Function):
-    """all_to_all.py:105-134: forward = the exchange, backward = the inverse exchange."""
+    """all_to_all.py:105-134: forward = the exchange, backward = the inverse exchange.  Like the reference the
+    result is CONTIGUOUS.  The layers of this package pass `contiguous=False` (a sixth positional argument the
+    reference does not have): the head-scatter result is then the strided (B,S,H/P,D) VIEW of the receive buffer,
+    which the attention kernels consume directly (they take strides) -- one HBM pass less per exchange."""
 
     @staticmethod
     def forward(ctx: Any, group, input: Tensor, scatter_idx: int, gather_idx: int,
-                use_sync: bool = False) -> Tensor:
+                use_sync: bool = False, contiguous: bool = True) -> Tensor:
         ctx.group = group
         ctx.scatter_idx = scatter_idx
         ctx.gather_idx = gather_idx
         ctx.use_sync = use_sync
+        ctx.contiguous = contiguous
         if scatter_idx == 2 and gather_idx == 1:
-            return heads_to_seq(input, group, use_sync)
+            return heads_to_seq(input, group, use_sync, contiguous=contiguous)
         if scatter_idx == 1 and gather_idx == 2:
             return seq_to_heads(input, group, use_sync)
         raise RuntimeError("scatter_idx must be 1 or 2 and gather_idx must be 1 or 2")
 
     @staticmethod
-    def backward(ctx: Any, *grad_output: Tensor) -> Tuple[None, Tensor, None, None, None]:
+    def backward(ctx: Any, *grad_output: Tensor) -> Tuple[None, Tensor, None, None, None, None]:
         return (None,
                 SeqAllToAll4D.apply(ctx.group, grad_output[0], ctx.gather_idx, ctx.scatter_idx,
-                                    ctx.use_sync),
-                None, None, None)
+                                    ctx.use_sync, ctx.contiguous),
+                None, None, None, None)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -264,22 +269,25 @@ def all_to_all_5D(input: torch.Tensor, scatter_idx: int = 3, gather_idx: int = 1
 
 
 class SeqAllToAll5D(torch.autograd.Function):
+    """all_to_all.py:236-259; `contiguous` as in SeqAllToAll4D."""
+
     @staticmethod
     def forward(ctx: Any, group, input: Tensor, scatter_idx: int = 3, gather_idx: int = 1,
-                use_sync: bool = False) -> Tensor:
+                use_sync: bool = False, contiguous: bool = True) -> Tensor:
         ctx.group = group
         ctx.scatter_idx = scatter_idx
         ctx.gather_idx = gather_idx
         ctx.use_sync = use_sync
+        ctx.contiguous = contiguous
         if scatter_idx == 3 and gather_idx == 1:
-            return heads_to_seq_5d(input, group, use_sync)
+            return heads_to_seq_5d(input, group, use_sync, contiguous=contiguous)
         if scatter_idx == 1 and gather_idx == 3:
             return seq_to_heads_5d(input, group, use_sync)
         raise RuntimeError("scatter_idx must be 1 or 3 and gather_idx must be 1 or 3")
 
     @staticmethod
-    def backward(ctx: Any, *grad_output: Tensor) -> Tuple[None, Tensor, None, None, None]:
+    def backward(ctx: Any, *grad_output: Tensor) -> Tuple[None, Tensor, None, None, None, None]:
         return (None,
                 SeqAllToAll5D.apply(ctx.group, grad_output[0], ctx.gather_idx, ctx.scatter_idx,
-                                    ctx.use_sync),
-                None, None, None)
+                                    ctx.use_sync, ctx.contiguous),
+                None, None, None, None)

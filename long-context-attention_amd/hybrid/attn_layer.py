@@ -114,11 +114,11 @@ class LongContextAttention(_USPLayer):
         if self.ulysses_size == 1:      # nothing to exchange (the reference still makes 8 layout copies here)
             return _first(self.ring_attn_fn(query, key, value, attn_processor=self.attn_processor, **options))
         # sequence shards -> head shards: (bs, seq_len/N, heads, d) -> (bs, seq_len, heads/N, d)
-        q, k, v = (SeqAllToAll4D.apply(self.ulysses_pg, t, self.scatter_idx, self.gather_idx, self.use_sync)
+        q, k, v = (SeqAllToAll4D.apply(self.ulysses_pg, t, self.scatter_idx, self.gather_idx, self.use_sync, False)
                    for t in (query, key, value))
         context = _first(self.ring_attn_fn(q, k, v, attn_processor=self.attn_processor, **options))
         # ... and back: (bs, seq_len, heads/N, d) -> (bs, seq_len/N, heads, d)
-        return SeqAllToAll4D.apply(self.ulysses_pg, context, self.gather_idx, self.scatter_idx, self.use_sync)
+        return SeqAllToAll4D.apply(self.ulysses_pg, context, self.gather_idx, self.scatter_idx, self.use_sync, False)
 
 
 class LongContextAttentionQKVPacked(_USPLayer):
@@ -137,11 +137,11 @@ class LongContextAttentionQKVPacked(_USPLayer):
                 *args: Any) -> Tensor:
         exchange = self.ulysses_size > 1
         if exchange:         # scatter 3 (heads), gather 1 (sequence)
-            qkv = SeqAllToAll5D.apply(self.ulysses_pg, qkv, self.scatter_idx, self.gather_idx, self.use_sync)
+            qkv = SeqAllToAll5D.apply(self.ulysses_pg, qkv, self.scatter_idx, self.gather_idx, self.use_sync, False)
         out = _first(self.ring_attn_fn(qkv, **self._ring_options(dropout_p, softmax_scale, causal, window_size,
                                                                   softcap, alibi_slopes, deterministic,
                                                                   return_attn_probs)))
         if exchange:         # (bs, seq_len, head_cnt/N, head_size) -> (bs, seq_len/N, head_cnt, head_size)
             out = SeqAllToAll4D.apply(self.ulysses_pg, out, self.gather_idx, self.scatter_idx - 1,
-                                      self.use_sync)
+                                      self.use_sync, False)
         return out

@@ -27,10 +27,10 @@ class UlyssesAttention(torch.nn.Module):
         self.attn_fn = select_flash_attn_impl(attn_type, stage="fwd-bwd")
 
     def _to_heads(self, x: Tensor) -> Tensor:      # (bs, seq/N, heads, d) -> (bs, seq, heads/N, d)
-        return SeqAllToAll4D.apply(self.spg, x, self.scatter_idx, self.gather_idx, self.use_sync)
+        return SeqAllToAll4D.apply(self.spg, x, self.scatter_idx, self.gather_idx, self.use_sync, False)
 
     def _to_seq(self, x: Tensor) -> Tensor:        # (bs, seq, heads/N, d) -> (bs, seq/N, heads, d)
-        return SeqAllToAll4D.apply(self.spg, x, self.gather_idx, self.scatter_idx, self.use_sync)
+        return SeqAllToAll4D.apply(self.spg, x, self.gather_idx, self.scatter_idx, self.use_sync, False)
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, dropout_p=0.0, softmax_scale=None,
                 causal=False, window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,

@@ -102,6 +102,7 @@ def nccl_single():
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(900)
 def test_ring_backward_ordering_through_rccl_self_sendrecv(nccl_single, monkeypatch):
     import yunchang_amd.ring.utils as U
     import yunchang_amd.ring.zigzag_ring_flash_attn as Z
