@@ -12,7 +12,7 @@ import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
 
-__all__ = ["update_out_and_lse", "RingComm", "KVRelay", "travel_dkdv", "final_grads"]
+__all__ = ["update_out_and_lse", "RingComm", "KVRelay", "ZigzagKVFetch", "kv_relay_mode", "travel_dkdv", "final_grads"]
 
 
 def update_out_and_lse(out: Optional[torch.Tensor], lse: Optional[torch.Tensor],
@@ -133,8 +133,7 @@ class KVRelay:
             self._stream.wait_stream(self._main)          # k, v are produced on the compute stream
         recv = self._recv_slots(k, v, dist.get_rank(process_group))
         ctx = torch.cuda.stream(self._stream) if cuda else _NullCtx()
-        mode = os.environ.get("USP_KV_RELAY", "direct" if self.P > 2 else "chain")
-        if mode == "direct":
+        if kv_relay_mode(self.P) == "direct":
             with ctx:
                 r = dist.get_rank(process_group)
                 to_global = lambda i: dist.get_global_rank(process_group, i % self.P) if process_group is not None else i % self.P
@@ -200,6 +199,95 @@ class KVRelay:
     def __exit__(self, *exc):
         self.finish()
         return False
+
+
+class ZigzagKVFetch:
+    """K/V transport of the zigzag FORWARD for ring degree > 2: the direct mesh fetch of KVRelay, in two waves and
+    without the bytes the schedule never reads.
+
+    With the local sequence = [chunk r | chunk 2P-1-r], ring step s of rank r reads the K/V of rank r-s: only its
+    FRONT half rows when s <= r, both halves (against the back half of q) when s > r
+    (zigzag_ring_flash_attn.py:54-67).  So
+      wave A (one grouped send/recv): every rank sends the front half of its K/V to all P-1 peers;
+      wave B (one grouped send/recv): the back half goes only to the peers that read it (destination rank
+              (r+s) mod P with r+s >= P), a quarter of all K/V bytes is never sent;
+    and the attention of a step that needs both halves is two launches -- front-half keys as soon as wave A has
+    landed, back-half keys merged in by the kernel's fused LSE merge once wave B has.  Where the ring is
+    link-bound (BASELINE's 4-GPU config: 64 MiB of K/V per peer = ~1 ms per xGMI link against ~1 ms of attention
+    per rank) the compute that waits for the wire shrinks from three ring steps to three half steps, and every
+    rank has work from the middle of the transfer on.  Both waves run on the "ring" side stream; receive slots are
+    persistent like KVRelay's.  Context manager, like KVRelay."""
+
+    _SLOTS = {}
+
+    def __init__(self, process_group, k: torch.Tensor, v: torch.Tensor):
+        P = self.P = dist.get_world_size(process_group)
+        r = self.r = dist.get_rank(process_group)
+        assert P > 2 and k.shape[1] % 2 == 0
+        c = k.shape[1] // 2
+        mine = [[t[:, :c].contiguous() for t in (k, v)], [t[:, c:].contiguous() for t in (k, v)]]   # views at B = 1
+        cuda = k.is_cuda
+        self._stream = None
+        if cuda:
+            self._stream = _side_stream(k.device, "ring")
+            self._stream.wait_stream(torch.cuda.current_stream())     # k, v are produced on the compute stream
+        key = (tuple(mine[0][0].shape), tuple(mine[0][1].shape), k.dtype, k.device.index if cuda else -1, P, r)
+        slots = ZigzagKVFetch._SLOTS.get(key) if cuda else None
+        if slots is None:       # slots[half][s - 1] = (k_half, v_half) of source rank r - s
+            slots = [[tuple(torch.empty_like(t) for t in mine[h]) for _ in range(P - 1)] for h in (0, 1)]
+            if cuda:
+                ZigzagKVFetch._SLOTS[key] = slots
+        self.slots = slots
+        to_global = lambda i: dist.get_global_rank(process_group, i % P) if process_group is not None else i % P
+        self.events = [None, None]
+        with (torch.cuda.stream(self._stream) if cuda else _NullCtx()):
+            for half in (0, 1):
+                comm = RingComm(process_group)
+                for s in range(1, P):
+                    if half == 0 or r + s >= P:          # destination (r+s) % P reads my back half: its step s > its rank
+                        comm._ops += [dist.P2POp(dist.isend, t, to_global(r + s), group=process_group) for t in mine[half]]
+                    if half == 0 or s > r:               # I read the back half of source r - s
+                        comm._ops += [dist.P2POp(dist.irecv, t, to_global(r - s), group=process_group)
+                                      for t in slots[half][s - 1]]
+                comm.commit()
+                comm.wait()
+                if cuda:
+                    self.events[half] = torch.cuda.Event()
+                    self.events[half].record(self._stream)
+            for t in mine[0] + mine[1]:
+                if cuda:
+                    t.record_stream(self._stream)
+
+    def _get(self, half, step):
+        if self.events[half] is not None:
+            torch.cuda.current_stream().wait_event(self.events[half])
+        return self.slots[half][step - 1]
+
+    def front(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Front-half K, V of ring rank r - step (rows [0, c)); the compute stream waits for wave A."""
+        return self._get(0, step)
+
+    def back(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Back-half K, V of ring rank r - step; only fetched for the steps that read it (step > rank)."""
+        assert step > self.r, "the zigzag schedule never reads this half"
+        return self._get(1, step)
+
+    def finish(self):
+        if self._stream is not None:
+            torch.cuda.current_stream().wait_stream(self._stream)
+            self._stream = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.finish()
+        return False
+
+
+def kv_relay_mode(P: int) -> str:
+    """"direct" (mesh fetch) or "chain" (hop-by-hop relay): USP_KV_RELAY, default direct for ring degree > 2."""
+    return os.environ.get("USP_KV_RELAY", "direct" if P > 2 else "chain")
 
 
 def travel_dkdv(process_group, k, v, block, fold, zero: bool = False):

@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 from ..kernels import AttnType
 from ..kernels.attention import get_block_backend
-from .utils import KVRelay, final_grads, travel_dkdv
+from .utils import KVRelay, ZigzagKVFetch, final_grads, kv_relay_mode, travel_dkdv
 
 
 
@@ -88,6 +88,21 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
         be.fwd(q, k, v, softmax_scale, True, lse, out)
         return out, lse
     acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev)
+    if P > 2 and kv_relay_mode(P) == "direct":      # mesh fetch in two waves, only the halves the schedule reads
+        c = S2 // 2
+        with ZigzagKVFetch(process_group, k, v) as fetch:
+            zigzag_fwd_step(be, r, P, 0, q, k, v, softmax_scale, lse, out, acc)
+            for step in range(1, P):
+                last = step == P - 1
+                kf, vf = fetch.front(step)
+                if step <= r:                           # :54-58
+                    zigzag_fwd_step(be, r, P, step, q, kf, vf, softmax_scale, lse, out, acc)
+                else:                                   # :59-67 as two launches: front-half keys, then back-half keys
+                    be.fwd(q[:, c:], kf, vf, softmax_scale, False, lse[:, :, c:], out[:, c:], acc[:, c:], True, 0, 0)
+                    kb, vb = fetch.back(step)
+                    be.fwd(q[:, c:], kb, vb, softmax_scale, False, lse[:, :, c:], out[:, c:], acc[:, c:], True, 0,
+                           c if last else 0)
+        return out, lse
     with KVRelay(process_group, k, v) as relay:
         for step in range(P):
             kk, vv = relay.get(step)

@@ -83,10 +83,18 @@ def test_zigzag_schedule_block_shapes():
     c = g.S // (2 * g.rd)
     for r in range(g.ws):
         fwd = [x for x in res[r]["calls"] if x[0] == "fwd"]
-        assert len(fwd) == g.rd
-        for step, (_, qs, ks, causal, merge_in, fb, fe) in enumerate(fwd):
-            assert qs[1] * ks[1] == (4 if step == 0 else 2) * c * c       # causal step 0 does half of 4c^2
-            assert causal == (step == 0) and merge_in == (step > 0)
+        # ring degree 4 takes the two-wave mesh fetch (ring/utils.py:ZigzagKVFetch): a step that reads both K/V
+        # halves (step > rank) is two launches of c x c, front-half keys first
+        assert len(fwd) == g.rd + (g.rd - 1 - r)
+        steps, i = [], 0
+        for step in range(g.rd):
+            n = 2 if step > r else 1
+            steps.append(fwd[i:i + n]); i += n
+        for step, launches in enumerate(steps):
+            assert sum(qs[1] * ks[1] for _, qs, ks, *_ in launches) == (4 if step == 0 else 2) * c * c   # causal step 0: half of 4c^2
+            for _, qs, ks, causal, merge_in, fb, fe in launches:
+                assert causal == (step == 0) and merge_in == (step > 0)
+            assert all(x[6] == x[5] for x in launches[:-1])               # only a step's LAST launch finalises rows
         finals = sorted((x[5], x[6], x[1][1]) for x in fwd if x[6] > x[5])
         emitted = sum(fe - fb for fb, fe, _ in finals)
         assert emitted == 2 * c

@@ -10,7 +10,7 @@ runs the package's real zigzag ring forward / backward (HIP kernels, KVRelay in 
 RingComm); the wire is a 1-rank NCCL group, i.e. RCCL self send/recv (each hop's P sends and P receives are one
 grouped call, matched first-in first-out).  No host synchronisation anywhere: a rank's sends are ordered behind
 its compute by stream events, as ProcessGroupNCCL orders its internal stream behind the caller's current stream,
-and its next kernels behind the receive.  50 iterations must be bit-identical and match the reference golden."""
+and its next kernels behind the receive.  Every iteration must be bit-identical to the first and match the reference golden."""
 import os
 import threading
 
@@ -103,7 +103,8 @@ def nccl_single():
 
 
 @pytest.mark.timeout(900)
-def test_ring_backward_ordering_through_rccl_self_sendrecv(nccl_single, monkeypatch):
+@pytest.mark.parametrize("relay,iters", [("chain", 50), ("direct", 20)])
+def test_ring_backward_ordering_through_rccl_self_sendrecv(nccl_single, monkeypatch, relay, iters):
     import yunchang_amd.ring.utils as U
     import yunchang_amd.ring.zigzag_ring_flash_attn as Z
     real = nccl_single
@@ -123,7 +124,10 @@ def test_ring_backward_ordering_through_rccl_self_sendrecv(nccl_single, monkeypa
     ring = _VirtualRing(P, real)
     for mod in (U, Z):
         monkeypatch.setattr(mod, "dist", ring)
-    monkeypatch.setenv("USP_KV_RELAY", "chain")               # hop-by-hop relay: one event per slot, P-1 grouped calls
+    # "chain": hop-by-hop relay, one event per slot, P-1 grouped calls.  "direct" (the default at ring degree 4): the
+    # forward's two-wave mesh fetch (ZigzagKVFetch: ranks post DIFFERENT numbers of sends / receives per wave) and the
+    # backward's one-call mesh fetch
+    monkeypatch.setenv("USP_KV_RELAY", relay)
     dtype = getattr(torch, g.dtype)
     loc = [[torch.from_numpy(np.ascontiguousarray(g.shard(x, r))).to(dtype).to(dev) for x in (g.q, g.k, g.v, g.dout)]
            for r in range(P)]
@@ -145,7 +149,7 @@ def test_ring_backward_ordering_through_rccl_self_sendrecv(nccl_single, monkeypa
             ring.barrier.abort()
 
     first = None
-    for it in range(50):
+    for it in range(iters):
         res, errs = [None] * P, []
         threads = [threading.Thread(target=run_rank, args=(r, res, errs)) for r in range(P)]
         for t in threads:
