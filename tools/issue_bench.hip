@@ -1,0 +1,78 @@
+// issue_bench -- how many non-MFMA instructions per v_mfma_f32_32x32x16_bf16 can a gfx950 SIMD hide?
+// DEV TOOL (not part of libusp_hip.so).  Every wave runs   loop { 1 MFMA ; K VALU (T of them v_exp_f32) ; L ds_read_b128 }
+// on independent registers (4 rotating accumulators, no data dependence between the fillers and the MFMAs), with W waves
+// per SIMD.  Prints the MFMA throughput relative to the 2.5 PFLOP/s peak.  The flash kernels sit at W = 2 with
+// ~3 VALU + ~1.3 LDS reads + ~1 wait per MFMA and per wave.
+//   build: hipcc --offload-arch=gfx950 -O3 tools/issue_bench.hip -o gpurun_tools/issue_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+#define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
+
+template <int K, int T, int L>
+__global__ __launch_bounds__(512, 2) void issue_kernel(float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  u32x4 a = {0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = a;
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = 0.001f * (lane + i);
+  u32x4 ld[2] = {a, a};
+  const __attribute__((address_space(3))) char* lp = (const __attribute__((address_space(3))) char*)smem + (threadIdx.x & 255) * 16;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[m], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        float& v = x[(m * K + k) & 7];
+        if (k < T) asm volatile("v_exp_f32 %0, %0" : "+v"(v));
+        else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v) : "v"(x[(m * K + k + 1) & 7]));
+      }
+#pragma unroll
+      for (int l = 0; l < L; ++l) {
+        u32x4& d = ld[l & 1];
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(lp), "i"(4096 * ((m * 2 + l) & 7)));
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (L) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  for (int i = 0; i < 8; ++i) s += x[i];
+  s += __builtin_bit_cast(float, ld[0][0]) + __builtin_bit_cast(float, ld[1][1]);
+  if (s == 123.456f) out[threadIdx.x] = s;
+}
+
+template <int K, int T, int L> static void run(float* out, int waves_per_simd) {
+  const int iters = 2000, threads = 256 * waves_per_simd;
+  hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((issue_kernel<K, T, L>), dim3(256), dim3(threads), 40960, 0, out, iters);
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipEventRecord(e0));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((issue_kernel<K, T, L>), dim3(256), dim3(threads), 40960, 0, out, iters);
+  HIP_OK(hipEventRecord(e1)); HIP_OK(hipEventSynchronize(e1));
+  float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
+  const double flops = 256.0 * (threads / 64) * iters * 4 * 32768.0;
+  const double tf = flops / (ms * 1e-3) / 1e12;
+  printf("W=%d waves/SIMD  per MFMA: %d VALU (%d exp) + %d ds_read_b128 : %7.1f TFLOP/s = %4.1f %% of 2500\n",
+         waves_per_simd, K, T, L, tf, tf / 25.0);
+}
+
+int main() {
+  float* out; HIP_OK(hipMalloc(&out, 4096));
+  for (int w = 1; w <= 2; ++w) {
+    run<0, 0, 0>(out, w); run<1, 0, 0>(out, w); run<2, 0, 0>(out, w); run<3, 0, 0>(out, w); run<4, 0, 0>(out, w);
+    run<6, 0, 0>(out, w); run<8, 0, 0>(out, w);
+    run<3, 1, 0>(out, w); run<4, 1, 1>(out, w); run<3, 1, 1>(out, w); run<3, 1, 2>(out, w); run<6, 2, 2>(out, w);
+    run<0, 0, 1>(out, w); run<0, 0, 2>(out, w);
+  }
+  return 0;
+}
