@@ -26,3 +26,16 @@ for name, fn in cases.items():
     torch.cuda.synchronize()
     t_all = (time.perf_counter() - t0) / n
     print(f"{name:32s} host enqueue {t_host * 1e6:7.1f} us/step   with device {t_all * 1e6:7.1f} us/step")
+
+# fixed cost of a timed region: t(K) = a + b K  (bench.timed brackets K steps with synchronize on both sides)
+fn = cases["LongContextAttention.forward"]
+for K in (5, 10, 20, 50, 100, 200):
+    ts = []
+    for rep in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(K): fn()
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    t = min(ts)
+    print(f"K={K:4d}: {t * 1e3:8.3f} ms total  {t / K * 1e6:7.1f} us/step   (min of 5)")
