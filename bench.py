@@ -167,8 +167,7 @@ def _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, iters):
 
 def kernel_roofline(cfg, dev, iters=20):
     """Dominant kernel of the N=1 workload (flash_fwd_kernel) timed alone, live, with device events on the stream
-    the kernel is launched on, plus the forward+backward kernels of the same shape and of the metric's own
-    sequence length on one GPU (S = 65536, BASELINE.json configs[4]'s global shape: it fits one MI355X)."""
+    the kernel is launched on, plus the forward+backward kernels of the same shape."""
     B, S, Hq, Hkv, D = cfg["B"], cfg["S"], cfg["Hq"], cfg["Hkv"], cfg["D"]
     _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, 300)                # ~0.5 s of work first: measure at sustained clocks,
     t = _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, iters)          # not on the DVFS ramp of a device that was idle
@@ -181,6 +180,14 @@ def kernel_roofline(cfg, dev, iters=20):
                         "bwd_achieved": round(t["bwd"], 1), "bwd_frac": frac(t["bwd"]),
                         "achieved": round(t["fwd_bwd"], 1), "frac": frac(t["fwd_bwd"]),
                         "note": "algorithmic FLOPs: backward = 2.5x forward (the two-launch backward executes 3.5x)"}}
+    return roof
+
+
+def seq64k_single_gpu(dev):
+    """Forward + backward kernels at the metric's own sequence length and global shape on ONE GPU (S = 65536, BASELINE.json
+    configs[4]: it fits one MI355X).  Runs AFTER the timed region (133 ms iterations heat the part)."""
+    frac = lambda x: round(x / PEAK_BF16_TFLOPS, 4)
+    roof = {}
     try:
         c5 = WORKLOADS[8]
         t64 = _fwd_bwd_kernels(c5["B"], c5["S"], c5["Hq"], c5["Hkv"], c5["D"], dev, 3)
@@ -191,7 +198,7 @@ def kernel_roofline(cfg, dev, iters=20):
             "fwd_achieved": round(t64["fwd"], 1), "bwd_achieved": round(t64["bwd"], 1)}
     except Exception as e:                                   # informative entry: never kill the measurement
         roof["seq64k_single_gpu"] = {"error": repr(e)[:200]}
-    return roof
+    return roof["seq64k_single_gpu"]
 
 
 def reference_kernel(cfg, dev, ours_tflops, iters=10):
@@ -501,13 +508,12 @@ def main():
             parity_op, parity_rows = (None if parity_op is None else float(pt[0].item())), float(pt[1].item())
     del q, k, v, do, out
 
-    # N = 1: the kernel-level measurements run BEFORE the timed region.  They keep the GPU busy for ~1 s, so the
+    # N = 1: the kernel timings of this workload run BEFORE the timed region.  They keep the GPU busy for ~1 s, so the
     # W warm-up + K timed steps (which may be as few as 5 + 20 = 13 ms of work) run at sustained clocks instead of
-    # on the DVFS ramp of a cold device.
-    roofline = ref_kernel = None
+    # on the DVFS ramp of a cold device, and in the same power state as the kernel they are compared with.
+    roofline = None
     if ws == 1 and rank == 0:
         roofline = kernel_roofline(cfg, dev)
-        ref_kernel = reference_kernel(cfg, dev, roofline["achieved"])
 
     for _ in range(args.warmup):
         step()
@@ -549,7 +555,8 @@ def main():
             line["smoke"] = f"backend={backend}, all ranks on cuda:0 -- NOT a measurement"
         if ws == 1:
             line["roofline"] = roofline
-            line["reference_kernel_on_this_gpu"] = ref_kernel
+            roofline["seq64k_single_gpu"] = seq64k_single_gpu(dev)
+            line["reference_kernel_on_this_gpu"] = reference_kernel(cfg, dev, roofline["achieved"])
             if cfg["bwd"]:
                 line["reference_fwdbwd_on_this_gpu"] = reference_fwdbwd(cfg, dev, value)
             if not args.no_cpu_baseline:

@@ -14,7 +14,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 #define HIP_OK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(2); } } while (0)
 
-template <int K, int T, int L>
+// X: extra per-MFMA scalar-side fillers: bit 0 = one s_waitcnt lgkmcnt(15) (never blocks), bit 1 = one s_nop 0,
+// bit 2 = one SALU add
+template <int K, int T, int L, int X = 0>
 __global__ __launch_bounds__(512, 2) void issue_kernel(float* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -24,6 +26,7 @@ __global__ __launch_bounds__(512, 2) void issue_kernel(float* out, int iters) {
   float x[8];
   for (int i = 0; i < 8; ++i) x[i] = 0.001f * (lane + i);
   u32x4 ld[2] = {a, a};
+  unsigned sx = iters;
   const __attribute__((address_space(3))) char* lp = (const __attribute__((address_space(3))) char*)smem + (threadIdx.x & 255) * 16;
   for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -40,6 +43,9 @@ __global__ __launch_bounds__(512, 2) void issue_kernel(float* out, int iters) {
         u32x4& d = ld[l & 1];
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(lp), "i"(4096 * ((m * 2 + l) & 7)));
       }
+      if (X & 1) asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+      if (X & 2) asm volatile("s_nop 0");
+      if (X & 4) asm volatile("s_add_u32 %0, %0, 1" : "+s"(sx));
       __builtin_amdgcn_sched_barrier(0);
     }
     if (L) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -47,23 +53,23 @@ __global__ __launch_bounds__(512, 2) void issue_kernel(float* out, int iters) {
   float s = 0.f;
   for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
   for (int i = 0; i < 8; ++i) s += x[i];
-  s += __builtin_bit_cast(float, ld[0][0]) + __builtin_bit_cast(float, ld[1][1]);
+  s += __builtin_bit_cast(float, ld[0][0]) + __builtin_bit_cast(float, ld[1][1]) + (float)sx;
   if (s == 123.456f) out[threadIdx.x] = s;
 }
 
-template <int K, int T, int L> static void run(float* out, int waves_per_simd) {
+template <int K, int T, int L, int X = 0> static void run(float* out, int waves_per_simd) {
   const int iters = 2000, threads = 256 * waves_per_simd;
   hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((issue_kernel<K, T, L>), dim3(256), dim3(threads), 40960, 0, out, iters);
+  hipLaunchKernelGGL((issue_kernel<K, T, L, X>), dim3(256), dim3(threads), 40960, 0, out, iters);
   HIP_OK(hipDeviceSynchronize());
   HIP_OK(hipEventRecord(e0));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((issue_kernel<K, T, L>), dim3(256), dim3(threads), 40960, 0, out, iters);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((issue_kernel<K, T, L, X>), dim3(256), dim3(threads), 40960, 0, out, iters);
   HIP_OK(hipEventRecord(e1)); HIP_OK(hipEventSynchronize(e1));
   float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); ms /= 3;
   const double flops = 256.0 * (threads / 64) * iters * 4 * 32768.0;
   const double tf = flops / (ms * 1e-3) / 1e12;
-  printf("W=%d waves/SIMD  per MFMA: %d VALU (%d exp) + %d ds_read_b128 : %7.1f TFLOP/s = %4.1f %% of 2500\n",
-         waves_per_simd, K, T, L, tf, tf / 25.0);
+  printf("W=%d waves/SIMD  per MFMA: %d VALU (%d exp) + %d ds_read_b128%s%s%s : %7.1f TFLOP/s = %4.1f %% of 2500\n",
+         waves_per_simd, K, T, L, (X & 1) ? " + s_waitcnt" : "", (X & 2) ? " + s_nop" : "", (X & 4) ? " + SALU" : "", tf, tf / 25.0);
 }
 
 int main() {
@@ -73,6 +79,8 @@ int main() {
     run<6, 0, 0>(out, w); run<8, 0, 0>(out, w);
     run<3, 1, 0>(out, w); run<4, 1, 1>(out, w); run<3, 1, 1>(out, w); run<3, 1, 2>(out, w); run<6, 2, 2>(out, w);
     run<0, 0, 1>(out, w); run<0, 0, 2>(out, w);
+    run<3, 1, 1, 1>(out, w); run<3, 1, 1, 2>(out, w); run<3, 1, 1, 4>(out, w); run<3, 1, 1, 7>(out, w);
+    run<3, 0, 1>(out, w); run<2, 1, 1>(out, w); run<2, 0, 1>(out, w);
   }
   return 0;
 }
