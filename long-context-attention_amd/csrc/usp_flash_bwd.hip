@@ -684,7 +684,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
       if (r < p.Sq) {
         const float l_ = p.lse[b * p.lse_sb + (h0 + pf_hh) * p.lse_sh + r];
         st_lse = (l_ == USP_NEG_INF) ? __builtin_inff() : l_ * kLog2e;
-        st_delta = p.delta[b * p.dl_sb + (h0 + pf_hh) * p.dl_sh + r];
+        st_delta = -p.delta[b * p.dl_sb + (h0 + pf_hh) * p.dl_sh + r];     // NEGATED: role B folds it into the dP chain
       } else {
         st_lse = __builtin_inff();
         st_delta = 0.f;
@@ -788,16 +788,18 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
             for (int j = 0; j < 4; ++j) load_stat(h, j);
           };
 
-          // element r of half h: role A: P = exp2(S*c - lse2); role B: dS = P * (dP - delta)
+          // element r of half h: role A: P = exp2(S*c - lse2); role B: dS = P * (dP - delta), where the dP chain
+          // STARTS from -delta (the MFMA's C operand = the row statistics tuple: one VALU per score less in the role
+          // that has the most of them)
           auto elem = [&](int h, int r) {
-            if ((r & 3) == 0) st4 = stq[r >> 2];
+            if (ROLE == 0 && (r & 3) == 0) st4 = stq[r >> 2];
             float val;
             if (ROLE == 0) {
               val = fast_exp2(__builtin_fmaf(sc[h][r], c, -st4[r & 3]));
             } else {
               const uint32_t wd = pin[h][r >> 3][(r & 7) >> 1];
               const float pr = (r & 1) ? E::hi(wd) : E::lo(wd);
-              val = pr * (sc[h][r] - st4[r & 3]);
+              val = pr * sc[h][r];
             }
             sc[h][r] = val;
             if (r & 1) pk[h][r >> 3][(r & 7) >> 1] = E::pack2(sc[h][r - 1], sc[h][r]);
@@ -809,18 +811,24 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
             auto rd = [&](int kt) {
               f[kt] = *(USP_LDS const u32x4*)(xs + h * 32 * ROWB + rd_row + (((2 * kt) ^ rd_x) * 16));
             };
+            f32x16 c0 = zero16;
+            if (ROLE == 1) {                                     // -delta of this half's 16 rows: the chain's C operand
+              load_stats(h);
+#pragma unroll
+              for (int r = 0; r < 16; ++r) c0[r] = stq[r >> 2][r & 3];
+            }
             rd(0);
             if (NKT > 1) rd(1);
             if (ROLE == 1) {                                     // fetch A's P of this half early
               pin[h][0] = *(USP_LDS const u32x4*)(pslot + (2 * h) * 1024);
               pin[h][1] = *(USP_LDS const u32x4*)(pslot + (2 * h + 1) * 1024);
             }
-            if (vh >= 0) load_stats(vh);
+            if (ROLE == 0 && vh >= 0) load_stats(vh);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
               if (kt + 2 < NKT) rd(kt + 2);
-              sc[h] = E::mfma(f[kt], rf[kt], kt == 0 ? zero16 : sc[h]);
+              sc[h] = E::mfma(f[kt], rf[kt], kt == 0 ? c0 : sc[h]);
               if (vh >= 0) {
 #pragma unroll
                 for (int e = kt * 16 / NKT; e < (kt + 1) * 16 / NKT; ++e) elem(vh, e);
@@ -839,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
             };
             rd(0);
             if (NGR > 1) rd(1);
-            if (vh >= 0) load_stats(vh);
+            if (ROLE == 0 && vh >= 0) load_stats(vh);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NGR; ++i) {
