@@ -89,7 +89,7 @@ def _probe_worker(rank, ws, ud, rd):
     return t > 0 and set(ov) >= {"value", "ms_iter", "ms_compute_only", "ms_comm_only"}
 
 
-@pytest.mark.parametrize("ws,ud,rd", [(2, 1, 2), (4, 2, 2)])
+@pytest.mark.parametrize("ws,ud,rd", [(2, 1, 2), (4, 2, 2), (4, 1, 4)])
 def test_timed_and_overlap_probe_on_gloo(ws, ud, rd):
     """bench.timed / bench.overlap_probe on the N > 1 code path: a ring, and the packed + pipelined exchange beside
     a ring (compute-only swaps the wire for local copies, comm-only skips every kernel; both are restored)."""
