@@ -213,6 +213,9 @@ static int run_probe() {
 struct Tol { double out_atol, out_rtol, lse_atol; };
 static Tol tol_for(int dt) { return dt == 0 ? Tol{2e-2, 2e-2, 2e-3} : Tol{4e-3, 4e-3, 1e-3}; }
 
+// USP_KBENCH_FLAGS=1: time / check the launches with USP_LAUNCH_INTERLEAVE, as the ring schedules issue them
+static int env_flags() { const char* e = getenv("USP_KBENCH_FLAGS"); return e ? atoi(e) : 0; }
+
 static int run_fwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, int dt, int check, int iters) {
   const size_t nq = (size_t)B * Sq * Hq * D, nk = (size_t)B * Sk * Hkv * D, nl = (size_t)B * Hq * Sq;
   std::vector<uint16_t> qb, kb, vb; std::vector<float> qf, kf, vf;
@@ -220,7 +223,7 @@ static int run_fwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, in
   uint16_t *dq = dev_upload(qb), *dk = dev_upload(kb), *dv = dev_upload(vb);
   uint16_t* dout = dev_alloc<uint16_t>(nq);
   float* dlse = dev_alloc<float>(nl);
-  usp_fwd_args a; memset(&a, 0, sizeof(a));
+  usp_fwd_args a; memset(&a, 0, sizeof(a)); a.flags = env_flags();
   a.dtype = dt; a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.causal = causal;
   a.softmax_scale = 1.f / sqrtf((float)D);
   a.q = bshd(dq, Sq, Hq, D); a.k = bshd(dk, Sk, Hkv, D); a.v = bshd(dv, Sk, Hkv, D);
@@ -387,7 +390,7 @@ static int run_bwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, in
   int rc = usp_flash_fwd(&f, nullptr);
   usp_tensor tdo = bshd(ddo, Sq, Hq, D), tout = bshd(dout, Sq, Hq, D);
   rc |= usp_bwd_delta(dt, B, Sq, Hq, D, &tdo, &tout, ddelta, (int64_t)Hq * Sq, Sq, nullptr);
-  usp_bwd_args a; memset(&a, 0, sizeof(a));
+  usp_bwd_args a; memset(&a, 0, sizeof(a)); a.flags = env_flags();
   a.dtype = dt; a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.causal = causal;
   a.softmax_scale = scale;
   a.dout = tdo; a.q = f.q; a.k = f.k; a.v = f.v;

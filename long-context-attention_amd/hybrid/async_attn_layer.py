@@ -79,7 +79,11 @@ class _Lane:
 _MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer workgroups per launch)
 
 
-_FILL_ITEMS = 256   # 256-row work items that give every CU of an MI355X one item
+# 256-row work items a head group's launches must still have: two per CU of an MI355X.  Measured (kbench, C3 shape,
+# causal, interleavable launches): 8 heads x 64 blocks = 512 items run at 1040 TFLOP/s, 4 heads = 256 items at 814,
+# 2 heads at 536 -- with one item per CU slot nothing balances the causal triangle, and the pipeline then costs more
+# kernel time than the exchange it hides (profiles/r02_rank_emulation.txt)
+_FILL_ITEMS = 512
 
 
 def _groups(Hq, Hkv, P, B=None, S=None, max_groups=None):
