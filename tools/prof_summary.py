@@ -121,9 +121,11 @@ def main():
                 lines.append(f"  PMC {short(n)}  (dispatches {len(next(iter(agg[n].values())))}, avg dur "
                              f"{sum(dur[n]) / len(dur[n]) / 1e3:.1f} us)")
                 cv = {cn: sum(v) / len(v) for cn, v in agg[n].items()}
-                for cn, val in cv.items():
-                    if cn not in merged[n]:                    # the pass's own duration goes with its counter
+                nd = len(next(iter(agg[n].values())))
+                for cn, val in cv.items():                     # per counter: the pass with the most dispatches of this
+                    if nd > merged[n].get("n:" + cn, 0):       # kernel wins; its own duration goes with the counter
                         merged[n][cn], merged[n]["us:" + cn] = val, sum(dur[n]) / len(dur[n]) / 1e3
+                        merged[n]["n:" + cn] = nd
                 for cn in sorted(cv):
                     lines.append(f"      {cn:28s} {cv[cn]:18.1f}")
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in cv and "SQ_BUSY_CYCLES" in cv and cv["SQ_BUSY_CYCLES"]:
