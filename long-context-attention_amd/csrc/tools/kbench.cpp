@@ -274,7 +274,10 @@ __global__ void link_like_copy(const uint4* __restrict__ src, uint4* __restrict_
 }
 
 static int run_overlap(int steps, int mib, int wgs) {
-  const int B = 1, Sq = 16384, Sk = 8192, Hq = 16, Hkv = 2, D = 128, dt = 0;
+  // default: the C5 ring-step block; USP_OVL_SHAPE="Sq Sk Hq Hkv" for another launch size (e.g. a head group's)
+  int Sq = 16384, Sk = 8192, Hq = 16, Hkv = 2;
+  if (const char* e = getenv("USP_OVL_SHAPE")) sscanf(e, "%d %d %d %d", &Sq, &Sk, &Hq, &Hkv);
+  const int B = 1, D = 128, dt = 0;
   const size_t nq = (size_t)B * Sq * Hq * D, nk = (size_t)B * Sk * Hkv * D, nl = (size_t)B * Hq * Sq;
   std::vector<uint16_t> qb, kb, vb; std::vector<float> qf, kf, vf;
   fill(qb, qf, nq, dt, 1); fill(kb, kf, nk, dt, 2); fill(vb, vf, nk, dt, 3);

@@ -587,9 +587,11 @@ static int launch_fwd(const FwdParams& p, bool causal, hipStream_t st) {
   if (waves != 4 && waves != 8) {
     const int64_t grid8 = (int64_t)p.B * p.Hq * ((p.Sq + 255) / 256);
     // short causal sequences: less diagonal waste (dense only: in packed mode twice the items cost more to fetch)
-    // beside a transfer (interleave) RCCL's resident workgroups take a few CUs: with at most two 256-row items
-    // per CU one lost CU costs a whole extra round, so halve the granularity there
-    waves = (grid8 < 256 || (p.interleave && grid8 <= 512) || (!p.seq_q && causal && p.Sq <= 1024)) ? 4 : 8;
+    // beside a transfer (interleave) RCCL's resident workgroups take a few CUs: with ONE 256-row item per CU a lost
+    // CU costs a whole extra round, so halve the granularity there (kbench overlap, 8 resident copy workgroups:
+    // 256 items 0.695 vs 0.718 ms).  From two items per CU on the 256-row shape wins again, alone (+4...8 %) and
+    // beside the copies (512 items: 2.054 vs 2.084 ms) -- profiles/r02_rank_emulation.txt
+    waves = (grid8 < 256 || (p.interleave && grid8 < 512) || (!p.seq_q && causal && p.Sq <= 1024)) ? 4 : 8;
   }
   return waves == 4 ? launch_fwd_w<D, DT, 4>(p, causal, st) : launch_fwd_w<D, DT, 8>(p, causal, st);
 }
