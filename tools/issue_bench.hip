@@ -21,6 +21,13 @@ __global__ __launch_bounds__(512, 2) void issue_kernel(float* out, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   u32x4 a = {0x3f803f80u + lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}, b = a;
+  if (X & 8) {            // operands with random mantissas / signs / exponents near 1 (bf16 pairs): MFMA power depends on the data
+    unsigned h = (blockIdx.x * 512u + threadIdx.x) * 2654435761u + 12345u;
+    for (int i = 0; i < 4; ++i) {
+      h = h * 1664525u + 1013904223u; a[i] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 3) & 0x00800080u);
+      h = h * 1664525u + 1013904223u; b[i] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 5) & 0x00800080u);
+    }
+  }
   f32x16 acc[4];
   for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
   float x[8];
@@ -72,8 +79,31 @@ template <int K, int T, int L, int X = 0> static void run(float* out, int waves_
          waves_per_simd, K, T, L, (X & 1) ? " + s_waitcnt" : "", (X & 2) ? " + s_nop" : "", (X & 4) ? " + SALU" : "", tf, tf / 25.0);
 }
 
-int main() {
+// sustained clocks: the same loop for ~2.5 s, one figure per 250 ms window
+template <int K, int T, int L, int X = 0> static void sustain(float* out) {
+  const int iters = 2000, threads = 512, per_window = 200;
+  const double flops = 256.0 * (threads / 64) * iters * 4 * 32768.0 * per_window;
+  hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  printf("sustained, W=2, %s operands, per MFMA %d VALU (%d exp) + %d ds_read_b128, TFLOP/s per window of %d launches:",
+         (X & 8) ? "RANDOM" : "constant", K, T, L, per_window);
+  double t_total = 0;
+  while (t_total < 2500.0) {
+    HIP_OK(hipEventRecord(e0));
+    for (int i = 0; i < per_window; ++i) hipLaunchKernelGGL((issue_kernel<K, T, L, X>), dim3(256), dim3(threads), 40960, 0, out, iters);
+    HIP_OK(hipEventRecord(e1)); HIP_OK(hipEventSynchronize(e1));
+    float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    t_total += ms;
+    printf(" %.0f", flops / (ms * 1e-3) / 1e12);
+  }
+  printf("\n");
+}
+
+int main(int argc, char** argv) {
   float* out; HIP_OK(hipMalloc(&out, 4096));
+  if (argc > 1) {      // issue_bench sustain
+    sustain<0, 0, 0>(out); sustain<0, 0, 0, 8>(out); sustain<3, 1, 1>(out); sustain<3, 1, 1, 8>(out); sustain<4, 1, 2, 8>(out);
+    return 0;
+  }
   for (int w = 1; w <= 2; ++w) {
     run<0, 0, 0>(out, w); run<1, 0, 0>(out, w); run<2, 0, 0>(out, w); run<3, 0, 0>(out, w); run<4, 0, 0>(out, w);
     run<6, 0, 0>(out, w); run<8, 0, 0>(out, w);
