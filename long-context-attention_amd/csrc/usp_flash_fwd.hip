@@ -322,20 +322,25 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   constexpr int NA = 2 * NKT, NB = 4 * NDJ;
   int j = 0;
   const int n_main = n_full < nt - 1 ? n_full : nt - 1;    // j + 1 < nt holds inside: no branches
-  auto decide = [&](float mt) {
-    // mt: row max of the upcoming tile (both half-waves).  Wave-uniform branch.
-    if (!__all((mt - m_run) * c <= kThr)) {
-      asm volatile("; rescale (rare)" ::: "memory");          // keeps hipcc from if-converting the branch
-      const float m_new = fmaxf(m_run, mt);
-      const float m_use = (m_new == USP_NEG_INF) ? 0.f : m_new;
-      const float alpha = fast_exp2(m_run * c - m_use * c);
-      m_run = m_new;
-      l_run *= alpha;
+  // m_thr = m_run + kThr / c: a tile whose scores all stay below it keeps the reference max.  Every lane tests the
+  // maximum of ITS 32 scores of the row (the other half-wave's lane tests the other 32), so the common path needs no
+  // exchange between the half-waves; the (rare, wave-uniform) rescale does it.
+  const float thr_raw = kThr / c;
+  float m_thr = USP_NEG_INF;
+  float nmc = 0.f;             // -(reference max * c) of the pipelined loop, 0 while the reference is still -inf
+  auto rescale = [&](float mt_lane) {
+    asm volatile("; rescale (rare)" ::: "memory");          // keeps hipcc from if-converting the branch
+    const float m_new = fmaxf(m_run, xhalf_max(mt_lane));
+    const float m_use = (m_new == USP_NEG_INF) ? 0.f : m_new;
+    const float alpha = fast_exp2(m_run * c - m_use * c);
+    m_run = m_new;
+    m_thr = m_new + thr_raw;
+    nmc = -(m_use * c);
+    l_run *= alpha;
 #pragma unroll
-      for (int dj = 0; dj < NDJ; ++dj)
+    for (int dj = 0; dj < NDJ; ++dj)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
-    }
+      for (int r = 0; r < 16; ++r) o[dj][r] *= alpha;
   };
   // one pipelined iteration: softmax + PV of tile jj (scores in ca/cb), scores of tile jj+1 into na/nb
   auto iter = [&](int jj, f32x16& ca, f32x16& cb, f32x16& na, f32x16& nb) {
@@ -365,7 +370,6 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
     constexpr int PF = USP_PF;                                  // LDS fragment prefetch distance (k-steps / MFMAs)
 #pragma unroll
     for (int t = 0; t < PF && t < NKT; ++t) rd_k(t);
-    const float mc = ((m_run == USP_NEG_INF) ? 0.f : m_run) * c;
     float rs = 0.f;
     u32x4 pf[4];
     // element e of the tile's 32 scores: e < 16 -> ca[e], else cb[e - 16]
@@ -378,33 +382,26 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       }
       return;
 #endif
-      if (e < 16) { ca[e] = fast_exp2(__builtin_fmaf(ca[e], c, -mc)); rs += ca[e]; }
-      else { cb[e - 16] = fast_exp2(__builtin_fmaf(cb[e - 16], c, -mc)); rs += cb[e - 16]; }
-      if (e & 1) {                                          // pair (e-1, e) complete -> pack
-        const int r = (e & 15) - 1;
-        if (e < 16) pf[r >> 3][(r & 7) >> 1] = E::pack2(ca[r], ca[r + 1]);
+      // The consumers of an exp2 result run ONE ELEMENT LATE (the row-sum add of element e-1 and the pack of the pair
+      // (e-2, e-1) are issued with element e): nothing waits for the transcendental it was just issued behind.
+      auto P = [&](int i) -> float { return i < 16 ? ca[i] : cb[i - 16]; };
+      if (e < 16) ca[e] = fast_exp2(__builtin_fmaf(ca[e], c, nmc));
+      else cb[e - 16] = fast_exp2(__builtin_fmaf(cb[e - 16], c, nmc));
+      if (e == 1) rs = P(0);
+      else if (e > 1) rs += P(e - 1);
+      if (e >= 2 && (e & 1) == 0) {                         // pair (e-2, e-1) complete -> pack
+        const int r = (e - 2) & 15;
+        if (e - 2 < 16) pf[r >> 3][(r & 7) >> 1] = E::pack2(ca[r], ca[r + 1]);
         else pf[2 + (r >> 3)][(r & 7) >> 1] = E::pack2(cb[r], cb[r + 1]);
+      }
+      if (e == 31) {
+        rs += cb[15];
+        pf[3][3] = E::pack2(cb[14], cb[15]);
       }
     };
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int sl = 0; sl < NA; ++sl) {
-      const int kt = sl >> 1;
-      if ((sl & 1) == 0) {
-        if (kt + PF < NKT) rd_k(kt + PF);
-        na = E::mfma(ka[kt], qf[kt], kt == 0 ? zero : na);
-      } else {
-        nb = E::mfma(kc[kt], qf[kt], kt == 0 ? zero : nb);
-      }
-#pragma unroll
-      for (int e = sl * 24 / NA; e < (sl + 1) * 24 / NA; ++e) exp_elem(e);
-      if (sl % USP_FWD_G == USP_FWD_G - 1) __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---------------- phase B ----------------
     USP_LDS const char* vb = smem + (jj & 1) * KBYTES + v_rd;
     u32x4 va[NB];
-    float mt = USP_NEG_INF;
     auto rd_v = [&](int i) {                                  // i = ks * NDJ + dj
       const int ks = i / NDJ, dj = i % NDJ;
       USP_LDS const char* vp = vb + (4 * ks * NDJ + dj) * 256;
@@ -416,9 +413,32 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       va[i] = u32x4{v0[0], v0[1], v1[0], v1[1]};
 #endif
     };
+    // The first MFMA of the phase waits for the K fragments read just above (K(jj+1) is only guaranteed behind the
+    // barrier): the first slice of exp work goes IN FRONT of it, every later slice behind the MFMA before it; the V
+    // fragments of phase B's first MFMAs are read behind phase A's last ones (V(jj) has been resident since the
+    // previous barrier), so phase B starts without an LDS round trip.
 #pragma unroll
-    for (int t = 0; t < PF && t < NB; ++t) rd_v(t);
+    for (int e = 0; e < 24 / NA; ++e) exp_elem(e);
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int sl = 0; sl < NA; ++sl) {
+      const int kt = sl >> 1;
+      if ((sl & 1) == 0) {
+        if (kt + PF < NKT) rd_k(kt + PF);
+        na = E::mfma(ka[kt], qf[kt], kt == 0 ? zero : na);
+      } else {
+        nb = E::mfma(kc[kt], qf[kt], kt == 0 ? zero : nb);
+      }
+      if (sl + 1 < NA) {
+#pragma unroll
+        for (int e = (sl + 1) * 24 / NA; e < (sl + 2) * 24 / NA; ++e) exp_elem(e);
+      }
+      if (sl >= NA - PF && sl - (NA - PF) < NB) rd_v(sl - (NA - PF));
+      if (sl % USP_FWD_G == USP_FWD_G - 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---------------- phase B ----------------
+    float mt = USP_NEG_INF;
+    bool keep = true;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       if (i + PF < NB) rd_v(i + PF);
@@ -426,14 +446,20 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       if (i < NB / 2) {
 #pragma unroll
         for (int e = 24 + i * 16 / NB; e < 24 + (i + 1) * 16 / NB; ++e) exp_elem(e);
-      }
+        if (i == NB / 2 - 1) l_run += rs;
+      } else {                                                // row-max chain of S(jj+1), second half of the phase
 #pragma unroll
-      for (int e = i * 32 / NB; e < (i + 1) * 32 / NB; ++e)   // row-max chain of S(jj+1)
-        mt = fmaxf(mt, e < 16 ? na[e] : nb[e - 16]);
+        for (int e = (i - NB / 2) * 64 / NB; e < (i - NB / 2 + 1) * 64 / NB; ++e)
+#ifdef USP_ABLATE_NOMAX
+          ;
+#else
+          mt = fmaxf(mt, e < 16 ? na[e] : nb[e - 16]);
+#endif
+        if (i == NB - 1) keep = __all(mt <= m_thr);           // decided behind the last MFMA, not after it
+      }
       if (i % USP_FWD_G == USP_FWD_G - 1) __builtin_amdgcn_sched_barrier(0);
     }
-    l_run += rs;
-    decide(xhalf_max(mt));
+    if (!keep) rescale(mt);
 #ifndef USP_ABLATE_NOBARRIER
     dma_drain();                 // this wave's pieces of K(jj+2), V(jj+1) have landed ...
     __syncthreads();             // ... and so have everybody else's
@@ -446,7 +472,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
     for (int r = 1; r < 16; ++r) mt = fmaxf(mt, sa[r]);
 #pragma unroll
     for (int r = 0; r < 16; ++r) mt = fmaxf(mt, sb[r]);
-    decide(xhalf_max(mt));
+    if (!__all(mt <= m_thr)) rescale(mt);
     f32x16 ta, tb;
     for (; j + 1 < n_main; j += 2) {
       iter(j, sa, sb, ta, tb);

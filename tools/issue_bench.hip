@@ -79,6 +79,85 @@ template <int K, int T, int L, int X = 0> static void run(float* out, int waves_
          waves_per_simd, K, T, L, (X & 1) ? " + s_waitcnt" : "", (X & 2) ? " + s_nop" : "", (X & 4) ? " + SALU" : "", tf, tf / 25.0);
 }
 
+
+// Two waves per SIMD that alternate a filler-heavy and a filler-light phase of 16 MFMAs each (the forward kernel's phase A =
+// 5.25 VALU incl. 1.5 exp + 1 LDS read per MFMA, phase B = 2.75 VALU incl. 0.5 exp + 2 LDS reads), one s_barrier per 32 MFMAs.
+// SKEW = 0: all 8 waves run heavy, light, barrier (both waves of a SIMD are in the same phase at the same time);
+// SKEW = 1: waves 4-7 (the second wave of every SIMD) run half an iteration behind: light, heavy, barrier.
+template <int K, int T2, int L> __device__ __forceinline__ void phase16(f32x16 (&acc)[4], u32x4 a, u32x4 b, float (&x)[8], u32x4 (&ld)[2],
+                                                                        const __attribute__((address_space(3))) char* lp) {
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[m & 3], 0, 0, 0);
+    const int nexp = (T2 >> 1) + ((T2 & 1) & (m & 1));        // T2 = exps per TWO MFMAs
+#pragma unroll
+    for (int k = 0; k < K + ((m & 3) == 0 && K == 5 ? 1 : 0); ++k) {
+      float& v = x[(m * K + k) & 7];
+      if (k < nexp) asm volatile("v_exp_f32 %0, %0" : "+v"(v));
+      else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v) : "v"(x[(m * K + k + 1) & 7]));
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      u32x4& d = ld[l & 1];
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(lp), "i"(4096 * ((m * 2 + l) & 7)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int SKEW> __global__ __launch_bounds__(512, 2) void phase_kernel(float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32x4 a, b;
+  unsigned h = (blockIdx.x * 512u + threadIdx.x) * 2654435761u + 12345u;
+  for (int i = 0; i < 4; ++i) {
+    h = h * 1664525u + 1013904223u; a[i] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 3) & 0x00800080u);
+    h = h * 1664525u + 1013904223u; b[i] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 5) & 0x00800080u);
+  }
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = 0.001f * (lane + i);
+  u32x4 ld[2] = {a, a};
+  const __attribute__((address_space(3))) char* lp = (const __attribute__((address_space(3))) char*)smem + (threadIdx.x & 255) * 16;
+  if (SKEW && wave >= 4) {
+    phase16<5, 3, 1>(acc, a, b, x, ld, lp);
+    __builtin_amdgcn_s_barrier();
+    for (int it = 1; it < iters; ++it) {
+      phase16<3, 1, 2>(acc, a, b, x, ld, lp);
+      phase16<5, 3, 1>(acc, a, b, x, ld, lp);
+      __builtin_amdgcn_s_barrier();
+    }
+    phase16<3, 1, 2>(acc, a, b, x, ld, lp);
+  } else {
+    for (int it = 0; it < iters; ++it) {
+      phase16<5, 3, 1>(acc, a, b, x, ld, lp);
+      phase16<3, 1, 2>(acc, a, b, x, ld, lp);
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  float sum = 0.f;
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) sum += acc[i][r];
+  for (int i = 0; i < 8; ++i) sum += x[i];
+  sum += __builtin_bit_cast(float, ld[0][0]) + __builtin_bit_cast(float, ld[1][1]);
+  if (sum == 123.456f) out[threadIdx.x] = sum;
+}
+
+template <int SKEW> static void run_phase(float* out) {
+  const int iters = 500, threads = 512, reps = 20;
+  hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  for (int i = 0; i < 200; ++i) hipLaunchKernelGGL((phase_kernel<SKEW>), dim3(256), dim3(threads), 40960, 0, out, iters);
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((phase_kernel<SKEW>), dim3(256), dim3(threads), 40960, 0, out, iters);
+  HIP_OK(hipEventRecord(e1)); HIP_OK(hipEventSynchronize(e1));
+  float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+  const double flops = 256.0 * 8 * iters * 32 * 32768.0;
+  printf("phases (heavy 5.25 VALU/1.5 exp/1 LDS | light 2.75/0.5/2), random operands, barrier per 32 MFMAs, %s: %7.1f TFLOP/s = %4.1f %%\n",
+         SKEW ? "waves 4-7 HALF AN ITERATION BEHIND" : "all waves in phase", flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 25.0);
+}
+
 // sustained clocks: the same loop for ~2.5 s, one figure per 250 ms window
 template <int K, int T, int L, int X = 0> static void sustain(float* out) {
   const int iters = 2000, threads = 512, per_window = 200;
@@ -100,6 +179,10 @@ template <int K, int T, int L, int X = 0> static void sustain(float* out) {
 
 int main(int argc, char** argv) {
   float* out; HIP_OK(hipMalloc(&out, 4096));
+  if (argc > 1 && argv[1][0] == 'p') {      // issue_bench phase
+    for (int r = 0; r < 3; ++r) { run_phase<0>(out); run_phase<1>(out); }
+    return 0;
+  }
   if (argc > 1) {      // issue_bench sustain
     sustain<0, 0, 0>(out); sustain<0, 0, 0, 8>(out); sustain<3, 1, 1>(out); sustain<3, 1, 1, 8>(out); sustain<4, 1, 2, 8>(out);
     return 0;
