@@ -158,6 +158,79 @@ template <int SKEW> static void run_phase(float* out) {
          SKEW ? "waves 4-7 HALF AN ITERATION BEHIND" : "all waves in phase", flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 25.0);
 }
 
+// The dQ kernel's tile: 48 MFMAs with 144 VALU (32 exp) of element work.  SHAPE 0: as scheduled today -- 16 bare, 16 with 4.5 VALU
+// (1 exp), 8 with 9 VALU (2 exp), 8 bare; SHAPE 1: the same work spread evenly, 3 VALU (2 exps per 3 MFMAs) behind every MFMA.
+// LDS: 1 ds_read_b128 per MFMA in the first 32, 2 in the last 16 (transpose reads come in pairs).
+template <int NM, int K, int T3, int L> __device__ __forceinline__ void phaseN(f32x16 (&acc)[4], u32x4 a, u32x4 b, float (&x)[8], u32x4 (&ld)[2],
+                                                                               const __attribute__((address_space(3))) char* lp) {
+#pragma unroll
+  for (int m = 0; m < NM; ++m) {
+    acc[m & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc[m & 3], 0, 0, 0);
+    const int nexp = T3 / 3 + ((m % 3) < (T3 % 3) ? 1 : 0);    // T3 = exps per THREE MFMAs
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      float& v = x[(m * K + k) & 7];
+      if (k < nexp) asm volatile("v_exp_f32 %0, %0" : "+v"(v));
+      else asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(v) : "v"(x[(m * K + k + 1) & 7]));
+    }
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+      u32x4& d = ld[l & 1];
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(lp), "i"(4096 * ((m * 2 + l) & 7)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+template <int SHAPE> __global__ __launch_bounds__(512, 2) void dq_shape_kernel(float* out, int iters) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  u32x4 a, b;
+  unsigned h = (blockIdx.x * 512u + threadIdx.x) * 2654435761u + 12345u;
+  for (int i = 0; i < 4; ++i) {
+    h = h * 1664525u + 1013904223u; a[i] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 3) & 0x00800080u);
+    h = h * 1664525u + 1013904223u; b[i] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 5) & 0x00800080u);
+  }
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float x[8];
+  for (int i = 0; i < 8; ++i) x[i] = 0.001f * (lane + i);
+  u32x4 ld[2] = {a, a};
+  const __attribute__((address_space(3))) char* lp = (const __attribute__((address_space(3))) char*)smem + (threadIdx.x & 255) * 16;
+  for (int it = 0; it < iters; ++it) {
+    if (SHAPE == 0) {
+      phaseN<16, 0, 0, 1>(acc, a, b, x, ld, lp);
+      phaseN<16, 5, 3, 1>(acc, a, b, x, ld, lp);      // 4.5 -> alternate 4 / 5: use 5,4 below
+      phaseN<8, 8, 6, 2>(acc, a, b, x, ld, lp);
+      phaseN<8, 0, 0, 2>(acc, a, b, x, ld, lp);
+    } else {
+      phaseN<32, 3, 2, 1>(acc, a, b, x, ld, lp);
+      phaseN<16, 3, 2, 2>(acc, a, b, x, ld, lp);
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  float sum = 0.f;
+  for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) sum += acc[i][r];
+  for (int i = 0; i < 8; ++i) sum += x[i];
+  sum += __builtin_bit_cast(float, ld[0][0]) + __builtin_bit_cast(float, ld[1][1]);
+  if (sum == 123.456f) out[threadIdx.x] = sum;
+}
+
+template <int SHAPE> static void run_dq_shape(float* out) {
+  const int iters = 400, threads = 512, reps = 20;
+  hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  for (int i = 0; i < 200; ++i) hipLaunchKernelGGL((dq_shape_kernel<SHAPE>), dim3(256), dim3(threads), 40960, 0, out, iters);
+  HIP_OK(hipDeviceSynchronize());
+  HIP_OK(hipEventRecord(e0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((dq_shape_kernel<SHAPE>), dim3(256), dim3(threads), 40960, 0, out, iters);
+  HIP_OK(hipEventRecord(e1)); HIP_OK(hipEventSynchronize(e1));
+  float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+  const double flops = 256.0 * 8 * iters * 48 * 32768.0;
+  printf("dQ tile (48 MFMAs, ~144 VALU incl. 32 exp), random operands, %s: %7.1f TFLOP/s = %4.1f %%\n",
+         SHAPE ? "fillers spread EVENLY (3 per MFMA)" : "as scheduled today (0 | 5 | 8 | 0 per MFMA)", flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 25.0);
+}
+
 // sustained clocks: the same loop for ~2.5 s, one figure per 250 ms window
 template <int K, int T, int L, int X = 0> static void sustain(float* out) {
   const int iters = 2000, threads = 512, per_window = 200;
@@ -179,6 +252,10 @@ template <int K, int T, int L, int X = 0> static void sustain(float* out) {
 
 int main(int argc, char** argv) {
   float* out; HIP_OK(hipMalloc(&out, 4096));
+  if (argc > 1 && argv[1][0] == 'd') {      // issue_bench dq
+    for (int r = 0; r < 3; ++r) { run_dq_shape<0>(out); run_dq_shape<1>(out); }
+    return 0;
+  }
   if (argc > 1 && argv[1][0] == 'p') {      // issue_bench phase
     for (int r = 0; r < 3; ++r) { run_phase<0>(out); run_phase<1>(out); }
     return 0;
