@@ -417,8 +417,12 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
     // barrier): the first slice of exp work goes IN FRONT of it, every later slice behind the MFMA before it; the V
     // fragments of phase B's first MFMAs are read behind phase A's last ones (V(jj) has been resident since the
     // previous barrier), so phase B starts without an LDS round trip.
+#ifndef USP_FWD_LEAD   // exp elements issued in front of the first MFMA of phase A (A/B builds)
+#define USP_FWD_LEAD (24 / NA)
+#endif
+    constexpr int LEAD = USP_FWD_LEAD < 24 ? USP_FWD_LEAD : 24;
 #pragma unroll
-    for (int e = 0; e < 24 / NA; ++e) exp_elem(e);
+    for (int e = 0; e < LEAD; ++e) exp_elem(e);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int sl = 0; sl < NA; ++sl) {
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       }
       if (sl + 1 < NA) {
 #pragma unroll
-        for (int e = (sl + 1) * 24 / NA; e < (sl + 2) * 24 / NA; ++e) exp_elem(e);
+        for (int e = LEAD + sl * (24 - LEAD) / (NA - 1); e < LEAD + (sl + 1) * (24 - LEAD) / (NA - 1); ++e) exp_elem(e);
       }
       if (sl >= NA - PF && sl - (NA - PF) < NB) rd_v(sl - (NA - PF));
       if (sl % USP_FWD_G == USP_FWD_G - 1) __builtin_amdgcn_sched_barrier(0);
