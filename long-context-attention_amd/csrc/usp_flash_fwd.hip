@@ -79,16 +79,6 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   ItemQueue queue{p_in.sched, p_in.seq_q, p_in.B * p_in.Hq, p_in.nq, p_in.Hq, kBM, CAUSAL ? 1 : 0};
   int qstate = 0;
   USP_LDS int* qslots = (USP_LDS int*)(smem + 4 * KBYTES);          // 2 ints behind the K/V buffers
-#ifndef USP_FWD_NEXT   // 1: a workgroup that walks a static item list issues the NEXT item's first loads early
-#define USP_FWD_NEXT 1
-#endif
-  // Next-item preload (dense launches with a static item list): during the LAST tile of an item its K buffers and one V
-  // buffer are free and the Q fragments are dead, so the next item's Q loads and its K(0), K(1), V(0) DMA are issued
-  // there and fly behind that tile's softmax / PV and the epilogue -- the item no longer starts with an idle round trip
-  // to HBM.  `pre`: that has been done for the item at hand; `vpar`: which V buffer holds its tile 0.
-  u32x4 qf[NKT];
-  bool pre = false;
-  int vpar = 0;
   for (int pass = 0;; ++pass) {
   int w = p_in.sched ? item_queue_next(queue, qstate, qslots, pass) : walk.at(pass);
   if (w < 0) break;
@@ -149,12 +139,12 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   if (n_full > nt) n_full = nt;
 
   // ---- Q fragments (B operand: lane holds Q[row][16t + 8hi .. +7]) ---------------------------
-  if (!pre) {
+  u32x4 qf[NKT];
+  {
     const char* qp = p.q + 2 * (b * p.q_sb + (int64_t)row_c * p.q_ss + h * p.q_sh) + 16 * hi;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) qf[t] = *(const u32x4*)(qp + 32 * t);
   }
-  auto vbuf_of = [&](int tile) { return (tile + vpar) & 1; };      // V(tile) lives in Vbuf[vbuf_of(tile)]
 
   // ---- staging: LDS-DMA (buffer_load ... lds): no staging registers, no ds_write ---------------------
   // One wave-instruction fills 1 KiB of LDS linearly (wave-uniform base + lane*16):
@@ -303,11 +293,10 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   f32x16 sa, sb;          // S^T of the tile the softmax works on next
 #pragma unroll
   for (int r = 0; r < 16; ++r) { sa[r] = 0.f; sb[r] = 0.f; }
-  if (nt > 0 && !pre) {
-    dma_k(0, 0); dma_v(0, vbuf_of(0));
+  if (nt > 0) {
+    dma_k(0, 0); dma_v(0, 0);
     if (nt > 1) dma_k(1, 1);
   }
-  pre = false;
   dma_drain();
   __syncthreads();
   if (nt > 0 && wave_kv_end > 0) qk(0, sa, sb);
@@ -358,7 +347,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
     const int jk = jj + 2 < nt ? jj + 2 : nt - 1;           // clamped prefetch (redundant load at the end)
 #ifndef USP_ABLATE_NOSTAGE
     dma_k(jk, jj & 1);            // Kbuf[jj&1] held K(jj): last read in the previous iteration
-    dma_v(jj + 1, vbuf_of(jj + 1));  // that buffer held V(jj-1): last read in the previous iteration
+    dma_v(jj + 1, (jj + 1) & 1);  // Vbuf[(jj+1)&1] held V(jj-1): last read in the previous iteration
 #endif
     // ---------------- phase A ----------------
     USP_LDS const char* kb = smem + ((jj + 1) & 1) * KBYTES + k_rd_row;
@@ -411,7 +400,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       }
     };
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    USP_LDS const char* vb = smem + vbuf_of(jj) * KBYTES + v_rd;
+    USP_LDS const char* vb = smem + (jj & 1) * KBYTES + v_rd;
     u32x4 va[NB];
     auto rd_v = [&](int i) {                                  // i = ks * NDJ + dj
       const int ks = i / NDJ, dj = i % NDJ;
@@ -503,43 +492,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   for (; j < nt; ++j) {
     const int kt0 = j * kBN;
     if (j + 2 < nt) dma_k(j + 2, j & 1);
-    if (j + 1 < nt) dma_v(j + 1, vbuf_of(j + 1));
-    const int vcur = vbuf_of(j);               // (vpar changes hands below)
-    bool last_open = false;                    // last tile with the next item's loads in flight: no drain, no barrier
-    if (USP_FWD_NEXT && j + 1 == nt && p_in.sched == nullptr && p_in.seq_q == nullptr) {
-      const int w2 = walk.at(pass + 1);
-      if (w2 >= 0) {
-        // K(nt-1) was read one iteration ago and K(nt-2) two: both K buffers are free; V(nt-2)'s buffer is free, V(nt-1)'s
-        // is being read.  Nobody reads Q any more.  (Tiles past the next item's range read as zeros / are never used.)
-        const int qt2r = w2 % p.nq;
-        int rest2 = w2 / p.nq;
-        const int qt2 = CAUSAL ? (p.nq - 1 - qt2r) : qt2r;
-        const int g2 = rest2 % p.G;
-        rest2 /= p.G;
-        const int hkv2 = rest2 % p.Hkv, b2 = rest2 / p.Hkv;
-        const int row2 = qt2 * kBM + wave * 32 + l31;
-        const int row2c = row2 < p.Sq ? row2 : p.Sq - 1;
-        const char* qp = p.q + 2 * (b2 * p.q_sb + (int64_t)row2c * p.q_ss + (hkv2 * p.G + g2) * p.q_sh) + 16 * hi;
-#pragma unroll
-        for (int t = 0; t < NKT; ++t) qf[t] = *(const u32x4*)(qp + 32 * t);
-        const char* kb2 = p.k + 2 * (b2 * p.k_sb + hkv2 * p.k_sh);
-        const char* vb2 = p.v + 2 * (b2 * p.v_sb + hkv2 * p.v_sh);
-        const int vnext = vbuf_of(nt);
-        for (int t = 0; t < 2; ++t) {
-          const auto rk = tile_rsrc(kb2, p.k_ss, t);
-#pragma unroll
-          for (int i = 0; i < CPW; ++i)
-            if (CHUNKS % NW == 0 || wave + NW * i < CHUNKS) lds_dma16(rk, smem + t * KBYTES + (wave + NW * i) * 1024, k_voff[i]);
-        }
-        const auto rv = tile_rsrc(vb2, p.v_ss, 0);
-#pragma unroll
-        for (int i = 0; i < CPW; ++i)
-          if (CHUNKS % NW == 0 || wave + NW * i < CHUNKS) lds_dma16(rv, smem + VOFF + vnext * KBYTES + (wave + NW * i) * 1024, v_voff[i]);
-        pre = true;
-        vpar = vnext;                          // (tile 0 + vpar) & 1 == vnext for the next item
-        last_open = true;
-      }
-    }
+    if (j + 1 < nt) dma_v(j + 1, (j + 1) & 1);
     f32x16 na, nb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { na[r] = 0.f; nb[r] = 0.f; }
@@ -549,13 +502,11 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
       if (need_mask) mask(kt0, sa, sb);
       u32x4 pf[4];
       softmax(sa, sb, pf);
-      pv(vcur, pf);
+      pv(j & 1, pf);
     }
     sa = na; sb = nb;
-    if (!last_open) {
-      dma_drain();
-      __syncthreads();
-    }
+    dma_drain();
+    __syncthreads();
   }
 
   // ---- epilogue: normalise, merge with the running result, store -------------------------------
