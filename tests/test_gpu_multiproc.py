@@ -168,7 +168,8 @@ def test_long_context_attention_with_pipelined_exchange(gloo_cuda, path):
 
 
 @pytest.mark.parametrize("ws,ud,rd,impl,Hq,Hkv,D", [(4, 2, 2, "zigzag", 8, 4, 128), (4, 2, 2, "basic", 4, 4, 64),
-                                                    (4, 2, 2, "strip", 8, 2, 128), (4, 1, 4, "zigzag", 4, 2, 128)])
+                                                    (4, 2, 2, "strip", 8, 2, 128), (4, 1, 4, "zigzag", 4, 2, 128),
+                                                    (8, 4, 2, "zigzag", 8, 4, 128)])       # ulysses 4: P = 4 exchange kernels
 def test_batch2_on_a_ulysses_x_ring_grid(gloo_cuda, ws, ud, rd, impl, Hq, Hkv, D):
     for got, truth in run_distributed(_batch2_worker, ws, ud, rd, impl, Hq, Hkv, D):
         for a, t, key in zip(got, truth, ("out", "dq", "dk", "dv")):
