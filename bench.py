@@ -350,8 +350,10 @@ def exchange_mode(attn, lq, lk, cfg, ws):
     cap = attn._packed_exchange(lq, lk)
     if cap is None:
         return "three separate exchanges (reference structure)"
-    from yunchang_amd.hybrid.async_attn_layer import _groups
-    ng = _groups(cfg["Hq"], cfg["Hkv"], cfg["ud"], cfg["B"], lq.shape[1] * cfg["ud"], max_groups=cap)[0]
+    from yunchang_amd.hybrid.async_attn_layer import _groups, _link_bound
+    S = lq.shape[1] * cfg["ud"]
+    lb = _link_bound(cfg["Hq"], cfg["Hkv"], cfg["ud"], cfg["B"], S, lq.shape[-1], lq.element_size(), cfg["rd"], True)
+    ng = _groups(cfg["Hq"], cfg["Hkv"], cfg["ud"], cfg["B"], S, max_groups=cap, link_bound=lb)[0]
     return f"one packed q|k|v exchange per head group, {ng} group(s)" + (", pipelined on a side stream" if ng > 1 else "")
 
 

@@ -79,25 +79,43 @@ class _Lane:
 _MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer workgroups per launch)
 
 
-# 256-row work items a head group's launches must still have: two per CU of an MI355X.  Measured (kbench, C3 shape,
-# causal, interleavable launches): 8 heads x 64 blocks = 512 items run at 1040 TFLOP/s, 4 heads = 256 items at 814,
-# 2 heads at 536 -- with one item per CU slot nothing balances the causal triangle, and the pipeline then costs more
-# kernel time than the exchange it hides (profiles/r02_rank_emulation.txt)
+# 256-row work items a head group's attention launch must still have.  Measured (kbench, C3 shape = one causal launch
+# per group, interleavable): 8 heads x 64 blocks = 512 items run at 1040 TFLOP/s, 4 heads = 256 items at 814, 2 heads at
+# 536 -- with one item per CU nothing balances the causal triangle.  So two items per CU are asked for ...
 _FILL_ITEMS = 512
+# ... unless the exchange is long against the attention it can hide behind: then the pipeline wins even with starved
+# launches.  C3 (2 GPUs, forward only, MHA): 50 MB in + 17 MB out per rank over ONE link = 1.05 ms against 0.5 ms of
+# attention -- sequential 0.79 + 0.54 + 0.26 = 1.59 ms, two groups of 256 items (0.36 ms each) 1.28 ms, four groups
+# 1.33 ms (the schedule: all input exchanges queued first on the lane, group i's output behind its attention).  The
+# one-GPU rank emulation cannot see this (its wire is an HBM copy): its 0.69 vs 0.86 ms is kernel time only.
+_FILL_ITEMS_LINK_BOUND = 256
+_LINK_BYTES_PER_S = 64e9      # one xGMI link, one direction (MI355X guide: 7 links x ~153 GB/s bidirectional per GPU)
+_KERNEL_FLOPS_PER_S = 1.1e15  # forward flash kernel on large launches (profiles/)
 
 
-def _groups(Hq, Hkv, P, B=None, S=None, max_groups=None):
+def _link_bound(Hq, Hkv, P, B, S, D, itemsize, ring, causal):
+    """Is the Ulysses exchange of one forward pass at least half as long as the attention it surrounds?  Every rank
+    sends 1/P of its local q|k|v to each of its P-1 peers over that peer's own link, and gets 1/P of the output back."""
+    rows = B * (S // P)                                              # local rows before the exchange
+    t_comm = rows * (2 * Hq + 2 * Hkv) * D * itemsize / P / _LINK_BYTES_PER_S
+    flops = 4.0 * B * (Hq // P) * S * (S * ring) * D * (0.5 if causal else 1.0)
+    return t_comm >= 0.5 * flops / _KERNEL_FLOPS_PER_S
+
+
+def _groups(Hq, Hkv, P, B=None, S=None, max_groups=None, link_bound=False):
     """(number of head groups, kv heads per rank per group, query heads per kv head).  A group is a
     set of whole KV heads (with their query heads) of every rank's post-exchange share.  With the problem
-    size (B, S = full sequence) given, the pipeline is kept shallow enough that every group's attention
-    launch still has one 256-row work item per CU (a starved launch costs more than the exposed exchange)."""
+    size (B, S = sequence after the exchange) given, the pipeline is kept shallow enough that every group's
+    attention launch still has _FILL_ITEMS 256-row work items (_FILL_ITEMS_LINK_BOUND when the caller found the
+    exchange long against the attention, `_link_bound`)."""
     assert Hq % P == 0 and Hkv % P == 0, f"heads ({Hq}, {Hkv}) not divisible by ulysses degree {P}"
     per_rank = Hkv // P
     ng = 1
     if P > 1:                       # nothing to hide without an exchange
         cap = _MAX_GROUPS if max_groups is None else min(_MAX_GROUPS, max_groups)
         if B is not None and S is not None:
-            cap = max(1, min(cap, (B * (Hq // P) * ((S + 255) // 256)) // _FILL_ITEMS))
+            fill = min(_FILL_ITEMS, _FILL_ITEMS_LINK_BOUND) if link_bound else _FILL_ITEMS
+            cap = max(1, min(cap, (B * (Hq // P) * ((S + 255) // 256)) // fill))
         for cand in range(min(cap, per_rank), 0, -1):
             if per_rank % cand == 0:
                 ng = cand
@@ -160,7 +178,9 @@ class _AsyncUSPFunc(torch.autograd.Function):
         P = dist.get_world_size(ulysses_pg)
         B, Sl, Hq, D = q.shape
         Hkv = k.shape[2]
-        ng, kvh, g = _groups(Hq, Hkv, P, B, Sl * P, max_groups=ng_cap)
+        ring = dist.get_world_size(ring_pg) if ring_pg is not None else 1
+        ng, kvh, g = _groups(Hq, Hkv, P, B, Sl * P, max_groups=ng_cap,
+                             link_bound=P > 1 and _link_bound(Hq, Hkv, P, B, Sl * P, D, q.element_size(), ring, causal))
         if softmax_scale is None:
             softmax_scale = D ** (-0.5)
         overlap = ng > 1                # kernels run beside later groups' exchanges

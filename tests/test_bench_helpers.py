@@ -78,7 +78,7 @@ def _probe_worker(rank, ws, ud, rd):
     glob = [torch.randn(B, S, H, D).to(torch.bfloat16) for _ in range(3)]
     lq, lk, lv = (Y.EXTRACT_FUNC_DICT["zigzag"](t, rank, world_size=ws, rd=rd, ud=ud) for t in glob)
     attn = Y.LongContextAttention(ring_impl_type="zigzag")
-    assert b.exchange_mode(attn, lq, lk, dict(ud=ud, Hq=H, Hkv=H, B=B), ws).startswith(
+    assert b.exchange_mode(attn, lq, lk, dict(ud=ud, rd=rd, Hq=H, Hkv=H, B=B), ws).startswith(
         "none" if ud == 1 else "one packed q|k|v exchange per head group, 2 group(s), pipelined")
     ref = attn(lq, lk, lv, causal=True)
     dev = torch.device("cpu")
