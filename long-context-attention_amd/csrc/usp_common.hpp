@@ -156,6 +156,18 @@ struct ItemWalk {
     const int loc = pass * wgs_l + ((pass & 1) ? (wgs_l - 1 - wg_l) : wg_l);
     return loc < items_l ? item0 + loc : -1;
   }
+  // Few heads: when one (batch, head) has more tiles than an XCD has items -- n_inner = m * items_l -- its tiles
+  // [0, n_inner), heaviest first, would be cut into m contiguous runs and the XCD with the first run gets several times
+  // the work of the one with the last (causal; B1 H4 S16384: 814 TFLOP/s against 1040 for 8 heads).  Deal them instead:
+  // round i gives tile i*m + j to run j, in alternating direction, so every run is still sorted heaviest first and all
+  // runs weigh the same.  `w` = item id as returned by at(); returns the id to decode (same head, dealt tile).
+  USP_DEV int dealt(int w, int n_inner) const {
+    if (items_l >= n_inner || n_inner % items_l != 0) return w;      // whole heads per XCD (or no XCD split at all)
+    const int m = n_inner / items_l;
+    const int head = w / n_inner, pos = w - head * n_inner;
+    const int j = pos / items_l, i = pos - j * items_l;
+    return head * n_inner + i * m + ((i & 1) ? (m - 1 - j) : j);
+  }
 };
 
 // Dynamic item queue, used for packed batches (sequences of unequal length defeat any static split: the

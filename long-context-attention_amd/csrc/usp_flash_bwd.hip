@@ -117,6 +117,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   int w = p_in.sched ? item_queue_next(queue, qstate, qslots, pass) : walk.at(pass);
   if (w < 0) break;
   BwdParams p = p_in;
+  if (!p_in.sched) w = walk.dealt(w, p.nblk);
   const int blk_r = w % p.nblk;
   int rest = w / p.nblk;
   int b, hkv, h0, blk, split_g = 0;
@@ -612,6 +613,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   int w = p_in.sched ? item_queue_next(queue, qstate, qslots, pass) : walk.at(pass);
   if (w < 0) break;
   BwdParams p = p_in;
+  if (!p_in.sched) w = walk.dealt(w, p.nblk);
   const int blk = w % p.nblk;                    // early key blocks are seen by most rows: first
   int rest = w / p.nblk;
   int g = 0;

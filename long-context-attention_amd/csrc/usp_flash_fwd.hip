@@ -83,6 +83,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   int w = p_in.sched ? item_queue_next(queue, qstate, qslots, pass) : walk.at(pass);
   if (w < 0) break;
   FwdParams p = p_in;
+  if (!p_in.sched) w = walk.dealt(w, p.nq);
   const int qt_r = w % p.nq;
   int rest = w / p.nq;
   const int qt = CAUSAL ? (p.nq - 1 - qt_r) : qt_r;      // heavy (late) tiles first

@@ -80,8 +80,9 @@ _MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer 
 
 
 # 256-row work items a head group's attention launch must still have.  Measured (kbench, C3 shape = one causal launch
-# per group, interleavable): 8 heads x 64 blocks = 512 items run at 1040 TFLOP/s, 4 heads = 256 items at 814, 2 heads at
-# 536 -- with one item per CU nothing balances the causal triangle.  So two items per CU are asked for ...
+# per group, interleavable): 8 heads x 64 blocks = 512 items run at 1040-1145 TFLOP/s, 4 heads = 256 items at 814 (905 since
+# the tiles of a head are dealt evenly to its XCDs), 2 heads at 536-565 -- with one item per CU nothing balances the causal
+# triangle.  So two items per CU are asked for ...
 _FILL_ITEMS = 512
 # ... unless the exchange is long against the attention it can hide behind: then the pipeline wins even with starved
 # launches.  C3 (2 GPUs, forward only, MHA): 50 MB in + 17 MB out per rank over ONE link = 1.05 ms against 0.5 ms of
