@@ -187,3 +187,19 @@ def test_abi_structs_match_the_header(tmp_path):
             assert ctypes.sizeof(cls) == int(layout[sname]), f"sizeof({sname}) vs {cls.__name__}"
     assert _C.ABI_VERSION == int(re.search(r"#define USP_ABI_VERSION (\d+)", open(
         os.path.join(ROOT, "include", "usp_hip.h")).read()).group(1))
+
+
+def test_head_group_cap_is_link_aware():
+    """hybrid/async_attn_layer.py: two 256-row items per CU per head-group launch, one where the exchange of a forward
+    pass is at least half as long as its attention (BASELINE configs[2] is link-bound, configs[4] is not)."""
+    from yunchang_amd.hybrid.async_attn_layer import _groups, _link_bound
+    c3 = _link_bound(16, 16, 2, 1, 16384, 128, 2, 1, True)            # 2 GPUs, ulysses 2, MHA, forward
+    c5 = _link_bound(32, 4, 2, 1, 16384, 128, 2, 4, True)             # 8 GPUs, ulysses 2 x ring 4, GQA
+    assert c3 and not c5
+    assert _groups(16, 16, 2, 1, 16384, link_bound=c3)[0] == 2 and _groups(16, 16, 2, 1, 16384)[0] == 1
+    assert _groups(32, 4, 2, 1, 16384, link_bound=c5) == (2, 1, 8)
+    assert _groups(32, 32, 8, 1, 131072)[0] == 4                      # long sequence: plenty of items, attention-bound
+    assert _groups(8, 8, 2, 1, 2048, link_bound=True)[0] == 1         # too small to split at all
+    assert _groups(16, 16, 1)[0] == 1                                 # no exchange, nothing to hide
+    with pytest.raises(AssertionError):
+        _groups(6, 6, 4)
