@@ -266,7 +266,7 @@ def kernel_source_sha16():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "long-context-attention_amd", "csrc")
-    for name in ("usp_common.hpp", "usp_flash_fwd.hip", "usp_flash_bwd.hip", "Makefile"):
+    for name in ("usp_common.hpp", "usp_item_deal.h", "usp_flash_fwd.hip", "usp_flash_bwd.hip", "Makefile"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]

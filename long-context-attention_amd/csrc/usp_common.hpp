@@ -7,6 +7,8 @@
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#define USP_DEAL_FN __device__ __forceinline__
+#include "usp_item_deal.h"
 
 namespace usp {
 
@@ -156,28 +158,9 @@ struct ItemWalk {
     const int loc = pass * wgs_l + ((pass & 1) ? (wgs_l - 1 - wg_l) : wg_l);
     return loc < items_l ? item0 + loc : -1;
   }
-  // Fewer than 8 heads (the Ulysses-8 / small head-group case): one (batch, head) has more tiles than an XCD has items.
-  // Cut contiguously, its tiles [0, n_inner), heaviest first, give one XCD the heavy end of the causal triangle and
-  // the next the light end (B1 H4/1 S32768: 1008 TFLOP/s forward against 1190 dealt; backward 655 against 824).  Deal
-  // them instead.  Regular case, n_inner = m * items_l: the m XCDs of a head take its tiles round by round in
-  // alternating direction (XCD j: tile i*m + j, or i*m + m-1-j in odd rounds).  Irregular head counts (3, 5, 6, 7):
-  // every head is dealt to all 8 XCDs the same way and the run is ordered round-major, i.e. still heaviest first across
-  // the heads (B1 H6 S16384 forward 769 -> 1020).  Every share is sorted heaviest first and all shares weigh the same.
-  // Launches with 8 or more heads keep the contiguous runs (dealing the remainder heads of 12 or 20 measured -1...-5 %:
-  // what they gain in balance they lose in K/V sharers behind one L2).
+  // Fewer than 8 heads: the tiles of a head that spans several XCDs are dealt to them evenly (usp_item_deal.h).
   // `w` = item id as returned by at(); returns the id to decode (head * n_inner + tile).
-  USP_DEV int dealt(int w, int n_inner) const {
-    if (items_l >= n_inner) return w;               // whole heads per XCD first (always so without the XCD split)
-    const int x = w / items_l, loc = w - x * items_l;
-    if (n_inner % items_l == 0) {
-      const int m = n_inner / items_l, j = x % m;
-      return (x / m) * n_inner + loc * m + ((loc & 1) ? (m - 1 - j) : j);
-    }
-    if ((n_inner & 7) != 0) return w;
-    const int heads = items_l / (n_inner >> 3);     // items_l = heads * n_inner / 8
-    const int i = loc / heads, head = loc - i * heads;
-    return head * n_inner + i * 8 + ((i & 1) ? (7 - x) : x);
-  }
+  USP_DEV int dealt(int w, int n_inner) const { return usp_deal_item(w, n_inner, items_l); }
 };
 
 // Dynamic item queue, used for packed batches (sequences of unequal length defeat any static split: the

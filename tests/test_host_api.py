@@ -203,3 +203,50 @@ def test_head_group_cap_is_link_aware():
     assert _groups(16, 16, 1)[0] == 1                                 # no exchange, nothing to hide
     with pytest.raises(AssertionError):
         _groups(6, 6, 4)
+
+
+def test_item_deal_is_a_balanced_bijection(tmp_path):
+    """csrc/usp_item_deal.h (the map the flash kernels use to hand the tiles of a head that spans several XCDs to those
+    XCDs) compiled for the host: for every (heads, tiles per head) it must permute the item ids -- a skipped or doubled
+    id would be a silently wrong result -- keep every id inside its head, keep every run sorted heaviest first, and,
+    where it deals at all, give the eight runs equal weight."""
+    import subprocess
+    src = tmp_path / "deal.c"
+    src.write_text('#define USP_DEAL_FN\n#include "usp_item_deal.h"\n')
+    lib = tmp_path / "libdeal.so"
+    subprocess.check_call(["gcc", "-O1", "-shared", "-fPIC", "-I",
+                           os.path.join(ROOT, "long-context-attention_amd", "csrc"), str(src), "-o", str(lib)])
+    deal = ctypes.CDLL(str(lib)).usp_deal_item
+    deal.restype = ctypes.c_int
+    dealt_cases = 0
+    for heads in range(1, 41):
+        for n_inner in (1, 2, 3, 4, 8, 12, 16, 20, 24, 32, 64, 96, 128, 256):
+            n = heads * n_inner
+            if n % 8:                                   # ItemWalk only splits by XCD when 8 divides the item count
+                continue
+            items_l = n // 8
+            ids = [deal(w, n_inner, items_l) for w in range(n)]
+            assert sorted(ids) == list(range(n)), (heads, n_inner)
+            if ids == list(range(n)):
+                continue
+            dealt_cases += 1
+            assert heads < 8, (heads, n_inner)          # 8 or more heads keep their contiguous runs
+            weights = []
+            for x in range(8):
+                run = ids[x * items_l:(x + 1) * items_l]
+                tiles = [t % n_inner for t in run]
+                per_head = {}
+                for t in run:
+                    per_head.setdefault(t // n_inner, []).append(t % n_inner)
+                assert all(v == sorted(v) for v in per_head.values()), (heads, n_inner, x)   # heaviest first per head
+                weights.append(sum(n_inner - t for t in tiles))
+            regular = n_inner % items_l == 0
+            rounds = items_l if regular else n_inner // 8          # tiles a run gets from one head
+            if rounds % 2 == 0:                         # whole (up, down) round pairs: exactly equal shares
+                assert len(set(weights)) == 1, (heads, n_inner, weights)
+            else:                                       # one unpaired round: shares differ by at most its spread
+                spread = (n_inner // items_l - 1) if regular else 7 * heads
+                assert max(weights) - min(weights) <= spread, (heads, n_inner, weights)
+    assert dealt_cases > 30
+    # without the XCD split (items_l = all items) nothing is remapped
+    assert all(deal(w, 64, 256) == w for w in range(256))
