@@ -177,7 +177,10 @@ def _async_worker(rank, ws, ud, rd, impl, Hq, Hkv):
                                                   (4, 4, 1, "basic", 16, 8), (4, 2, 2, "basic", 4, 4),
                                                   (4, 1, 4, "zigzag", 4, 2),      # ring 4: two-wave mesh fetch, B = 2
                                                   (8, 4, 2, "zigzag", 8, 4),      # ulysses 4 beside a ring of 2
-                                                  (8, 8, 1, "basic", 8, 8)])      # ulysses 8
+                                                  (8, 8, 1, "basic", 8, 8),       # ulysses 8
+                                                  (8, 1, 8, "zigzag", 4, 2),      # ring 8: two-wave mesh fetch over 7 peers
+                                                  (8, 1, 8, "basic", 2, 2),       # ring 8, direct K/V fetch
+                                                  (8, 2, 4, "strip", 4, 2)])      # stripe layout beside ulysses 2
 def test_exchange_variants_agree_and_match_exact_attention(ws, ud, rd, impl, Hq, Hkv):
     """LongContextAttention with the pipelined packed exchange (default), with one packed exchange, with the
     reference's three separate exchanges, and AsyncLongContextAttention: bit-identical
