@@ -242,6 +242,45 @@ def test_varlen_ring_on_gloo_matches_reference_golden(path):
             assert_close(res[r][key], getattr(g, key)[r], gt, gr, f"{g.name} {key} rank {r}")
 
 
+def _varlen_truth_worker(rank, ws, impl, lens, Hq, Hkv):
+    """No reference run has ring degree 8: exact causal attention per sequence (fp64 oracle) is the truth here."""
+    import torch.distributed as dist
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    from oracle import usp_oracle as O
+    set_block_backend(OracleBlockBackend())
+    torch.manual_seed(1)
+    D, T = 32, sum(lens)
+    cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    q, k, v, do = (torch.randn(T, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
+    layout = "zigzag" if impl == "zigzag" else "basic"
+    truth = [np.zeros((T, h, D)) for h in (Hq, Hq, Hkv, Hkv)]                 # out, dq, dk, dv
+    for a, b in zip(cu[:-1], cu[1:]):
+        qn, kn, vn, don = (t[a:b].float().numpy().astype(np.float64)[None] for t in (q, k, v, do))
+        ro, rl = O.attention_ref(qn, kn, vn, causal=True)
+        for dst, val in zip(truth, (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, True))):
+            dst[a:b] = val[0]
+    truth = [Y.extract_local_varlen(torch.from_numpy(t), cu, rank, ws, layout).float() for t in truth]
+    lq, lk, lv, ldo = (Y.extract_local_varlen(t, cu, rank, ws, layout) for t in (q, k, v, do))
+    for t in (lq, lk, lv):
+        t.requires_grad_(True)
+    cu_local = torch.tensor(cu // ws, dtype=torch.int32)
+    fn = Y.zigzag_ring_flash_attn_varlen_func if impl == "zigzag" else Y.ring_flash_attn_varlen_func
+    out = fn(lq, lk, lv, cu_local, int(max(lens)) // ws, causal=True, group=dist.group.WORLD)
+    out.backward(ldo)
+    got = [t.detach().float() for t in (out, lq.grad, lk.grad, lv.grad)]
+    return all(torch.allclose(a, t, atol=tol, rtol=tol) for a, t, tol in zip(got, truth, (2e-2, 5e-2, 5e-2, 5e-2)))
+
+
+@pytest.mark.parametrize("ws,impl,lens,Hq,Hkv", [(8, "zigzag", (64, 160, 32, 16), 4, 2), (8, "basic", (40, 8, 96), 2, 2),
+                                                 (4, "zigzag", (8, 8, 72), 2, 1)])
+def test_varlen_ring_matches_exact_attention(ws, impl, lens, Hq, Hkv):
+    """Packed variable-length rings at ring degree 8 (and sequences of one 1-token chunk per rank half) against exact
+    per-sequence attention, forward and backward, with GQA."""
+    assert all(run_distributed(_varlen_truth_worker, ws, impl, lens, Hq, Hkv))
+
+
 # ---- launches inside a ring (or a pipelined exchange) must ask for interleavable launches ---------------------
 def _overlap_worker(rank, ws, ud, rd, use_async, force_groups):
     import yunchang_amd as Y
