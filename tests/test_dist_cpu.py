@@ -189,6 +189,47 @@ def test_exchange_variants_agree_and_match_exact_attention(ws, ud, rd, impl, Hq,
     assert all(run_distributed(_async_worker, ws, ud, rd, impl, Hq, Hkv))
 
 
+def _other_layers_worker(rank, ws, layer, ud, rd, impl, Hq, Hkv, causal):
+    """UlyssesAttention and LongContextAttentionQKVPacked at world size 8, where no
+    reference run exists: exact attention on the unsharded tensors (fp64 oracle) is the truth."""
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    from oracle import usp_oracle as O
+    set_block_backend(OracleBlockBackend())
+    Y.set_seq_parallel_pg(ud, rd, rank, ws)
+    torch.manual_seed(2)
+    B, S, D = 2, 16 * ws, 32
+    q, k, v, do = (torch.randn(B, S, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
+    ext = Y.EXTRACT_FUNC_DICT[impl]
+    qn, kn, vn, don = (t.float().numpy().astype(np.float64) for t in (q, k, v, do))
+    ro, rl = O.attention_ref(qn, kn, vn, causal=causal)
+    truth = [ext(torch.from_numpy(np.ascontiguousarray(t)), rank, world_size=ws, rd=rd, ud=ud).float()
+             for t in (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, causal))]
+    lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=rd, ud=ud).detach().clone() for t in (q, k, v, do))
+    if layer == "ulysses":
+        for t in (lq, lk, lv):
+            t.requires_grad_(True)
+        out = Y.UlyssesAttention(Y.PROCESS_GROUP.ULYSSES_PG, attn_type=Y.AttnType.HIP)(lq, lk, lv, causal=causal)
+        out.backward(ldo)
+        got = [out, lq.grad, lk.grad, lv.grad]
+    else:
+        qkv = torch.stack([lq, lk, lv], dim=2).requires_grad_(True)
+        out = Y.LongContextAttentionQKVPacked(ring_impl_type=impl, attn_type=Y.AttnType.HIP)(qkv, causal=causal)
+        out.backward(ldo)
+        got = [out, qkv.grad[:, :, 0], qkv.grad[:, :, 1], qkv.grad[:, :, 2]]
+    got = [t.detach().float() for t in got]
+    return all(torch.allclose(a, t, atol=tol, rtol=tol) for a, t, tol in zip(got, truth, (2e-2, 5e-2, 5e-2, 5e-2)))
+
+
+@pytest.mark.parametrize("ws,layer,ud,rd,impl,Hq,Hkv,causal", [(8, "ulysses", 8, 1, "basic", 16, 8, True),
+                                                              (4, "ulysses", 4, 1, "basic", 4, 4, False),
+                                                              (8, "qkvpacked", 4, 2, "zigzag", 8, 8, True),
+                                                              (8, "qkvpacked", 2, 4, "basic", 4, 4, False)])
+def test_ulysses_and_qkvpacked_layers_match_exact_attention(ws, layer, ud, rd, impl, Hq, Hkv, causal):
+    assert all(run_distributed(_other_layers_worker, ws, layer, ud, rd, impl, Hq, Hkv, causal))
+
+
 # ---- packed variable-length ring schedules (SURVEY.md 8(f) row 4) -------------------------------------
 def _varlen_worker(rank, ws, path, packed_qkv):
     import torch.distributed as dist
