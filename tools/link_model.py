@@ -1,0 +1,82 @@
+"""Link arithmetic for the multi-GPU BASELINE configs (DEV TOOL, no GPU needed).
+
+What one rank's iteration should cost on a real node, from (a) the per-rank compute-only times measured on one MI355X
+(tools/rank_emulation.py, profiles/r02_rank_emulation.txt), (b) the bytes each schedule puts on a link and (c) an
+assumed xGMI rate per link and direction.  It replays the ORDER the package issues things in -- every input exchange of
+the head groups first on the "ulysses" lane, group i's output exchange behind its attention; the ring K/V fetch in one
+or two waves over P-1 links in parallel; the travelling dK/dV one hop per step -- with two resources, the lane(s) and
+the compute stream.  Nothing here is a measurement; it is the expectation the driver's N = 2/4/8 runs can be held
+against."""
+import argparse
+
+MiB = 2 ** 20
+
+
+def pipeline(t_in, t_comp, t_out, ng, eff=1.0):
+    """ng head groups: inputs queued up-front on the lane, outputs as their attention finishes.  Returns (total,
+    exposed = total - compute)."""
+    i, c, o = t_in / ng, t_comp / eff / ng, t_out / ng
+    lane = comp = 0.0
+    landed = []
+    for _ in range(ng):
+        lane += i
+        landed.append(lane)
+    for g in range(ng):
+        comp = max(comp, landed[g]) + c
+        lane = max(lane, comp) + o
+    return lane, lane - t_comp / eff
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--link-gbs", type=float, default=64.0, help="one xGMI link, one direction, GB/s")
+    a = ap.parse_args()
+    bw = a.link_gbs * 1e9
+    ms = lambda nbytes: nbytes / bw * 1e3
+    print(f"assumed link rate {a.link_gbs:.0f} GB/s per direction; compute-only times from profiles/r02_rank_emulation.txt\n")
+
+    # configs[2]: 2 GPUs, ulysses 2, B1 S16384 H16 D128 bf16, forward.  Per rank: q,k,v local 3 x 32 MiB, half goes to the peer.
+    t_in, t_out = ms(48 * MiB), ms(16 * MiB)
+    print("configs[2]  2 GPUs  ulysses 2, forward          exchange in %.2f ms, out %.2f ms over ONE link" % (t_in, t_out))
+    for ng, comp in ((1, 0.48 / 0.93), (2, 2 * 0.30), (4, 4 * 0.26)):      # kernel time of the group launches (kbench)
+        tot, exp = pipeline(t_in, comp, t_out, ng)
+        print("   %d head group(s): %.2f ms per iteration = %5.0f TFLOP/s on 2 GPUs (attention %.2f ms, exposed %.2f ms)"
+              % (ng, tot, 2 * 0.2749 / tot * 1e3, comp, exp))
+
+    # configs[3]: 4 GPUs, ring 4 zigzag, B1 S32768 H16, forward.  K/V 2 x 32 MiB per peer, each peer over its own link.
+    # kernel times of a rank (rocprofv3, profiles/r02_rank_emulation.txt): step 0 (causal) 0.294 ms, a half step 0.143 ms
+    step0, half = 0.294, 0.143
+    whole = ms(64 * MiB)                                                    # K and V of one peer over one link
+    print("\nconfigs[3]  4 GPUs  ring 4 zigzag, forward      K/V of a peer: %.2f ms per link" % whole)
+    t = step0
+    for s in (1, 2, 3):                                                     # hop s has crossed s links one after the other
+        t = max(t, s * whole) + 2 * half
+    print("   hop-by-hop relay (reference order):  %.2f ms per iteration" % t)
+    print("   one-wave mesh fetch:                 %.2f ms (steps 1-3 wait for the whole fetch)" % (max(step0, whole) + 6 * half))
+    worst = 0.0
+    for r in range(4):                                                      # two waves: front halves land at whole/2, back halves at whole
+        t = max(step0, whole / 2)
+        both = [s for s in (1, 2, 3) if s > r]                              # steps that also read the back half
+        t += 2 * half * (3 - len(both)) + half * len(both)                  # everything that only needs wave A
+        t = max(t, whole) + half * len(both) if both else t                 # back-half keys once wave B has landed
+        worst = max(worst, t)
+    print("   two-wave fetch, split steps:         %.2f ms (slowest rank; front halves land after %.2f ms)" % (worst, whole / 2))
+    print("   -> %.0f TFLOP/s on 4 GPUs at the last figure, %.0f with the relay" % (4 * 1.0995 / worst * 1e3, 4 * 1.0995 / (3 * whole + 2 * half) * 1e3))
+
+    # configs[4]: 8 GPUs, ulysses 2 x ring 4, B1 S65536 H32/4, forward + backward.
+    fwd, bwd = 16.7 * 0.29, 16.7 * 0.71
+    ex = dict(fi=ms(40 * MiB), fo=ms(32 * MiB), bi=ms(32 * MiB), bo=ms(40 * MiB))
+    hop = ms(32 * MiB)
+    print("\nconfigs[4]  8 GPUs  ulysses 2 x ring 4, fwd+bwd  exchanges %.2f + %.2f + %.2f + %.2f ms, dK/dV hop %.2f ms, K/V fetch %.2f ms x 2"
+          % (ex["fi"], ex["fo"], ex["bi"], ex["bo"], hop, ms(16 * MiB)))
+    for ng, eff_f, eff_b in ((1, 1.0, 1.0), (2, 0.95, 0.99)):
+        tf, _ = pipeline(ex["fi"], fwd, ex["fo"], ng, eff_f)
+        tb, _ = pipeline(ex["bi"], bwd, ex["bo"], ng, eff_b)
+        tot = tf + tb + ng * (hop / ng)                                     # each group's last dK/dV hop (1/ng of the heads) is exposed
+        comm = sum(ex.values()) + 4 * hop * 1.0 + 2 * ms(16 * MiB)
+        print("   %d head group(s): %.1f ms per iteration = %5.0f TFLOP/s on 8 GPUs; overlap = 1 - (t - t_compute)/t_comm = %.2f"
+              % (ng, tot, 8 * 15.39 / tot * 1e3, 1 - (tot - (fwd / eff_f + bwd / eff_b)) / comm))
+
+
+if __name__ == "__main__":
+    main()
