@@ -21,6 +21,7 @@ import ctypes
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -359,7 +360,10 @@ def exchange_mode(attn, lq, lk, cfg, ws):
 
 def barrier(ws):
     if ws > 1:            # a barrier over one rank is empty; NCCL would still launch an all-reduce for it
-        dist.barrier()
+        if dist.get_backend() == "nccl":      # name the device: without it ProcessGroupNCCL guesses one from the rank
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def _sync(dev):
@@ -436,6 +440,45 @@ def overlap_probe(step, steps, ws, dev, t_iter):
             "ms_comm_only": round(t_comm * 1e3, 4),
             "note": "comm-only skips every kernel (incl. pack/unpack); compute-only replaces each transfer by a "
                     "local copy of the same size"}
+
+
+class _LineOnce:
+    """Prints rank 0's JSON line exactly once, from whichever thread gets there first (None on other ranks)."""
+
+    def __init__(self, line):
+        self.line, self._lock, self.done = line, threading.Lock(), False
+
+    def __call__(self, extra=None):
+        with self._lock:
+            if self.done:
+                return
+            self.done = True
+            if self.line is not None:
+                print(json.dumps({**self.line, **(extra or {})}), flush=True)
+
+
+class _Deadline:
+    """Context manager: if the body has not finished after `seconds`, call emit(extra) and leave the process with exit
+    code 0 (every rank arms the same deadline, so a rank stuck in a collective cannot keep the launcher waiting for
+    the process-group timeout)."""
+
+    def __init__(self, seconds, emit, extra):
+        self._t = threading.Timer(seconds, self._fire)
+        self._t.daemon = True
+        self._emit, self._extra = emit, extra
+
+    def _fire(self):
+        self._emit(self._extra)
+        sys.stdout.flush()
+        os._exit(0)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._t.cancel()
+        return False
 
 
 def main():
@@ -531,14 +574,7 @@ def main():
     flops = fwd_flops(cfg["B"], cfg["Hq"], cfg["S"], cfg["D"]) * (3.5 if cfg["bwd"] else 1.0)
     value = flops / (ms * 1e-3) / 1e12
 
-    overlap = None
-    if ws > 1 and not args.no_overlap:
-        try:
-            overlap = overlap_probe(step, max(3, args.steps // 4), ws, dev, ms * 1e-3)
-        except Exception as e:
-            print(f"[rank {rank}] overlap probe failed to run: {e!r}", file=sys.stderr)
-            overlap = {"value": None, "error": repr(e)}
-
+    line = None
     if rank == 0:
         line = {
             "metric": "attention TFLOP/s (algorithmic, causal) of LongContextAttention ulysses x ring",
@@ -556,19 +592,33 @@ def main():
             "parity_max_abs_err_vs_reference_op": parity_op,
             "parity_max_abs_err_vs_fp64_rows": parity_rows,
         }
-        if overlap is not None:
-            line["overlap"] = overlap
         if smoke:
             line["smoke"] = f"backend={backend}, all ranks on cuda:0 -- NOT a measurement"
-        if ws == 1:
-            line["roofline"] = roofline
-            roofline["seq64k_single_gpu"] = seq64k_single_gpu(dev)
-            line["reference_kernel_on_this_gpu"] = reference_kernel(cfg, dev, roofline["achieved"])
-            if cfg["bwd"]:
-                line["reference_fwdbwd_on_this_gpu"] = reference_fwdbwd(cfg, dev, value)
-            if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(line), flush=True)
+
+    # The measurement is complete here.  What follows is informative and must never cost the line: the overlap probe
+    # re-runs the step with patched transports on every rank, so it runs under a deadline -- if it has not returned
+    # by then (a rank stuck in a collective), rank 0 prints the line without it and every rank leaves.
+    emit = _LineOnce(line)
+    if ws > 1 and not args.no_overlap:
+        with _Deadline(float(os.environ.get("USP_BENCH_PROBE_DEADLINE_S", "120")), emit,
+                       {"overlap": {"value": None, "error": "overlap probe did not finish before its deadline"}}):
+            try:
+                overlap = overlap_probe(step, max(3, args.steps // 4), ws, dev, ms * 1e-3)
+            except Exception as e:
+                print(f"[rank {rank}] overlap probe failed to run: {e!r}", file=sys.stderr)
+                overlap = {"value": None, "error": repr(e)}
+        if rank == 0:
+            line["overlap"] = overlap
+
+    if rank == 0 and ws == 1:
+        line["roofline"] = roofline
+        roofline["seq64k_single_gpu"] = seq64k_single_gpu(dev)
+        line["reference_kernel_on_this_gpu"] = reference_kernel(cfg, dev, roofline["achieved"])
+        if cfg["bwd"]:
+            line["reference_fwdbwd_on_this_gpu"] = reference_fwdbwd(cfg, dev, value)
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+    emit()
     barrier(ws)
     dist.destroy_process_group()
 

@@ -94,3 +94,31 @@ def test_timed_and_overlap_probe_on_gloo(ws, ud, rd):
     """bench.timed / bench.overlap_probe on the N > 1 code path: a ring, and the packed + pipelined exchange beside
     a ring (compute-only swaps the wire for local copies, comm-only skips every kernel; both are restored)."""
     assert all(run_distributed(_probe_worker, ws, ud, rd))
+
+
+_DEADLINE_SCRIPT = """
+import importlib.util, sys, time
+spec = importlib.util.spec_from_file_location("bench_mod", sys.argv[1])
+b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+emit = b._LineOnce({"value": 1.0})
+with b._Deadline(float(sys.argv[2]), emit, {"overlap": {"value": None, "error": "deadline"}}):
+    time.sleep(float(sys.argv[3]))
+emit({"overlap": {"value": 0.5}})
+emit()                                  # a second call prints nothing
+"""
+
+
+@pytest.mark.parametrize("deadline,body,expect", [(0.3, 30.0, None), (30.0, 0.05, 0.5)])
+def test_probe_deadline_prints_the_line_exactly_once(deadline, body, expect):
+    """A probe stuck in a collective must not cost the measurement: at the deadline the line is printed without the
+    probe's entry and the process leaves with exit code 0; a probe that finishes prints the line with it.  One line."""
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-c", _DEADLINE_SCRIPT, os.path.join(ROOT, "bench.py"), str(deadline), str(body)],
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["value"] == 1.0 and line["overlap"]["value"] == expect
