@@ -107,7 +107,7 @@ def parity_check(cfg, rank, ws, out_local, q, k, v, n_rows=6):
             pos += b - a
         del ref, kk, vv
     except Exception as e:                                   # the op may be missing from a torch build
-        print(f"[rank {rank}] reference op not available for the parity check: {e!r}", file=sys.stderr)
+        print(f"[rank {rank}] reference op not available for the parity check: {repr(e)[:160]}", file=sys.stderr)
     worst_rows, pos = 0.0, 0
     for a, b in ranges:
         for row in sorted({a, b - 1, *np.random.RandomState(a).randint(a, b, size=n_rows).tolist()}):
@@ -481,7 +481,9 @@ class _Deadline:
         return False
 
 
-def main():
+def main(argv=None, dev=None):
+    """`argv` / `dev`: the CPU tests drive this function in-process on host tensors (gloo group already set up, a
+    test block backend installed); the driver calls it with neither."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -492,7 +494,7 @@ def main():
     ap.add_argument("--bwd", type=int, default=-1, help="override: 1 = fwd+bwd, 0 = fwd only")
     ap.add_argument("--async-ulysses", action="store_true",
                     help="use AsyncLongContextAttention (head-group pipelined all-to-all) instead of LongContextAttention")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -512,15 +514,18 @@ def main():
     smoke = backend != "nccl"
     if smoke:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if dev is None:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if ws == 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29751")
-    dist.init_process_group(backend, rank=rank, world_size=ws)
+    own_pg = not dist.is_initialized()
+    if own_pg:
+        dist.init_process_group(backend, rank=rank, world_size=ws)
 
     import yunchang_amd as Y
-    if smoke:      # gloo's p2p is not stream-ordered for device tensors (tests/test_gpu_multiproc.py)
+    if smoke and dev.type == "cuda":      # gloo's p2p is not stream-ordered for device tensors (tests/test_gpu_multiproc.py)
         import yunchang_amd.ring.utils as _U
         _commit = _U.RingComm.commit
         _U.RingComm.commit = lambda self: (torch.cuda.synchronize(), _commit(self))[1]
@@ -593,7 +598,7 @@ def main():
             "parity_max_abs_err_vs_fp64_rows": parity_rows,
         }
         if smoke:
-            line["smoke"] = f"backend={backend}, all ranks on cuda:0 -- NOT a measurement"
+            line["smoke"] = f"backend={backend}, all ranks on {dev} -- NOT a measurement"
 
     # The measurement is complete here.  What follows is informative and must never cost the line: the overlap probe
     # re-runs the step with patched transports on every rank, so it runs under a deadline -- if it has not returned
@@ -620,7 +625,8 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg)
     emit()
     barrier(ws)
-    dist.destroy_process_group()
+    if own_pg:
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

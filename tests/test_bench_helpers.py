@@ -122,3 +122,51 @@ def test_probe_deadline_prints_the_line_exactly_once(deadline, body, expect):
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["value"] == 1.0 and line["overlap"]["value"] == expect
+
+
+def _main_worker(rank, ws):
+    """bench.main() end to end on host tensors: gloo group of the test harness, the oracle as block backend, tiny
+    workloads, the kernel-only probes (which need the device) stubbed."""
+    import contextlib
+    import io
+    import json
+    import yunchang_amd.hybrid.async_attn_layer as AL
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    b = _bench()
+    set_block_backend(OracleBlockBackend())
+    AL._FILL_ITEMS = 1
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), USP_BENCH_BACKEND="gloo")
+    for n, w in b.WORKLOADS.items():
+        w.update(B=1, S=64 * n, Hq=4, Hkv=4 if n < 8 else 2, D=32)
+    b.kernel_roofline = lambda cfg, dev: {"achieved": 1.0, "stub": True}
+    b.seq64k_single_gpu = lambda dev: {"stub": True}
+    b.reference_kernel = lambda cfg, dev, ours: {"stub": True}
+    b.cpu_baseline = lambda cfg: {"stub": True}
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        b.main(["--gpus", str(ws), "--steps", "2", "--warmup", "1"], dev=torch.device("cpu"))
+    lines = [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]
+    if rank != 0:
+        return lines == []
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    need = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "parity_max_abs_err_vs_fp64_rows"}
+    assert need <= set(line), need - set(line)
+    assert line["n_gpus"] == ws and line["steps"] == 2 and line["ms_per_step"] > 0, line
+    assert line["parity_max_abs_err_vs_fp64_rows"] < 2e-2
+    if ws == 1:
+        assert {"roofline", "cpu_baseline", "reference_kernel_on_this_gpu"} <= set(line) and "overlap" not in line
+        assert line["roofline"]["seq64k_single_gpu"] == {"stub": True}
+    else:
+        assert set(line["overlap"]) >= {"value", "ms_iter", "ms_compute_only", "ms_comm_only"}
+    return True
+
+
+@pytest.mark.parametrize("ws", [1, 2, 4, 8])
+def test_bench_main_prints_one_contract_line(ws):
+    """The driver's contract on every GPU count it launches (N = 1, 2, 4, 8 -> ulysses x ring grids 1x1, 2x1, 1x4,
+    2x4 with GQA and a backward): rank 0 prints exactly ONE JSON line carrying the contract keys, the in-bench
+    parity of every rank's shard and -- for N > 1 -- the overlap probe; other ranks print nothing."""
+    assert all(run_distributed(_main_worker, ws))
