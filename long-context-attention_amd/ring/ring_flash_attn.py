@@ -11,7 +11,7 @@ import torch.distributed as dist
 
 from ..kernels import AttnType
 from ..kernels.attention import get_block_backend
-from .utils import KVRelay, final_grads, travel_dkdv
+from .utils import FULL, KVRelay, final_grads, travel_dkdv
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
 
@@ -81,7 +81,9 @@ def ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, sof
         be.add(dk_acc, dk_acc, dk_blk)
         be.add(dv_acc, dv_acc, dv_blk)
 
-    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold)
+    # under causal only steps <= rank compute (:93-122)
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be,
+                                 extent=lambda rank, step: None if (causal and step > rank) else FULL)
     return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 
 

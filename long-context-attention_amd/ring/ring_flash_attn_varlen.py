@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
-from .utils import KVRelay, final_grads, travel_dkdv
+from .utils import FULL, KVRelay, final_grads, travel_dkdv
 from .varlen_utils import SeqTables, unflatten_lse
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
@@ -84,7 +84,8 @@ def ring_flash_attn_varlen_backward(process_group, dout, q, k, v, out, softmax_l
         be.add(dk_acc, dk_acc, dk_blk)
         be.add(dv_acc, dv_acc, dv_blk)
 
-    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, zero=True)
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, zero=True, be=be,
+                                 extent=lambda rank, step: None if (causal and step > rank) else FULL)
     return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 
 

@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 from ..kernels import AttnType
 from ..kernels.attention import get_block_backend
-from .utils import KVRelay, final_grads, travel_dkdv
+from .utils import FULL, KVRelay, final_grads, travel_dkdv
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
 
@@ -94,7 +94,9 @@ def stripe_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, s
     def fold(step, dk_acc, dv_acc, dk_blk, dv_blk):
         stripe_bwd_fold(be, r, step, dk_acc, dv_acc, dk_blk, dv_blk)
 
-    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold)
+    # steps > rank see k[:, :-1] only (:137-160, :179-181); a one-token shard has nothing to do there
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be,
+                                 extent=lambda rank, step: FULL if step <= rank else (slice(0, S - 1) if S > 1 else None))
     return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 
 

@@ -12,7 +12,8 @@ import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
 
-__all__ = ["update_out_and_lse", "RingComm", "KVRelay", "ZigzagKVFetch", "kv_relay_mode", "travel_dkdv", "final_grads"]
+__all__ = ["update_out_and_lse", "RingComm", "KVRelay", "ZigzagKVFetch", "kv_relay_mode", "travel_dkdv", "return_dkdv_direct",
+           "dkdv_return_mode", "FULL", "final_grads"]
 
 
 def update_out_and_lse(out: Optional[torch.Tensor], lse: Optional[torch.Tensor],
@@ -290,7 +291,16 @@ def kv_relay_mode(P: int) -> str:
     return os.environ.get("USP_KV_RELAY", "direct" if P > 2 else "chain")
 
 
-def travel_dkdv(process_group, k, v, block, fold, zero: bool = False):
+def dkdv_return_mode() -> str:
+    """"relay" (the reference's hop-by-hop travel, default) or "direct" (every block straight to its owner):
+    USP_DKDV_RETURN."""
+    return os.environ.get("USP_DKDV_RETURN", "relay")
+
+
+FULL = slice(None)
+
+
+def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=None, be=None):
     """The travelling dK/dV of every ring backward (zigzag_ring_flash_attn.py:139-183, ring_flash_attn.py:
     86-147): the fp32 accumulators of K/V block j visit every rank that attends to it, one hop per step,
     each rank adding its block result; after P hops they are back home.
@@ -299,13 +309,19 @@ def travel_dkdv(process_group, k, v, block, fold, zero: bool = False):
             runs the block backward of `step` against the K/V that arrived after `step` hops, writing the
             dK/dV block into dk_dst/dv_dst (at step 0 these ARE the travelling accumulators);
         fold(step, dk_acc, dv_acc, dk_blk, dv_blk)
-            adds the block into the accumulators that just arrived.
+            adds this step's block into the accumulators that just arrived;
+        extent(rank, step) -> None | slice
+            the K/V rows (dim 1) the block of `step` on ring rank `rank` carries gradients for (None: that step
+            computes nothing there; FULL: all rows).  Given together with `be`, USP_DKDV_RETURN=direct is honoured
+            (`return_dkdv_direct`).
 
     The hop of step s is posted from the compute stream right after the kernels of step s, and runs beside
     the kernels of step s+1.  `zero`: start every buffer from zeros (packed batches: the kernels do not touch
     rows outside every sequence's range, which would otherwise travel -- and be summed -- uninitialised).
     Returns the final (dk, dv) fp32 accumulators."""
     P = dist.get_world_size(process_group)
+    if P > 1 and extent is not None and be is not None and dkdv_return_mode() == "direct":
+        return return_dkdv_direct(process_group, k, v, block, extent, be, zero)
     new = (lambda t: torch.zeros(t.shape, dtype=torch.float32, device=t.device)) if zero else \
           (lambda t: torch.empty(t.shape, dtype=torch.float32, device=t.device))
     dk_blk, dv_blk = new(k), new(v)
@@ -329,6 +345,61 @@ def travel_dkdv(process_group, k, v, block, fold, zero: bool = False):
             d_comm.commit()
         d_comm.wait()
     return next_dk, next_dv
+
+
+def return_dkdv_direct(process_group, k, v, block, extent, be, zero: bool = False):
+    """dK/dV without the relay (USP_DKDV_RETURN=direct): ring rank r computes at step s the block of the K/V owned
+    by rank r-s and sends it STRAIGHT to that owner, which adds the P-1 arriving blocks to its own step-0 block in
+    step order -- the order the relay adds them in, so the result is bit-identical to it.
+
+    What the xGMI mesh buys: the relay moves the whole fp32 accumulator over the ONE link to rank r+1 every step,
+    and hop s cannot start before hop s-1 has landed AND step s has been computed; here the block of step s rides
+    the link to rank r-s (a different link every step), depends on nothing but its own kernels, and carries only the
+    rows it has gradients for (`extent`: the zigzag steps s <= r produce front-half rows only, a quarter of all bytes
+    is never sent).  At the 8-GPU BASELINE config either form hides behind 3.4 ms of kernels per step; an MHA ring
+    (2 x 64 MiB of fp32 per hop at ring 4 x 8192 tokens x 16 heads, ~2 ms per link against ~0.9 ms of kernels) is
+    link-bound in the relay and not here.  Costs P-1 receive buffers instead of one (sized for 288 GB).
+    Every step's send is posted from the compute stream behind that step's kernels, like the relay's hops."""
+    P = dist.get_world_size(process_group)
+    r = dist.get_rank(process_group)
+    new = (lambda shape, dev: torch.zeros(shape, dtype=torch.float32, device=dev)) if zero else \
+          (lambda shape, dev: torch.empty(shape, dtype=torch.float32, device=dev))
+    to_global = (lambda i: dist.get_global_rank(process_group, i % P)) if process_group is not None else (lambda i: i % P)
+
+    def rows(t, sl):                                    # the rows of a block that carry gradients
+        return t if sl == FULL else t[:, sl]
+
+    def wire(t, sl):                                    # ... as a contiguous tensor (a view at batch 1)
+        return rows(t, sl).contiguous()
+
+    pending = []
+    with KVRelay(process_group, k, v) as relay:
+        kk, vv = relay.get(0)
+        dk_acc, dv_acc = new(k.shape, k.device), new(v.shape, v.device)
+        block(0, kk, vv, dk_acc, dv_acc)
+        for step in range(1, P):
+            kk, vv = relay.get(step)
+            out_sl, in_sl = extent(r, step), extent((r + step) % P, step)
+            comm = RingComm(process_group)
+            keep = None
+            if out_sl is not None:
+                dk_blk, dv_blk = new(k.shape, k.device), new(v.shape, v.device)      # one pair per step: the send
+                block(step, kk, vv, dk_blk, dv_blk)                                  # reads it beside later steps
+                keep = (wire(dk_blk, out_sl), wire(dv_blk, out_sl))
+                comm._ops += [dist.P2POp(dist.isend, t, to_global(r - step), group=process_group) for t in keep]
+            got = None
+            if in_sl is not None:
+                got = tuple(new(rows(t, in_sl).shape, t.device) for t in (k, v))
+                comm._ops += [dist.P2POp(dist.irecv, t, to_global(r + step), group=process_group) for t in got]
+            if comm._ops:
+                comm.commit()
+                pending.append((comm, in_sl, got, keep))
+        for comm, in_sl, got, _keep in pending:         # step order == the relay's summation order
+            comm.wait()
+            if got is not None:
+                be.add(rows(dk_acc, in_sl), rows(dk_acc, in_sl), got[0])
+                be.add(rows(dv_acc, in_sl), rows(dv_acc, in_sl), got[1])
+    return dk_acc, dv_acc
 
 
 def final_grads(be, refs, accs):

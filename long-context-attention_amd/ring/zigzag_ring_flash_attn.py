@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 from ..kernels import AttnType
 from ..kernels.attention import get_block_backend
-from .utils import KVRelay, ZigzagKVFetch, final_grads, kv_relay_mode, travel_dkdv
+from .utils import FULL, KVRelay, ZigzagKVFetch, final_grads, kv_relay_mode, travel_dkdv
 
 
 
@@ -136,7 +136,9 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
     def fold(step, dk_acc, dv_acc, dk_blk, dv_blk):
         zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk)
 
-    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold)
+    # steps s <= rank carry gradients for the front-half K/V rows only (:151-155, :161-170)
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be,
+                                 extent=lambda rank, step: slice(0, c) if step <= rank else FULL)
     return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 
 

@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
-from .utils import KVRelay, final_grads, travel_dkdv
+from .utils import FULL, KVRelay, final_grads, travel_dkdv
 from .varlen_utils import SeqTables, unflatten_lse
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
@@ -113,7 +113,9 @@ def zigzag_ring_flash_attn_varlen_backward(process_group, dout, q, k, v, out, so
         be.add(dk_acc, dk_acc, dk_blk)
         be.add(dv_acc, dv_acc, dv_blk)
 
-    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, zero=True)
+    # the front halves of a packed batch are not one row range: every block travels whole (zeros elsewhere)
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, zero=True, be=be,
+                                 extent=lambda rank, step: FULL)
     return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 
 

@@ -21,6 +21,9 @@ def _usp_worker(rank, ws, path, use_autograd):
     g = Golden(path)
     be = OracleBlockBackend()
     set_block_backend(be)
+    import yunchang_amd.ring.utils as U
+    direct_calls, real_direct = [], U.return_dkdv_direct
+    U.return_dkdv_direct = lambda *a, **k: (direct_calls.append(1), real_direct(*a, **k))[1]
     dtype = getattr(torch, g.dtype)
     Y.set_seq_parallel_pg(g.ud, g.rd, rank, ws)
     ext = Y.EXTRACT_FUNC_DICT[g.impl]
@@ -42,7 +45,7 @@ def _usp_worker(rank, ws, path, use_autograd):
         qkv = torch.stack([lq.detach(), lk.detach(), lv.detach()], dim=2).requires_grad_(g.bwd)
         attn = Y.LongContextAttentionQKVPacked(ring_impl_type=g.impl, attn_type=Y.AttnType.HIP)
         out = attn(qkv, **kw)
-    res = {"out": out.detach().float().numpy(), "calls": list(be.calls)}
+    res = {"out": out.detach().float().numpy(), "calls": list(be.calls), "direct": direct_calls}
     if g.bwd:
         out.backward(ldo)
         if qkv is not None:
@@ -376,3 +379,40 @@ def test_kernels_inside_a_transfer_window_are_launched_interleavable(ud, rd, use
     `backend.beside_transfers()` (USP_LAUNCH_INTERLEAVE on the C ABI).  The backend holds no mutable state."""
     for seen in run_distributed(_overlap_worker, 2, ud, rd, use_async, force_groups):
         assert seen and all(d == expect for _, d in seen), seen
+
+
+# ---- USP_DKDV_RETURN=direct: every dK/dV block straight to its owner instead of the hop-by-hop relay ---------------
+_RING_BWD = [f for f in MULTI if Golden(f).rd > 1 and Golden(f).bwd]
+
+
+@pytest.mark.parametrize("path", _RING_BWD, ids=lambda p: p.split("/")[-1][:-4])
+def test_direct_dkdv_return_is_bit_identical_to_the_relay(path, monkeypatch):
+    """The owner adds the arriving blocks in step order = the order the relay adds them in: same fp32 sums, bit for
+    bit, on every reference grid with a ring (zigzag incl. the half-row blocks, basic causal and full, stripe, batch 2,
+    GQA, beside a Ulysses exchange) -- and therefore the same agreement with the reference's own run."""
+    g = Golden(path)
+    relay = run_distributed(_usp_worker, g.ws, path, True)
+    monkeypatch.setenv("USP_DKDV_RETURN", "direct")
+    direct = run_distributed(_usp_worker, g.ws, path, True)
+    atol, rtol = TOL[g.dtype]["grad"]
+    for r in range(g.ws):
+        for key in ("out", "dq", "dk", "dv"):
+            assert np.array_equal(direct[r][key], relay[r][key]), f"{g.name} {key} rank {r}"
+        for key in ("dq", "dk", "dv"):
+            assert_close(direct[r][key], getattr(g, key)[r], atol, rtol, f"{g.name} {key} rank {r} vs reference run")
+        # the block kernels ran on the same shapes in the same order (only the transport differs)
+        assert direct[r]["calls"] == relay[r]["calls"]
+        assert len(direct[r]["direct"]) >= 1 and relay[r]["direct"] == []
+
+
+@pytest.mark.parametrize("path", varlen_golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+def test_direct_dkdv_return_packed_rings(path, monkeypatch):
+    from golden_util import VarlenGolden
+    g = VarlenGolden(path)
+    packed = g.Hq == g.Hkv and "oneseq" in g.name
+    relay = run_distributed(_varlen_worker, g.ws, path, packed)
+    monkeypatch.setenv("USP_DKDV_RETURN", "direct")
+    direct = run_distributed(_varlen_worker, g.ws, path, packed)
+    for r in range(g.ws):
+        for key in ("out", "lse", "dq", "dk", "dv"):
+            assert np.array_equal(direct[r][key], relay[r][key]), f"{g.name} {key} rank {r}"

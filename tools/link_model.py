@@ -77,6 +77,20 @@ def main():
         print("   %d head group(s): %.1f ms per iteration = %5.0f TFLOP/s on 8 GPUs; overlap = 1 - (t - t_compute)/t_comm = %.2f"
               % (ng, tot, 8 * 15.39 / tot * 1e3, 1 - (tot - (fwd / eff_f + bwd / eff_b)) / comm))
 
+    # Ring backward: the travelling dK/dV (relay, the reference's order) against USP_DKDV_RETURN=direct (every block
+    # straight to its owner over its own link, front-half blocks at half size).  Per ring rank; t_c = kernels of one step.
+    print("\nring backward, dK/dV transport (ring 4):")
+    for name, t_c, hop_mib in (("configs[4] rank, one of two head groups (GQA: 1 KV head)", 16.7 * 0.71 / 2 / 4, 16),
+                               ("an MHA ring: configs[3]'s shape trained (16 KV heads, 8192 tokens per rank)", 2.5 * 2 * half, 128)):
+        hop = ms(hop_mib * MiB)
+        relay = t_c + sum(max(t_c, hop) for _ in range(3)) + hop          # hop s needs hop s-1 AND the kernels of step s
+        t, landed = t_c, 0.0
+        for s in (1, 2, 3):                                               # worst rank (0): every arriving block is whole
+            t += t_c
+            landed = max(landed, t + hop)                                 # own link per step: transfers overlap each other
+        print("   %s:\n      kernels %.2f ms per step, fp32 dK+dV %d MiB = %.2f ms per link -> relay %.1f ms, direct %.1f ms per backward"
+              % (name, t_c, hop_mib, hop, relay, landed))
+
 
 if __name__ == "__main__":
     main()
