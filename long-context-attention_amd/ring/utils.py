@@ -12,7 +12,7 @@ import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
 
-__all__ = ["update_out_and_lse", "RingComm", "KVRelay", "ZigzagKVFetch", "kv_relay_mode", "travel_dkdv", "return_dkdv_direct",
+__all__ = ["update_out_and_lse", "RingComm", "KVRelay", "ZigzagKVFetch", "zigzag_fetch_pieces", "kv_relay_mode", "travel_dkdv", "return_dkdv_direct",
            "dkdv_return_mode", "FULL", "final_grads"]
 
 
@@ -203,75 +203,76 @@ class KVRelay:
 
 
 class ZigzagKVFetch:
-    """K/V transport of the zigzag FORWARD for ring degree > 2: the direct mesh fetch of KVRelay, in two waves and
+    """K/V transport of the zigzag FORWARD for ring degree > 2: the direct mesh fetch of KVRelay, in waves and
     without the bytes the schedule never reads.
 
     With the local sequence = [chunk r | chunk 2P-1-r], ring step s of rank r reads the K/V of rank r-s: only its
     FRONT half rows when s <= r, both halves (against the back half of q) when s > r
-    (zigzag_ring_flash_attn.py:54-67).  So
-      wave A (one grouped send/recv): every rank sends the front half of its K/V to all P-1 peers;
-      wave B (one grouped send/recv): the back half goes only to the peers that read it (destination rank
-              (r+s) mod P with r+s >= P), a quarter of all K/V bytes is never sent;
-    and the attention of a step that needs both halves is two launches -- front-half keys as soon as wave A has
-    landed, back-half keys merged in by the kernel's fused LSE merge once wave B has.  Where the ring is
-    link-bound (BASELINE's 4-GPU config: 64 MiB of K/V per peer = ~1 ms per xGMI link against ~1 ms of attention
-    per rank) the compute that waits for the wire shrinks from three ring steps to three half steps, and every
-    rank has work from the middle of the transfer on.  Both waves run on the "ring" side stream; receive slots are
-    persistent like KVRelay's.  Context manager, like KVRelay."""
+    (zigzag_ring_flash_attn.py:54-67).  Every half is cut into `pieces` row ranges; wave w (one grouped send/recv
+    each, 2 * pieces waves) carries piece w % pieces of half w // pieces:
+      front waves: every rank sends the piece to all P-1 peers;
+      back waves:  the piece goes only to the peers that read it (destination rank (r+s) mod P with r+s >= P),
+                   a quarter of all K/V bytes is never sent;
+    and the attention of a step is one launch per piece it reads, merged by the kernel's fused LSE merge, issued
+    WAVE by wave (zigzag_ring_flash_attn_forward): everything that needs only the waves that have landed runs
+    before the compute stream waits for the next one.  Where the ring is link-bound (BASELINE's 4-GPU config:
+    64 MiB of K/V per peer = ~1 ms per xGMI link against ~1 ms of attention per rank) what waits for the wire
+    shrinks from three ring steps to the launches of the last piece.  All waves run on the "ring" side stream;
+    receive slots are persistent like KVRelay's.  Context manager, like KVRelay."""
 
     _SLOTS = {}
 
-    def __init__(self, process_group, k: torch.Tensor, v: torch.Tensor):
+    def __init__(self, process_group, k: torch.Tensor, v: torch.Tensor, pieces: int = 1):
         P = self.P = dist.get_world_size(process_group)
         r = self.r = dist.get_rank(process_group)
         assert P > 2 and k.shape[1] % 2 == 0
         c = k.shape[1] // 2
-        mine = [[t[:, :c].contiguous() for t in (k, v)], [t[:, c:].contiguous() for t in (k, v)]]   # views at B = 1
+        W = self.pieces = max(1, min(int(pieces), c))
+        self.waves = 2 * W
+        cut = [(i * c) // W for i in range(W + 1)]
+        # mine[w] = [k piece, v piece] of wave w, contiguous (views at B = 1)
+        mine = [[t[:, h * c + cut[i]:h * c + cut[i + 1]].contiguous() for t in (k, v)] for h in (0, 1) for i in range(W)]
         cuda = k.is_cuda
         self._stream = None
         if cuda:
             self._stream = _side_stream(k.device, "ring")
             self._stream.wait_stream(torch.cuda.current_stream())     # k, v are produced on the compute stream
-        key = (tuple(mine[0][0].shape), tuple(mine[0][1].shape), k.dtype, k.device.index if cuda else -1, P, r)
+        key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index if cuda else -1, P, r, W)
         slots = ZigzagKVFetch._SLOTS.get(key) if cuda else None
-        if slots is None:       # slots[half][s - 1] = (k_half, v_half) of source rank r - s
-            slots = [[tuple(torch.empty_like(t) for t in mine[h]) for _ in range(P - 1)] for h in (0, 1)]
+        if slots is None:       # slots[w][s - 1] = (k piece, v piece) of source rank r - s
+            slots = [[tuple(torch.empty_like(t) for t in mine[w]) for _ in range(P - 1)] for w in range(2 * W)]
             if cuda:
                 ZigzagKVFetch._SLOTS[key] = slots
         self.slots = slots
         to_global = lambda i: dist.get_global_rank(process_group, i % P) if process_group is not None else i % P
-        self.events = [None, None]
+        self.events = [None] * (2 * W)
         with (torch.cuda.stream(self._stream) if cuda else _NullCtx()):
-            for half in (0, 1):
+            for w in range(2 * W):
+                front = w < W
                 comm = RingComm(process_group)
                 for s in range(1, P):
-                    if half == 0 or r + s >= P:          # destination (r+s) % P reads my back half: its step s > its rank
-                        comm._ops += [dist.P2POp(dist.isend, t, to_global(r + s), group=process_group) for t in mine[half]]
-                    if half == 0 or s > r:               # I read the back half of source r - s
+                    if front or r + s >= P:              # destination (r+s) % P reads my back half: its step s > its rank
+                        comm._ops += [dist.P2POp(dist.isend, t, to_global(r + s), group=process_group) for t in mine[w]]
+                    if front or s > r:                   # I read the back half of source r - s
                         comm._ops += [dist.P2POp(dist.irecv, t, to_global(r - s), group=process_group)
-                                      for t in slots[half][s - 1]]
+                                      for t in slots[w][s - 1]]
                 comm.commit()
                 comm.wait()
                 if cuda:
-                    self.events[half] = torch.cuda.Event()
-                    self.events[half].record(self._stream)
-            for t in mine[0] + mine[1]:
-                if cuda:
-                    t.record_stream(self._stream)
+                    self.events[w] = torch.cuda.Event()
+                    self.events[w].record(self._stream)
+            for pair in mine:
+                for t in pair:
+                    if cuda:
+                        t.record_stream(self._stream)
 
-    def _get(self, half, step):
-        if self.events[half] is not None:
-            torch.cuda.current_stream().wait_event(self.events[half])
-        return self.slots[half][step - 1]
-
-    def front(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Front-half K, V of ring rank r - step (rows [0, c)); the compute stream waits for wave A."""
-        return self._get(0, step)
-
-    def back(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """Back-half K, V of ring rank r - step; only fetched for the steps that read it (step > rank)."""
-        assert step > self.r, "the zigzag schedule never reads this half"
-        return self._get(1, step)
+    def get(self, wave: int, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(K, V) rows of wave `wave` (piece wave % pieces of the front half for wave < pieces, of the back half
+        otherwise) of ring rank r - step; the compute stream waits for that wave."""
+        assert wave < self.pieces or step > self.r, "the zigzag schedule never reads this half"
+        if self.events[wave] is not None:
+            torch.cuda.current_stream().wait_event(self.events[wave])
+        return self.slots[wave][step - 1]
 
     def finish(self):
         if self._stream is not None:
@@ -284,6 +285,17 @@ class ZigzagKVFetch:
     def __exit__(self, *exc):
         self.finish()
         return False
+
+
+def zigzag_fetch_pieces(k: torch.Tensor) -> int:
+    """Row ranges per K/V half of the zigzag mesh fetch: USP_ZZ_PIECES, default 2 where a half of one peer's K + V is
+    at least 16 MiB (a quarter of a millisecond on an xGMI link: BASELINE's 4-GPU config moves 32 MiB per half against
+    0.14 ms of kernels per half step), else 1 (the 8-GPU config moves 4 MiB per half: more launches would buy nothing)."""
+    env = os.environ.get("USP_ZZ_PIECES")
+    if env:
+        return max(1, int(env))
+    half_bytes = k.numel() * k.element_size()                   # half the rows of K and of V
+    return 2 if half_bytes >= (16 << 20) else 1
 
 
 def kv_relay_mode(P: int) -> str:

@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 from ..kernels import AttnType
 from ..kernels.attention import get_block_backend
-from .utils import FULL, KVRelay, ZigzagKVFetch, final_grads, kv_relay_mode, travel_dkdv
+from .utils import FULL, KVRelay, ZigzagKVFetch, final_grads, kv_relay_mode, travel_dkdv, zigzag_fetch_pieces
 
 
 
@@ -88,20 +88,26 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
         be.fwd(q, k, v, softmax_scale, True, lse, out)
         return out, lse
     acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev)
-    if P > 2 and kv_relay_mode(P) == "direct":      # mesh fetch in two waves, only the halves the schedule reads
+    if P > 2 and kv_relay_mode(P) == "direct":      # mesh fetch in waves, only the halves the schedule reads
         c = S2 // 2
-        with ZigzagKVFetch(process_group, k, v) as fetch:
+        with ZigzagKVFetch(process_group, k, v, zigzag_fetch_pieces(k)) as fetch:
             zigzag_fwd_step(be, r, P, 0, q, k, v, softmax_scale, lse, out, acc)
-            for step in range(1, P):
-                last = step == P - 1
-                kf, vf = fetch.front(step)
-                if step <= r:                           # :54-58
-                    zigzag_fwd_step(be, r, P, step, q, kf, vf, softmax_scale, lse, out, acc)
-                else:                                   # :59-67 as two launches: front-half keys, then back-half keys
-                    be.fwd(q[:, c:], kf, vf, softmax_scale, False, lse[:, :, c:], out[:, c:], acc[:, c:], True, 0, 0)
-                    kb, vb = fetch.back(step)
-                    be.fwd(q[:, c:], kb, vb, softmax_scale, False, lse[:, :, c:], out[:, c:], acc[:, c:], True, 0,
-                           c if last else 0)
+            # One launch per (wave, step that reads it), WAVE-major: whatever needs only the waves that have landed
+            # runs before the compute stream waits for the next one (step-major, rank 0 would sit behind the last
+            # wave from its first step on while the front-half launches of its other steps were ready).  Steps
+            # s <= r read front waves with every q row (:54-58), steps s > r read all waves with q[c:] (:59-67).
+            launches = [(w, step, step <= r) for w in range(fetch.waves) for step in range(1, P)
+                        if w < fetch.pieces or step > r]
+            last_any = len(launches) - 1
+            last_front_rows = max((i for i, l in enumerate(launches) if l[2]), default=-1)
+            for i, (w, step, all_rows) in enumerate(launches):
+                kp, vp = fetch.get(w, step)
+                if all_rows:      # rows [0,c) are final behind their last launch, rows [c,2c) behind the last of all
+                    fe = S2 if i == last_any else (c if i == last_front_rows else 0)
+                    be.fwd(q, kp, vp, softmax_scale, False, lse, out, acc, True, 0, fe)
+                else:
+                    be.fwd(q[:, c:], kp, vp, softmax_scale, False, lse[:, :, c:], out[:, c:], acc[:, c:], True, 0,
+                           c if i == last_any else 0)
         return out, lse
     with KVRelay(process_group, k, v) as relay:
         for step in range(P):

@@ -77,30 +77,39 @@ def test_usp_on_gloo_matches_reference_golden(path):
                 assert_close(res[r][key], getattr(g, key)[r], atol, rtol, f"{g.name} {key} rank {r}")
 
 
-def test_zigzag_schedule_block_shapes():
-    """Every ring step of the zigzag schedule costs the same 2c^2 score entries (the load-balance
-    property the layout exists for) and rows are emitted exactly once."""
+@pytest.mark.parametrize("pieces", [None, 2, 3])
+def test_zigzag_schedule_block_shapes(pieces, monkeypatch):
+    """Every ring step of the zigzag schedule costs the same 2c^2 score entries (the load-balance property the layout
+    exists for), whatever the number of row ranges the mesh fetch cuts a K/V half into (ring/utils.py:ZigzagKVFetch;
+    default 1 at this size, 3 = uneven cuts), launches come wave by wave, and every row is emitted exactly once --
+    by the LAST launch that touches it."""
+    if pieces:
+        monkeypatch.setenv("USP_ZZ_PIECES", str(pieces))
+    W = pieces or 1
     path = [f for f in MULTI if "c4_w4_u1r4" in f][0]
     g = Golden(path)
     res = run_distributed(_usp_worker, g.ws, path, False)
     c = g.S // (2 * g.rd)
+    full, _ = __import__("oracle.usp_oracle", fromlist=["x"]).attention_ref(g.q, g.k, g.v, causal=True)
     for r in range(g.ws):
+        assert_close(res[r]["out"], g.shard(full, r), *[t / 2 for t in TOL[g.dtype]["out"]], f"pieces {pieces} rank {r}")
         fwd = [x for x in res[r]["calls"] if x[0] == "fwd"]
-        # ring degree 4 takes the two-wave mesh fetch (ring/utils.py:ZigzagKVFetch): a step that reads both K/V
-        # halves (step > rank) is two launches of c x c, front-half keys first
-        assert len(fwd) == g.rd + (g.rd - 1 - r)
-        steps, i = [], 0
-        for step in range(g.rd):
-            n = 2 if step > r else 1
-            steps.append(fwd[i:i + n]); i += n
-        for step, launches in enumerate(steps):
-            assert sum(qs[1] * ks[1] for _, qs, ks, *_ in launches) == (4 if step == 0 else 2) * c * c   # causal step 0: half of 4c^2
-            for _, qs, ks, causal, merge_in, fb, fe in launches:
-                assert causal == (step == 0) and merge_in == (step > 0)
-            assert all(x[6] == x[5] for x in launches[:-1])               # only a step's LAST launch finalises rows
-        finals = sorted((x[5], x[6], x[1][1]) for x in fwd if x[6] > x[5])
-        emitted = sum(fe - fb for fb, fe, _ in finals)
-        assert emitted == 2 * c
+        # step 0, then per wave: steps <= r read the front waves with every q row, steps > r read all waves with q[c:]
+        assert len(fwd) == 1 + W * (g.rd - 1) + W * (g.rd - 1 - r)
+        _, qs, ks, causal, merge_in, fb, fe = fwd[0]
+        assert causal and not merge_in and qs[1] == ks[1] == 2 * c
+        assert sum(x[1][1] * x[2][1] for x in fwd[1:]) == (g.rd - 1) * 2 * c * c
+        assert all(not x[3] and x[4] for x in fwd[1:])                      # later launches: full blocks, merged in
+        key_rows = [x[2][1] for x in fwd[1:]]                               # wave-major: piece sizes never interleave
+        cuts = [(i + 1) * c // W - i * c // W for i in range(W)]
+        want = [n for n in cuts for _ in range(g.rd - 1)] + [n for n in cuts for _ in range(g.rd - 1 - r)]
+        assert key_rows == want
+        done = np.zeros(2 * c, bool)                                        # rows already emitted in 16 bits
+        for _, qs, ks, causal, merge_in, fb, fe in fwd:
+            off = 2 * c - qs[1]                                             # q[c:] launches address rows c..2c
+            assert not done[off:].any(), "a launch touches rows that were already final"
+            done[off + fb:off + fe] = True
+        assert done.all()
 
 
 def _a2a_worker(rank, ws):
@@ -382,13 +391,16 @@ def test_kernels_inside_a_transfer_window_are_launched_interleavable(ud, rd, use
 
 
 # ---- USP_DKDV_RETURN=direct: every dK/dV block straight to its owner instead of the hop-by-hop relay ---------------
-_RING_BWD = [f for f in MULTI if Golden(f).rd > 1 and Golden(f).bwd]
+# one grid of each kind (the CPU suite runs serially in the driver): zigzag half-row blocks at ring 4, GQA beside a Ulysses
+# exchange at world size 8, basic causal at ring 2 (steps that compute nothing), basic non-causal with batch 2, stripe
+_RING_BWD = [f for f in MULTI if Golden(f).rd > 1 and Golden(f).bwd and any(
+    tag in f for tag in ("c4_w4_u1r4", "c5_w8_u2r4_gqa_bf16", "b_w2_u1r2", "f_w4_u2r2_full_b2_gqa", "n_w4_u1r4_strip"))]
 
 
 @pytest.mark.parametrize("path", _RING_BWD, ids=lambda p: p.split("/")[-1][:-4])
 def test_direct_dkdv_return_is_bit_identical_to_the_relay(path, monkeypatch):
     """The owner adds the arriving blocks in step order = the order the relay adds them in: same fp32 sums, bit for
-    bit, on every reference grid with a ring (zigzag incl. the half-row blocks, basic causal and full, stripe, batch 2,
+    bit, on reference grids of every kind of ring (zigzag incl. the half-row blocks, basic causal and full, stripe, batch 2,
     GQA, beside a Ulysses exchange) -- and therefore the same agreement with the reference's own run."""
     g = Golden(path)
     relay = run_distributed(_usp_worker, g.ws, path, True)
@@ -405,7 +417,8 @@ def test_direct_dkdv_return_is_bit_identical_to_the_relay(path, monkeypatch):
         assert len(direct[r]["direct"]) >= 1 and relay[r]["direct"] == []
 
 
-@pytest.mark.parametrize("path", varlen_golden_files(), ids=lambda p: p.split("/")[-1][:-4])
+@pytest.mark.parametrize("path", [f for f in varlen_golden_files() if "v_w4_zigzag" in f or "v_w2_basic" in f],
+                         ids=lambda p: p.split("/")[-1][:-4])
 def test_direct_dkdv_return_packed_rings(path, monkeypatch):
     from golden_util import VarlenGolden
     g = VarlenGolden(path)

@@ -53,15 +53,34 @@ def main():
         t = max(t, s * whole) + 2 * half
     print("   hop-by-hop relay (reference order):  %.2f ms per iteration" % t)
     print("   one-wave mesh fetch:                 %.2f ms (steps 1-3 wait for the whole fetch)" % (max(step0, whole) + 6 * half))
-    worst = 0.0
-    for r in range(4):                                                      # two waves: front halves land at whole/2, back halves at whole
-        t = max(step0, whole / 2)
-        both = [s for s in (1, 2, 3) if s > r]                              # steps that also read the back half
-        t += 2 * half * (3 - len(both)) + half * len(both)                  # everything that only needs wave A
-        t = max(t, whole) + half * len(both) if both else t                 # back-half keys once wave B has landed
-        worst = max(worst, t)
-    print("   two-wave fetch, split steps:         %.2f ms (slowest rank; front halves land after %.2f ms)" % (worst, whole / 2))
-    print("   -> %.0f TFLOP/s on 4 GPUs at the last figure, %.0f with the relay" % (4 * 1.0995 / worst * 1e3, 4 * 1.0995 / (3 * whole + 2 * half) * 1e3))
+    def waves(W, order):
+        """Slowest rank's iteration with 2 W waves (W row ranges per K/V half; wave w lands at (w + 1) / (2 W) of the
+        transfer).  order "wave": every launch that needs only the landed waves first (what the package issues);
+        "step": a step's launches together (round 2's first form: rank 0 waits for the LAST wave at its first step)."""
+        worst = 0.0
+        for r in range(4):
+            land = [(w + 1) * whole / (2 * W) for w in range(2 * W)]
+            # every q row x piece, or q[c:] x piece; each launch pays its own merge epilogue (read + write of the fp32
+            # running output of its q rows: 128 / 64 MiB at ~4 TB/s), which the measured (half) step time holds once
+            def cost(w, s):
+                base, merge = (2 * half, 0.032) if (w < W and s <= r) else (half, 0.016)
+                return (base - merge) / W + merge
+            reads = lambda w, s: w < W or s > r
+            if order == "wave":
+                seq = [(w, s) for w in range(2 * W) for s in (1, 2, 3) if reads(w, s)]
+            else:
+                seq = [(w, s) for s in (1, 2, 3) for w in range(2 * W) if reads(w, s)]
+            t = step0
+            for w, s in seq:
+                t = max(t, land[w]) + cost(w, s)
+            worst = max(worst, t)
+        return worst
+    print("   two-wave fetch, launches step by step: %.2f ms (slowest rank)" % waves(1, "step"))
+    worst = waves(1, "wave")
+    print("   two-wave fetch, launches wave by wave: %.2f ms (front halves land after %.2f ms)" % (worst, whole / 2))
+    worst = waves(2, "wave")
+    print("   four waves (2 row ranges per half):    %.2f ms   [default at this size; eight waves: %.2f ms]" % (worst, waves(4, "wave")))
+    print("   -> %.0f TFLOP/s on 4 GPUs at the four-wave figure, %.0f with the relay" % (4 * 1.0995 / worst * 1e3, 4 * 1.0995 / (3 * whole + 2 * half) * 1e3))
 
     # configs[4]: 8 GPUs, ulysses 2 x ring 4, B1 S65536 H32/4, forward + backward.
     fwd, bwd = 16.7 * 0.29, 16.7 * 0.71
