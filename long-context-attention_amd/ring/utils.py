@@ -125,13 +125,27 @@ class KVRelay:
         self.slots: List[Tuple[torch.Tensor, torch.Tensor]] = [(k, v)]
         self.events = [None]
         self._stream = None
+        self._pending = None
         if self.P == 1:
             return
-        cuda = k.is_cuda
-        if cuda:
+        if k.is_cuda:
             self._main = torch.cuda.current_stream()
             self._stream = _side_stream(k.device, "ring")
             self._stream.wait_stream(self._main)          # k, v are produced on the compute stream
+        # The transfers are POSTED by the first get(step >= 1): the caller enqueues the kernels of step 0 (local K/V)
+        # first, so the compute stream has work while the host walks through the grouped send/recv calls.  The side
+        # stream is ordered behind the compute stream as of NOW, not behind those kernels.
+        self._pending = (process_group, k, v)
+
+    def post(self):
+        """Post the transfers now (idempotent; get(step >= 1) does it otherwise).  A caller that posts traffic of its
+        own on the ring's communicator behind step 0 (the travelling dK/dV) calls this first: the communicator's
+        internal stream runs its calls in order, and that traffic waits for step 0's kernels."""
+        if self._pending is None:
+            return
+        process_group, k, v = self._pending
+        self._pending = None
+        cuda = k.is_cuda
         recv = self._recv_slots(k, v, dist.get_rank(process_group))
         ctx = torch.cuda.stream(self._stream) if cuda else _NullCtx()
         if kv_relay_mode(self.P) == "direct":
@@ -181,7 +195,10 @@ class KVRelay:
         return slots
 
     def get(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """K, V held after `step` hops; makes the current stream wait for that hop."""
+        """K, V held after `step` hops; makes the current stream wait for that hop.  The first call with step >= 1
+        posts the transfers."""
+        if step > 0:
+            self.post()
         ev = self.events[step]
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
@@ -244,8 +261,19 @@ class ZigzagKVFetch:
             if cuda:
                 ZigzagKVFetch._SLOTS[key] = slots
         self.slots = slots
-        to_global = lambda i: dist.get_global_rank(process_group, i % P) if process_group is not None else i % P
         self.events = [None] * (2 * W)
+        # posted by the first get(): the caller enqueues step 0 (local K/V) first, so the compute stream has work while
+        # the host walks through the 2 W grouped calls; the side stream is ordered behind the compute stream as of NOW
+        self._pending = (process_group, mine)
+
+    def post(self):
+        if self._pending is None:
+            return
+        process_group, mine = self._pending
+        self._pending = None
+        P, r, W = self.P, self.r, self.pieces
+        slots, cuda = self.slots, self._stream is not None
+        to_global = lambda i: dist.get_global_rank(process_group, i % P) if process_group is not None else i % P
         with (torch.cuda.stream(self._stream) if cuda else _NullCtx()):
             for w in range(2 * W):
                 front = w < W
@@ -270,6 +298,7 @@ class ZigzagKVFetch:
         """(K, V) rows of wave `wave` (piece wave % pieces of the front half for wave < pieces, of the back half
         otherwise) of ring rank r - step; the compute stream waits for that wave."""
         assert wave < self.pieces or step > self.r, "the zigzag schedule never reads this half"
+        self.post()
         if self.events[wave] is not None:
             torch.cuda.current_stream().wait_event(self.events[wave])
         return self.slots[wave][step - 1]
@@ -345,6 +374,7 @@ def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=Non
             if step == 0:
                 dk_acc, dv_acc = new(k), new(v)
                 block(0, kk, vv, dk_acc, dv_acc)
+                relay.post()                        # the K/V fetch goes out before the first dK/dV hop
             else:
                 computed = block(step, kk, vv, dk_blk, dv_blk)
                 d_comm.wait()                       # the travelling accumulators of step-1 have landed
@@ -389,6 +419,7 @@ def return_dkdv_direct(process_group, k, v, block, extent, be, zero: bool = Fals
         kk, vv = relay.get(0)
         dk_acc, dv_acc = new(k.shape, k.device), new(v.shape, v.device)
         block(0, kk, vv, dk_acc, dv_acc)
+        relay.post()
         for step in range(1, P):
             kk, vv = relay.get(step)
             out_sl, in_sl = extent(r, step), extent((r + step) % P, step)
