@@ -132,15 +132,17 @@ class KVRelay:
             self._main = torch.cuda.current_stream()
             self._stream = _side_stream(k.device, "ring")
             self._stream.wait_stream(self._main)          # k, v are produced on the compute stream
-        # The transfers are POSTED by the first get(step >= 1): the caller enqueues the kernels of step 0 (local K/V)
-        # first, so the compute stream has work while the host walks through the grouped send/recv calls.  The side
-        # stream is ordered behind the compute stream as of NOW, not behind those kernels.
+        # Posted NOW, in front of the caller's step-0 kernels: a transfer kernel that is queued before an attention
+        # launch is resident at once, one that arrives while the launch already holds every CU waits for the first
+        # workgroups to drain (~0.2 ms on the causal step 0) -- and on the link-bound configs the wire is the
+        # critical path.  It is ONE grouped call (direct mode), so the compute stream is not kept waiting for long.
         self._pending = (process_group, k, v)
+        self.post()
 
     def post(self):
-        """Post the transfers now (idempotent; get(step >= 1) does it otherwise).  A caller that posts traffic of its
-        own on the ring's communicator behind step 0 (the travelling dK/dV) calls this first: the communicator's
-        internal stream runs its calls in order, and that traffic waits for step 0's kernels."""
+        """Post the transfers (idempotent; the constructor does it).  Traffic a caller puts on the ring's communicator
+        itself (the travelling dK/dV) must come behind this: the communicator's internal stream runs its calls in
+        order, and that traffic waits for step 0's kernels."""
         if self._pending is None:
             return
         process_group, k, v = self._pending
@@ -195,10 +197,7 @@ class KVRelay:
         return slots
 
     def get(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        """K, V held after `step` hops; makes the current stream wait for that hop.  The first call with step >= 1
-        posts the transfers."""
-        if step > 0:
-            self.post()
+        """K, V held after `step` hops; makes the current stream wait for that hop."""
         ev = self.events[step]
         if ev is not None:
             torch.cuda.current_stream().wait_event(ev)
@@ -262,20 +261,29 @@ class ZigzagKVFetch:
                 ZigzagKVFetch._SLOTS[key] = slots
         self.slots = slots
         self.events = [None] * (2 * W)
-        # posted by the first get(): the caller enqueues step 0 (local K/V) first, so the compute stream has work while
-        # the host walks through the 2 W grouped calls; the side stream is ordered behind the compute stream as of NOW
+        # Wave 0 is posted NOW, in front of the caller's step-0 kernels (a transfer kernel queued before an attention
+        # launch is resident at once; one that arrives while the launch holds every CU waits for workgroups to drain,
+        # and on the link-bound configs the wire is the critical path); the other 2 W - 1 grouped calls are posted by
+        # the first get(), i.e. BEHIND the launch of step 0, so the compute stream has work while the host walks
+        # through them (they queue behind wave 0 on the communicator's stream anyway).
         self._pending = (process_group, mine)
+        self._posted = 0
+        self.post(1)
 
-    def post(self):
-        if self._pending is None:
+    def post(self, upto=None):
+        """Post waves [posted, upto) (all that are left when upto is None); idempotent."""
+        upto = 2 * self.pieces if upto is None else upto
+        if self._pending is None or self._posted >= upto:
             return
         process_group, mine = self._pending
-        self._pending = None
+        first, self._posted = self._posted, upto
+        if upto == 2 * self.pieces:
+            self._pending = None
         P, r, W = self.P, self.r, self.pieces
         slots, cuda = self.slots, self._stream is not None
         to_global = lambda i: dist.get_global_rank(process_group, i % P) if process_group is not None else i % P
         with (torch.cuda.stream(self._stream) if cuda else _NullCtx()):
-            for w in range(2 * W):
+            for w in range(first, upto):
                 front = w < W
                 comm = RingComm(process_group)
                 for s in range(1, P):
@@ -289,9 +297,7 @@ class ZigzagKVFetch:
                 if cuda:
                     self.events[w] = torch.cuda.Event()
                     self.events[w].record(self._stream)
-            for pair in mine:
-                for t in pair:
-                    if cuda:
+                    for t in mine[w]:
                         t.record_stream(self._stream)
 
     def get(self, wave: int, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -374,7 +380,6 @@ def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=Non
             if step == 0:
                 dk_acc, dv_acc = new(k), new(v)
                 block(0, kk, vv, dk_acc, dv_acc)
-                relay.post()                        # the K/V fetch goes out before the first dK/dV hop
             else:
                 computed = block(step, kk, vv, dk_blk, dv_blk)
                 d_comm.wait()                       # the travelling accumulators of step-1 have landed
@@ -419,7 +424,6 @@ def return_dkdv_direct(process_group, k, v, block, extent, be, zero: bool = Fals
         kk, vv = relay.get(0)
         dk_acc, dv_acc = new(k.shape, k.device), new(v.shape, v.device)
         block(0, kk, vv, dk_acc, dv_acc)
-        relay.post()
         for step in range(1, P):
             kk, vv = relay.get(step)
             out_sl, in_sl = extent(r, step), extent((r + step) % P, step)
