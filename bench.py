@@ -18,6 +18,7 @@ bwd 2.5x fwd, no credit for masked tiles, recompute or merges.
 """
 import argparse
 import ctypes
+import gc
 import json
 import os
 import sys
@@ -573,6 +574,13 @@ def main(argv=None, dev=None):
     for _ in range(args.warmup):
         step()
 
+    # Python's cyclic collector: a FULL collection walks every object torch has created (~170 k: 40-60 ms measured on
+    # the N > 1 step, tools/host_cost.py) -- longer than the whole timed region of the short configs, and the N > 1 step
+    # allocates enough containers to trigger one now and then.  Collect once and move what exists to the permanent
+    # generation (the documented gc.freeze() pattern): the collector keeps running, but only over new objects.
+    gc.collect()
+    gc.freeze()
+
     dt = timed(step, args.steps, ws, dev) * args.steps
 
     ms = dt / args.steps * 1e3
@@ -592,7 +600,8 @@ def main(argv=None, dev=None):
                        "layer": "AsyncLongContextAttention" if args.async_ulysses else "LongContextAttention",
                        "ulysses_exchange": exchange_mode(attn, lq, lk, cfg, ws),
                        "tokens_per_gpu": cfg["S"] * cfg["B"] // ws,
-                       "assumed": "B=1 and causal=True where BASELINE.json's config string is silent"},
+                       "assumed": "B=1 and causal=True where BASELINE.json's config string is silent",
+                       "host": "gc.collect() + gc.freeze() in front of the timed region (no full-heap GC pause inside it)"},
             "frac_of_mfma_roofline": round(value / (ws * PEAK_BF16_TFLOPS), 4),
             "parity_max_abs_err_vs_reference_op": parity_op,
             "parity_max_abs_err_vs_fp64_rows": parity_rows,
