@@ -12,7 +12,7 @@ import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
 
-__all__ = ["update_out_and_lse", "RingComm", "KVRelay", "ZigzagKVFetch", "zigzag_fetch_pieces", "kv_relay_mode", "travel_dkdv", "return_dkdv_direct",
+__all__ = ["update_out_and_lse", "RingComm", "KVRelay", "ZigzagKVFetch", "zigzag_fetch_pieces", "zigzag_wave_steps", "kv_relay_mode", "travel_dkdv", "return_dkdv_direct",
            "dkdv_return_mode", "FULL", "final_grads"]
 
 
@@ -284,12 +284,12 @@ class ZigzagKVFetch:
         to_global = lambda i: dist.get_global_rank(process_group, i % P) if process_group is not None else i % P
         with (torch.cuda.stream(self._stream) if cuda else _NullCtx()):
             for w in range(first, upto):
-                front = w < W
+                send_steps, recv_steps = zigzag_wave_steps(P, r, w < W)
                 comm = RingComm(process_group)
                 for s in range(1, P):
-                    if front or r + s >= P:              # destination (r+s) % P reads my back half: its step s > its rank
+                    if s in send_steps:
                         comm._ops += [dist.P2POp(dist.isend, t, to_global(r + s), group=process_group) for t in mine[w]]
-                    if front or s > r:                   # I read the back half of source r - s
+                    if s in recv_steps:
                         comm._ops += [dist.P2POp(dist.irecv, t, to_global(r - s), group=process_group)
                                       for t in slots[w][s - 1]]
                 comm.commit()
@@ -320,6 +320,17 @@ class ZigzagKVFetch:
     def __exit__(self, *exc):
         self.finish()
         return False
+
+
+def zigzag_wave_steps(P: int, r: int, front: bool):
+    """(steps s whose destination rank (r+s) % P gets this wave from rank r, steps s whose source rank (r-s) % P
+    sends this wave to rank r).  Front-half waves go to everyone; a back-half wave goes to rank (r+s) % P only if that
+    rank reads it, i.e. its step s is beyond its rank: r + s >= P; and rank r reads the back half of source r - s
+    when s > r (zigzag_ring_flash_attn.py:59-67)."""
+    steps = range(1, P)
+    if front:
+        return set(steps), set(steps)
+    return {s for s in steps if r + s >= P}, {s for s in steps if s > r}
 
 
 def zigzag_fetch_pieces(k: torch.Tensor) -> int:
