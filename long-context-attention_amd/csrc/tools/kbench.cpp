@@ -5,6 +5,7 @@
 //   kbench fwd  B Sq Sk Hq Hkv D causal dtype check iters    forward: check vs oracle and/or time
 //   kbench fwdmerge B Sq Sk Hq Hkv D dtype                    fused-merge path vs oracle (2 KV halves)
 //   kbench bwd  B Sq Sk Hq Hkv D causal dtype check iters    backward
+//   kbench pieces [Sq Sk H D iters]      merged launches of q rows x K/V row ranges (zigzag fetch waves): time per W
 //   kbench suite                          the standard correctness list + C2-shape timings
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -473,8 +474,60 @@ static int suite(bool with_bwd) {
   return f;
 }
 
+// What the row-range waves of the zigzag mesh fetch cost in kernel time: the launches ring rank 0 issues behind step 0
+// at ring degree P (every step reads both K/V halves of its peer with q[c:]: Sq = c query rows against P-1 peers x 2
+// halves of Sk = c keys), each half cut into W row ranges -> (P-1) * 2W merged launches of Sq x Sk/W.  W = 1 is the
+// two-wave fetch; the difference to W = 2, 4 is the price of the extra merge epilogues (tools/link_model.py charges
+// 16 us per launch at configs[3]).  Interleavable launches (what runs beside a transfer).
+static int run_pieces(int Sq, int Sk, int H, int D, int iters) {
+  const int P = 4, dt = 0, B = 1;
+  const size_t nq = (size_t)B * Sq * H * D, nk = (size_t)B * Sk * H * D, nl = (size_t)B * H * Sq;
+  std::vector<uint16_t> qb, kb, vb; std::vector<float> qf, kf, vf;
+  fill(qb, qf, nq, dt, 21); fill(kb, kf, nk, dt, 22); fill(vb, vf, nk, dt, 23);
+  uint16_t *dq = dev_upload(qb), *dk = dev_upload(kb), *dv = dev_upload(vb);
+  uint16_t* dout = dev_alloc<uint16_t>(nq);
+  float* dacc = dev_alloc<float>(nq);
+  float* dlse = dev_alloc<float>(nl);
+  usp_fwd_args a; memset(&a, 0, sizeof(a));
+  a.flags = USP_LAUNCH_INTERLEAVE;
+  a.dtype = dt; a.B = B; a.Sq = Sq; a.Hq = H; a.Hkv = H; a.D = D; a.causal = 0;
+  a.softmax_scale = 1.f / sqrtf((float)D);
+  a.q = bshd(dq, Sq, H, D); a.out = bshd(dout, Sq, H, D); a.acc = bshd(dacc, Sq, H, D);
+  a.lse = dlse; a.lse_stride_b = (int64_t)H * Sq; a.lse_stride_h = Sq;
+  a.k = bshd(dk, Sk, H, D); a.v = bshd(dv, Sk, H, D);
+  // something to merge into
+  a.Sk = Sk; a.merge_in = 0; a.final_begin = 0; a.final_end = 0;
+  if (int rc = usp_flash_fwd(&a, nullptr)) { printf("PIECES launch failed: %s\n", usp_strerror(rc)); return 1; }
+  a.merge_in = 1;
+  hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  float base = 0.f;
+  for (int W : {1, 2, 4, 8}) {
+    auto pass = [&] {
+      for (int peer = 0; peer < P - 1; ++peer)
+        for (int w = 0; w < 2 * W; ++w) {
+          const int lo = (int)((int64_t)(w % W) * Sk / W), hi = (int)((int64_t)(w % W + 1) * Sk / W);
+          a.Sk = hi - lo;
+          a.k.ptr = dk + (size_t)lo * H * D; a.v.ptr = dv + (size_t)lo * H * D;
+          usp_flash_fwd(&a, nullptr);
+        }
+    };
+    warm_up(pass);
+    HIP_OK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) pass();
+    HIP_OK(hipEventRecord(e1, 0)); HIP_OK(hipEventSynchronize(e1));
+    float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+    if (W == 1) base = ms;
+    const int n = (P - 1) * 2 * W;
+    printf("PIECES Sq%d Sk%d H%d D%d  W=%d: %2d launches of %d x %d  %.4f ms  (+%.1f us per extra launch)  %.0f TFLOP/s\n", Sq, Sk, H, D, W, n,
+           Sq, Sk / W, ms, W > 1 ? (ms - base) * 1e3 / (n - (P - 1) * 2) : 0.0,
+           4.0 * B * H * (double)Sq * Sk * D * (P - 1) * 2 / (ms * 1e-3) / 1e12);
+  }
+  hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); hipFree(dacc); hipFree(dlse);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: kbench probe|fwd|fwdmerge|bwd|suite|overlap [steps MiB workgroups] ...\n"); return 64; }
+  if (argc < 2) { fprintf(stderr, "usage: kbench probe|fwd|fwdmerge|pieces|bwd|suite|overlap [steps MiB workgroups] ...\n"); return 64; }
   std::string cmd = argv[1];
   auto I = [&](int i) { return atoi(argv[i]); };
   if (cmd == "probe") return run_probe();
@@ -482,6 +535,7 @@ int main(int argc, char** argv) {
   if (cmd == "fwd" && argc >= 12) return run_fwd(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
   if (cmd == "bwd" && argc >= 12) return run_bwd(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
   if (cmd == "overlap") return run_overlap(argc > 2 ? I(2) : 4, argc > 3 ? I(3) : 16, argc > 4 ? I(4) : 8);
+  if (cmd == "pieces") return run_pieces(argc > 2 ? I(2) : 4096, argc > 3 ? I(3) : 4096, argc > 4 ? I(4) : 16, argc > 5 ? I(5) : 128, argc > 6 ? I(6) : 20);
   if (cmd == "fwdmerge" && argc >= 9) return run_fwdmerge(I(2), I(3), I(4), I(5), I(6), I(7), I(8));
   fprintf(stderr, "bad arguments\n");
   return 64;

@@ -61,9 +61,11 @@ def main():
         for r in range(4):
             land = [(w + 1) * whole / (2 * W) for w in range(2 * W)]
             # every q row x piece, or q[c:] x piece; each launch pays its own merge epilogue (read + write of the fp32
-            # running output of its q rows: 128 / 64 MiB at ~4 TB/s), which the measured (half) step time holds once
+            # running output of its q rows), which the measured (half) step time holds once.  Measured on MI355X
+            # (`kbench pieces`, profiles/r02_kbench_pieces*.log): +16.4 us per extra q[c:] launch, +39-41 us per extra
+            # all-rows launch at this shape
             def cost(w, s):
-                base, merge = (2 * half, 0.032) if (w < W and s <= r) else (half, 0.016)
+                base, merge = (2 * half, 0.040) if (w < W and s <= r) else (half, 0.0165)
                 return (base - merge) / W + merge
             reads = lambda w, s: w < W or s > r
             if order == "wave":
