@@ -6,6 +6,7 @@
 //   kbench fwdmerge B Sq Sk Hq Hkv D dtype                    fused-merge path vs oracle (2 KV halves)
 //   kbench bwd  B Sq Sk Hq Hkv D causal dtype check iters    backward
 //   kbench pieces [Sq Sk H D iters]      merged launches of q rows x K/V row ranges (zigzag fetch waves): time per W
+//   kbench split [S H iters]             few-head causal launch: one launch vs three concurrent launches cut along K
 //   kbench suite                          the standard correctness list + C2-shape timings
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -526,8 +527,71 @@ static int run_pieces(int Sq, int Sk, int H, int D, int iters) {
   return 0;
 }
 
+// Few-head causal launches (the head groups of the 2-GPU config: B1 S16384, 2 or 4 heads) last as long as their heaviest
+// item, whatever the placement.  Potential of cutting the work along K WITHOUT a new kernel: three launches on three
+// streams -- rows [0,S/2) causal on keys [0,S/2); rows [S/2,S) full on keys [0,S/2); rows [S/2,S) causal on keys
+// [S/2,S) -- the last two into separate fp32 partials (a merge of S/2 rows would follow; not timed: HBM-bound, ~10 us).
+// The heaviest item then holds S/2 keys instead of S.  Timed: the single launch, and the three together.
+static int run_split(int S, int H, int iters) {
+  const int B = 1, D = 128, dt = 0, h = S / 2;
+  const size_t nq = (size_t)B * S * H * D, nl = (size_t)B * H * S;
+  std::vector<uint16_t> qb, kb, vb; std::vector<float> qf, kf, vf;
+  fill(qb, qf, nq, dt, 31); fill(kb, kf, nq, dt, 32); fill(vb, vf, nq, dt, 33);
+  uint16_t *dq = dev_upload(qb), *dk = dev_upload(kb), *dv = dev_upload(vb);
+  uint16_t* dout = dev_alloc<uint16_t>(nq);
+  float *acc1 = dev_alloc<float>(nq), *acc2 = dev_alloc<float>(nq);
+  float *lse = dev_alloc<float>(nl), *lse1 = dev_alloc<float>(nl), *lse2 = dev_alloc<float>(nl);
+  auto base = [&](int Sq, int Sk, int causal, uint16_t* q, uint16_t* k, uint16_t* v, float* l) {
+    usp_fwd_args a; memset(&a, 0, sizeof(a));
+    a.dtype = dt; a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = H; a.Hkv = H; a.D = D; a.causal = causal;
+    a.softmax_scale = 1.f / sqrtf((float)D);
+    a.q = bshd(q, Sq, H, D); a.k = bshd(k, Sk, H, D); a.v = bshd(v, Sk, H, D);
+    a.lse = l; a.lse_stride_b = (int64_t)H * Sq; a.lse_stride_h = Sq;
+    return a;
+  };
+  const size_t half = (size_t)h * H * D;
+  hipStream_t st[3]; for (auto& x : st) HIP_OK(hipStreamCreate(&x));
+  hipEvent_t e0, e1[3]; HIP_OK(hipEventCreate(&e0)); for (auto& x : e1) HIP_OK(hipEventCreate(&x));
+  for (int inter = 0; inter < 2; ++inter) {
+    usp_fwd_args whole = base(S, S, 1, dq, dk, dv, lse);
+    whole.out = bshd(dout, S, H, D); whole.final_end = S; whole.flags = inter ? USP_LAUNCH_INTERLEAVE : 0;
+    usp_fwd_args a1 = base(h, h, 1, dq, dk, dv, lse);                       // rows [0,h) x keys [0,h), causal, final
+    a1.out = bshd(dout, h, H, D); a1.final_end = h; a1.flags = whole.flags;
+    usp_fwd_args a2 = base(h, h, 0, dq + half, dk, dv, lse1);               // rows [h,S) x keys [0,h), full -> partial 1
+    a2.acc = bshd(acc1, h, H, D); a2.final_end = 0; a2.flags = whole.flags;
+    usp_fwd_args a3 = base(h, h, 1, dq + half, dk + half, dv + half, lse2); // rows [h,S) x keys [h,S), causal -> partial 2
+    a3.acc = bshd(acc2, h, H, D); a3.final_end = 0; a3.flags = whole.flags;
+    auto time = [&](bool split) {
+      float best = 1e30f;
+      for (int rep = 0; rep < 5; ++rep) {
+        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipEventRecord(e0, st[0]));
+        HIP_OK(hipStreamWaitEvent(st[1], e0, 0)); HIP_OK(hipStreamWaitEvent(st[2], e0, 0));
+        for (int i = 0; i < iters; ++i) {
+          if (!split) { usp_flash_fwd(&whole, st[0]); continue; }
+          usp_flash_fwd(&a2, st[0]); usp_flash_fwd(&a3, st[1]); usp_flash_fwd(&a1, st[2]);   // heaviest first
+        }
+        float t = 0.f;
+        for (int j = 0; j < 3; ++j) { HIP_OK(hipEventRecord(e1[j], st[j])); }
+        for (int j = 0; j < 3; ++j) { HIP_OK(hipEventSynchronize(e1[j])); float x; HIP_OK(hipEventElapsedTime(&x, e0, e1[j])); t = x > t ? x : t; }
+        t /= iters;
+        best = t < best ? t : best;
+      }
+      return best;
+    };
+    if (int rc = usp_flash_fwd(&whole, st[0])) { printf("SPLIT launch failed: %s\n", usp_strerror(rc)); return 1; }
+    if (int rc = usp_flash_fwd(&a1, st[0]) | usp_flash_fwd(&a2, st[0]) | usp_flash_fwd(&a3, st[0])) { printf("SPLIT launch failed: %s\n", usp_strerror(rc)); return 1; }
+    const float t1 = time(false), t3 = time(true);
+    const double fl = attn_flops(B, S, S, H, D, 1);
+    printf("SPLIT B1 S%d H%d D128 causal %-12s one launch %.4f ms (%.0f TFLOP/s) | three launches cut along K, 3 streams %.4f ms (%.0f TFLOP/s)\n",
+           S, H, inter ? "interleave" : "persistent", t1, fl / (t1 * 1e-3) / 1e12, t3, fl / (t3 * 1e-3) / 1e12);
+  }
+  hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); hipFree(acc1); hipFree(acc2); hipFree(lse); hipFree(lse1); hipFree(lse2);
+  return 0;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: kbench probe|fwd|fwdmerge|pieces|bwd|suite|overlap [steps MiB workgroups] ...\n"); return 64; }
+  if (argc < 2) { fprintf(stderr, "usage: kbench probe|fwd|fwdmerge|pieces|split|bwd|suite|overlap [steps MiB workgroups] ...\n"); return 64; }
   std::string cmd = argv[1];
   auto I = [&](int i) { return atoi(argv[i]); };
   if (cmd == "probe") return run_probe();
@@ -535,6 +599,7 @@ int main(int argc, char** argv) {
   if (cmd == "fwd" && argc >= 12) return run_fwd(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
   if (cmd == "bwd" && argc >= 12) return run_bwd(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
   if (cmd == "overlap") return run_overlap(argc > 2 ? I(2) : 4, argc > 3 ? I(3) : 16, argc > 4 ? I(4) : 8);
+  if (cmd == "split") return run_split(argc > 2 ? I(2) : 16384, argc > 3 ? I(3) : 2, argc > 4 ? I(4) : 10);
   if (cmd == "pieces") return run_pieces(argc > 2 ? I(2) : 4096, argc > 3 ? I(3) : 4096, argc > 4 ? I(4) : 16, argc > 5 ? I(5) : 128, argc > 6 ? I(6) : 20);
   if (cmd == "fwdmerge" && argc >= 9) return run_fwdmerge(I(2), I(3), I(4), I(5), I(6), I(7), I(8));
   fprintf(stderr, "bad arguments\n");
