@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USP_ABI_VERSION 3
+#define USP_ABI_VERSION 4
 
 enum { USP_BF16 = 0, USP_FP16 = 1 };
 
@@ -108,9 +108,22 @@ typedef struct usp_fwd_args {
   const int32_t* seq_k;
   int32_t* sched;                /* packed mode, optional: 64-byte device control block, see below */
   int32_t flags;                 /* USP_LAUNCH_* bits */
+  int32_t k_splits;              /* dense mode, optional: cut every query tile's keys into this many work items
+                                    (2..8; 0 or 1 = off); needs `workspace`, see usp_flash_fwd_workspace_bytes() */
+  void* workspace;               /* device scratch of usp_flash_fwd_workspace_bytes(args, k_splits) bytes, 16-byte
+                                    aligned; NULL = no split */
 } usp_fwd_args;
 
 int usp_flash_fwd(const usp_fwd_args* args, void* stream);
+
+/* K split (dense launches): a launch with few (batch, head, 256-row tile) work items cannot fill 256 CUs, and a causal
+ * one lasts as long as its heaviest item (measured on MI355X, B1 S16384 D128 causal: 2 heads 548 TFLOP/s, 4 heads 891,
+ * 8 heads 1133; the same 2 / 4 heads cut in two along K: 833-857 / 1093 -- profiles/r02_kbench_split.log).  With
+ * k_splits = n and a workspace every item becomes n items over equal runs of the K tiles it sees; each writes a
+ * normalised fp32 partial + LSE to the workspace and a second, HBM-bound launch on the same stream combines them [and
+ * the running result when merge_in] into exactly the outputs described above (results equal up to fp32 summation
+ * order).  Returns the bytes needed: n * (B*Sq*Hq*D + B*Hq*Sq) * 4; 0 for n <= 1 or a packed batch. */
+int64_t usp_flash_fwd_workspace_bytes(const usp_fwd_args* args, int32_t k_splits);
 
 /* ----------------------------------------------------------------------------------------------
  * Blockwise flash-attention backward.

@@ -18,7 +18,7 @@ _lib = None
 
 USP_BF16, USP_FP16 = 0, 1
 USP_LAUNCH_INTERLEAVE = 1      # include/usp_hip.h: launch so that collectives on other streams can slip in
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class UspTensor(ctypes.Structure):
@@ -38,7 +38,7 @@ class UspFwdArgs(ctypes.Structure):
                 ("merge_in", ctypes.c_int32), ("final_begin", ctypes.c_int32),
                 ("final_end", ctypes.c_int32),
                 ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("sched", ctypes.c_void_p),
-                ("flags", ctypes.c_int32)]
+                ("flags", ctypes.c_int32), ("k_splits", ctypes.c_int32), ("workspace", ctypes.c_void_p)]
 
 
 class UspBwdArgs(ctypes.Structure):
@@ -59,7 +59,7 @@ class UspBwdArgs(ctypes.Structure):
                 ("sched", ctypes.c_void_p), ("flags", ctypes.c_int32)]
 
 
-EXPORTS = ("usp_flash_fwd", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
+EXPORTS = ("usp_flash_fwd", "usp_flash_fwd_workspace_bytes", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
            "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror")
 
 
@@ -88,6 +88,8 @@ def load():
     i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
     L.usp_flash_fwd.argtypes = [ctypes.POINTER(UspFwdArgs), vp]
     L.usp_flash_bwd.argtypes = [ctypes.POINTER(UspBwdArgs), vp]
+    L.usp_flash_fwd_workspace_bytes.argtypes = [ctypes.POINTER(UspFwdArgs), i32]
+    L.usp_flash_fwd_workspace_bytes.restype = ctypes.c_int64
     L.usp_flash_bwd_workspace_bytes.argtypes = [ctypes.POINTER(UspBwdArgs)]
     L.usp_flash_bwd_workspace_bytes.restype = ctypes.c_int64
     L.usp_bwd_delta.argtypes = [i32, i32, i32, i32, i32, ctypes.POINTER(UspTensor),
@@ -147,11 +149,34 @@ def _lse3(t: torch.Tensor):
     return ctypes.c_void_p(t.data_ptr()), t.stride(0), t.stride(1)
 
 
+_FWD_WS = {}
+
+
+def fwd_k_splits(B: int, Sq: int, Hq: int, causal: bool) -> int:
+    """How many work items a dense forward launch cuts every query tile's keys into (usp_fwd_args.k_splits).
+    The kernel path is checked and timed natively on MI355X (`kbench ksplit`, profiles/r02_kbench_ksplit*.log: B1 S16384
+    D128 causal, 2 heads 557 -> 936 TFLOP/s at n = 4, 4 heads 798 -> 1070 at n = 2, merge launch included; 8 heads fill
+    the part and gain nothing).  THIS binding's use of it is STAGED -- built after round 2's GPU budget was spent, not
+    yet through the GPU tests -- so it is off unless USP_FWD_KSPLIT is set:
+        USP_FWD_KSPLIT=auto  causal launches of >= 4096 rows with fewer than two 256-row items per CU: n = 2 from 256
+                             items up, 4 below (the measured optima);
+        USP_FWD_KSPLIT=n     n cuts (2..8) for every causal launch with fewer than two 256-row items per CU."""
+    mode = os.environ.get("USP_FWD_KSPLIT", "0") or "0"
+    items = B * Hq * ((Sq + 255) // 256)
+    if mode == "0" or not causal or items >= 512:
+        return 0
+    if mode == "auto":
+        return 0 if Sq < 4096 else (2 if items >= 256 else 4)
+    n = int(mode)
+    return 0 if n < 2 else min(n, 8)
+
+
 def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=None,
               merge_in: bool = False, final_begin: int = 0, final_end: Optional[int] = None,
-              interleave: bool = False):
+              interleave: bool = False, k_splits: Optional[int] = None):
     """usp_flash_fwd (include/usp_hip.h).  q (B,Sq,Hq,D); k,v (B,Sk,Hkv,D); lse (B,Hq,Sq) fp32;
-    out 16-bit / acc fp32 (B,Sq,Hq,D).  All may be strided views (unit dim stride)."""
+    out 16-bit / acc fp32 (B,Sq,Hq,D).  All may be strided views (unit dim stride).  `k_splits`: cut the keys of
+    every query tile into that many work items (None: fwd_k_splits decides; 0 / 1: off)."""
     _require_cuda(q, k, v, lse, out, acc)
     B, Sq, Hq, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
@@ -166,6 +191,16 @@ def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=No
     a.final_begin = final_begin
     a.final_end = Sq if final_end is None else final_end
     a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
+    n = fwd_k_splits(B, Sq, Hq, causal) if k_splits is None else int(k_splits)
+    if n > 1:
+        # scratch for the partial results: one buffer per (device, stream), grown on demand; launches on one stream
+        # are ordered, so the buffer is free again when the next launch on that stream starts
+        need = load().usp_flash_fwd_workspace_bytes(ctypes.byref(a), n)
+        key = (q.device.index, torch.cuda.current_stream().cuda_stream)
+        ws = _FWD_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _FWD_WS[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
+        a.k_splits, a.workspace = n, ws.data_ptr()
     _check(load().usp_flash_fwd(ctypes.byref(a), _stream()), "usp_flash_fwd")
 
 

@@ -7,6 +7,7 @@
 //   kbench bwd  B Sq Sk Hq Hkv D causal dtype check iters    backward
 //   kbench pieces [Sq Sk H D iters]      merged launches of q rows x K/V row ranges (zigzag fetch waves): time per W
 //   kbench split [S H iters]             few-head causal launch: one launch vs three concurrent launches cut along K
+//   kbench ksplit B Sq Sk Hq Hkv D causal dtype check iters   forward with k_splits = 1, 2, 4 (ABI v4): check + time
 //   kbench suite                          the standard correctness list + C2-shape timings
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -439,6 +440,7 @@ static int run_bwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, in
   return fail;
 }
 
+static int run_ksplit(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, int dt, int check, int iters);
 static int suite(bool with_bwd) {
   int f = 0;
   f += run_probe();
@@ -455,6 +457,12 @@ static int suite(bool with_bwd) {
   f += run_fwdmerge(1, 256, 512, 2, 2, 128, 0);
   f += run_fwdmerge(2, 300, 200, 4, 2, 64, 1);
   f += run_fwdmerge(1, 64, 192, 2, 1, 128, 0);
+  // K split (ABI v4): k_splits 1..8 x {plain, partly final, merge_in}; causal incl. Sq != Sk, GQA, ragged, every head dim
+  f += run_ksplit(1, 1024, 1024, 2, 2, 128, 1, 0, 1, 0);
+  f += run_ksplit(2, 300, 712, 4, 2, 64, 0, 1, 1, 0);
+  f += run_ksplit(1, 333, 200, 2, 1, 128, 1, 0, 1, 0);
+  f += run_ksplit(1, 200, 333, 3, 3, 32, 1, 1, 1, 0);
+  f += run_ksplit(2, 77, 77, 2, 2, 64, 1, 0, 1, 0);
   if (with_bwd) {
     const C bs[] = {{1, 256, 256, 1, 1, 128, 0, 0}, {1, 256, 256, 2, 2, 128, 1, 0}, {2, 512, 512, 4, 2, 128, 1, 0},
                     {1, 384, 640, 4, 2, 64, 0, 1},  {1, 200, 333, 3, 1, 128, 1, 0}, {1, 333, 200, 2, 2, 64, 1, 0},
@@ -468,6 +476,8 @@ static int suite(bool with_bwd) {
   run_fwd(1, 16384, 16384, 16, 2, 128, 1, 0, 0, 5);
   run_fwd(1, 16384, 8192, 16, 2, 128, 0, 0, 0, 5);
   run_fwd(1, 8192, 16384, 16, 2, 128, 0, 0, 0, 5);
+  run_ksplit(1, 16384, 16384, 4, 4, 128, 1, 0, 0, 5);      // few-head launches: the head groups of the 2-GPU config
+  run_ksplit(1, 16384, 16384, 2, 2, 128, 1, 0, 0, 5);
   if (with_bwd) {
     run_bwd(2, 8192, 8192, 16, 16, 128, 1, 0, 0, 5);
     run_bwd(1, 16384, 16384, 16, 2, 128, 1, 0, 0, 3);
@@ -590,8 +600,81 @@ static int run_split(int S, int H, int iters) {
   return 0;
 }
 
+// K split (ABI v4): the same call with k_splits = 1 (off), 2, 3, 4 and 8 -- against the oracle (check != 0), in three
+// forms: a plain final call, a call whose rows [Sq/2, Sq) are not final (fp32 acc), and a merge_in call on top of a
+// first half of the keys (what a ring step does); and timed (iters > 0).
+static int run_ksplit(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, int dt, int check, int iters) {
+  const size_t nq = (size_t)B * Sq * Hq * D, nk = (size_t)B * Sk * Hkv * D, nl = (size_t)B * Hq * Sq;
+  std::vector<uint16_t> qb, kb, vb; std::vector<float> qf, kf, vf;
+  fill(qb, qf, nq, dt, 41); fill(kb, kf, nk, dt, 42); fill(vb, vf, nk, dt, 43);
+  uint16_t *dq = dev_upload(qb), *dk = dev_upload(kb), *dv = dev_upload(vb);
+  uint16_t* dout = dev_alloc<uint16_t>(nq);
+  float* dacc = dev_alloc<float>(nq);
+  float* dlse = dev_alloc<float>(nl);
+  usp_fwd_args a; memset(&a, 0, sizeof(a)); a.flags = env_flags();
+  a.dtype = dt; a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.causal = causal;
+  a.softmax_scale = 1.f / sqrtf((float)D);
+  a.q = bshd(dq, Sq, Hq, D); a.k = bshd(dk, Sk, Hkv, D); a.v = bshd(dv, Sk, Hkv, D);
+  a.out = bshd(dout, Sq, Hq, D); a.acc = bshd(dacc, Sq, Hq, D);
+  a.lse = dlse; a.lse_stride_b = (int64_t)Hq * Sq; a.lse_stride_h = Sq;
+  const int64_t ws_bytes = usp_flash_fwd_workspace_bytes(&a, 8);
+  void* ws = nullptr; HIP_OK(hipMalloc(&ws, ws_bytes));
+  std::vector<float> ro(nq), rl(nl);
+  if (check) usp_oracle_attn_fwd(qf.data(), kf.data(), vf.data(), B, Sq, Sk, Hq, Hkv, D, a.softmax_scale, causal, ro.data(), rl.data());
+  Tol t = tol_for(dt);
+  int fail = 0;
+  hipEvent_t e0, e1; HIP_OK(hipEventCreate(&e0)); HIP_OK(hipEventCreate(&e1));
+  for (int n : {1, 2, 3, 4, 8}) {
+    a.k_splits = n; a.workspace = n > 1 ? ws : nullptr;
+    for (int form = 0; form < (check ? 3 : 1); ++form) {
+      HIP_OK(hipMemset(dout, 0xff, nq * 2)); HIP_OK(hipMemset(dacc, 0xff, nq * 4)); HIP_OK(hipMemset(dlse, 0xff, nl * 4));
+      a.merge_in = 0; a.final_begin = 0; a.final_end = Sq; a.Sk = Sk; a.k.ptr = dk; a.v.ptr = dv; a.causal = causal;
+      int rc = 0;
+      if (form == 1) a.final_end = Sq / 2;                       // rows [Sq/2, Sq) stay fp32 in acc
+      if (form == 2) {                                           // keys [0,h) first (plain, to acc), then the rest merged in
+        // causal alignment is bottom-right, so the first call must be the FULL block over the first keys of a
+        // non-causal problem; with causal inputs this form is only run for Sq == Sk on the second half being causal-aligned
+        const int h = (Sk / 2) & ~7;
+        if (causal || h == 0) continue;
+        usp_fwd_args f = a; f.k_splits = 0; f.workspace = nullptr; f.Sk = h; f.final_end = 0;
+        rc = usp_flash_fwd(&f, nullptr);
+        a.Sk = Sk - h; a.k.ptr = dk + (size_t)h * Hkv * D; a.v.ptr = dv + (size_t)h * Hkv * D; a.merge_in = 1;
+      }
+      rc |= usp_flash_fwd(&a, nullptr);
+      if (rc) { printf("KSPLIT launch failed (n=%d form=%d): %s\n", n, form, usp_strerror(rc)); return 1; }
+      HIP_OK(hipDeviceSynchronize());
+      if (!check) continue;
+      auto ob = dev_download(dout, nq); auto ab = dev_download(dacc, nq); auto lh = dev_download(dlse, nl);
+      std::vector<float> of(nq);
+      for (size_t i = 0; i < nq; ++i) {
+        const int s = (int)((i / ((size_t)Hq * D)) % Sq);
+        of[i] = s < a.final_end ? dec(ob[i], dt) : ab[i];
+      }
+      Err eo = compare(of.data(), ro.data(), nq, t.out_atol, t.out_rtol);
+      Err el = compare(lh.data(), rl.data(), nl, t.lse_atol, 1e-4);
+      const int bad = (eo.bad || el.bad || eo.nan);
+      fail |= bad;
+      printf("CHECK ksplit n=%d form=%d B%d Sq%d Sk%d Hq%d Hkv%d D%d %s %s : out max|err| %.3e bad %zu nan %zu | lse max|err| %.3e bad %zu  %s\n",
+             n, form, B, Sq, Sk, Hq, Hkv, D, causal ? "causal" : "full", dt ? "fp16" : "bf16", eo.max_abs, eo.bad, eo.nan,
+             el.max_abs, el.bad, bad ? "FAIL" : "ok");
+    }
+    if (iters > 0) {
+      a.merge_in = 0; a.final_begin = 0; a.final_end = Sq; a.Sk = Sk; a.k.ptr = dk; a.v.ptr = dv;
+      warm_up([&] { usp_flash_fwd(&a, nullptr); });
+      HIP_OK(hipEventRecord(e0, 0));
+      for (int i = 0; i < iters; ++i) usp_flash_fwd(&a, nullptr);
+      HIP_OK(hipEventRecord(e1, 0)); HIP_OK(hipEventSynchronize(e1));
+      float ms; HIP_OK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+      printf("TIME  ksplit n=%d B%d Sq%d Sk%d Hq%d Hkv%d D%d %s  %.4f ms  %.0f TFLOP/s (incl. the merge launch)\n", n, B, Sq, Sk, Hq,
+             Hkv, D, causal ? "causal" : "full", ms, attn_flops(B, Sq, Sk, Hq, D, causal) / (ms * 1e-3) / 1e12);
+    }
+  }
+  hipFree(dq); hipFree(dk); hipFree(dv); hipFree(dout); hipFree(dacc); hipFree(dlse); hipFree(ws);
+  return fail;
+}
+
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: kbench probe|fwd|fwdmerge|pieces|split|bwd|suite|overlap [steps MiB workgroups] ...\n"); return 64; }
+  if (argc < 2) { fprintf(stderr, "usage: kbench probe|fwd|fwdmerge|pieces|split|ksplit|bwd|suite|overlap [steps MiB workgroups] ...\n"); return 64; }
   std::string cmd = argv[1];
   auto I = [&](int i) { return atoi(argv[i]); };
   if (cmd == "probe") return run_probe();
@@ -599,6 +682,7 @@ int main(int argc, char** argv) {
   if (cmd == "fwd" && argc >= 12) return run_fwd(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
   if (cmd == "bwd" && argc >= 12) return run_bwd(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
   if (cmd == "overlap") return run_overlap(argc > 2 ? I(2) : 4, argc > 3 ? I(3) : 16, argc > 4 ? I(4) : 8);
+  if (cmd == "ksplit" && argc >= 12) return run_ksplit(I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11));
   if (cmd == "split") return run_split(argc > 2 ? I(2) : 16384, argc > 3 ? I(3) : 2, argc > 4 ? I(4) : 10);
   if (cmd == "pieces") return run_pieces(argc > 2 ? I(2) : 4096, argc > 3 ? I(3) : 4096, argc > 4 ? I(4) : 16, argc > 5 ? I(5) : 128, argc > 6 ? I(6) : 20);
   if (cmd == "fwdmerge" && argc >= 9) return run_fwdmerge(I(2), I(3), I(4), I(5), I(6), I(7), I(8));

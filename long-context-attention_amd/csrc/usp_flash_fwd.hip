@@ -40,6 +40,8 @@ struct FwdParams {
   const int* seq_q; const int* seq_k;   // packed variable-length batch: B (first row, rows) pairs, or NULL
   int* sched;                           // packed mode: control block of the dynamic item queue, or NULL
   int interleave;                       // USP_LAUNCH_INTERLEAVE: one workgroup per item (collectives can slip in)
+  int ksplit;                           // dense mode: every (batch, head, query tile) is cut into `ksplit` items along K (1 = off)
+  float* ws_o; float* ws_lse;           // ksplit > 1: partial results, [ksplit][B,Sq,Hq,D] fp32 and [ksplit][B,Hq,Sq] fp32
 };
 
 constexpr int kBN = 64;    // keys per KV tile
@@ -53,7 +55,9 @@ template <int D> struct KSwz {
 
 // NWAVES waves per workgroup, 32 query rows each: 8 (one 256-row workgroup per CU) or 4 (two 128-row
 // workgroups per CU: half the causal diagonal waste, and the two workgroups desynchronise).
-template <int D, int DT, bool CAUSAL, int NWAVES>
+// KSPLIT: the K-split variant is its own instantiation -- the plain kernels sit on the register cliff (256 VGPRs), and
+// with the split code compiled in unconditionally hipcc spilled 16 more bytes in them.
+template <int D, int DT, bool CAUSAL, int NWAVES, bool KSPLIT = false>
 __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdParams p_in) {
   using E = Elem<DT>;
   constexpr int kThreads = 64 * NWAVES;
@@ -83,7 +87,9 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   int w = p_in.sched ? item_queue_next(queue, qstate, qslots, pass) : walk.at(pass);
   if (w < 0) break;
   FwdParams p = p_in;
-  if (!p_in.sched) w = walk.dealt(w, p.nq);
+  if (!p_in.sched) w = walk.dealt(w, KSPLIT ? p.nq * p.ksplit : p.nq);    // the K cuts of a tile are dealt like tiles
+  int ks = 0;
+  if constexpr (KSPLIT) { ks = w % p_in.ksplit; w /= p_in.ksplit; }
   const int qt_r = w % p.nq;
   int rest = w / p.nq;
   const int qt = CAUSAL ? (p.nq - 1 - qt_r) : qt_r;      // heavy (late) tiles first
@@ -111,6 +117,34 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
     const int half = q_len >> 1;                            // final_begin/_end count half sequences here
     p.final_begin = p.final_begin >= 2 ? q_len : p.final_begin * half;
     p.final_end = p.final_end >= 2 ? q_len : p.final_end * half;
+  }
+
+  // ---- K split: bind this workgroup to cut `ks` of the keys its query tile sees ------------------------
+  // Few (batch, head, tile) items cannot fill the part, and a causal launch lasts as long as its heaviest item: the
+  // tiles [0, nt) of the item are cut into ksplit equal runs, one workgroup each, by rebasing the K/V pointers, Sk
+  // and the causal offset (the tile loops are untouched, as in packed mode).  Each cut writes its own normalised
+  // partial (fp32) and its LSE to the workspace through the ordinary not-final epilogue; split_merge_kernel combines
+  // them (and the running result, and the 16-bit emission) afterwards.
+  if constexpr (KSPLIT) {
+    const int q0s = qt * kBM;
+    int e = p.Sk;
+    if (CAUSAL) {
+      const int lim = (q0s + kBM < p.Sq ? q0s + kBM : p.Sq) + p.causal_off;
+      e = lim < e ? lim : e;
+    }
+    const int nt_all = e > 0 ? (e + kBN - 1) / kBN : 0;
+    const int kb = (ks * nt_all / p_in.ksplit) * kBN;
+    int ke = (ks == p_in.ksplit - 1) ? p.Sk : ((ks + 1) * nt_all / p_in.ksplit) * kBN;
+    ke = ke < p.Sk ? ke : p.Sk;
+    p.k += 2 * (int64_t)kb * p.k_ss;
+    p.v += 2 * (int64_t)kb * p.v_ss;
+    p.Sk = ke > kb ? ke - kb : 0;
+    p.causal_off -= kb;
+    p.acc = p_in.ws_o + (int64_t)ks * p.B * p.Sq * p.Hq * D;
+    p.a_sb = (int64_t)p.Sq * p.Hq * D; p.a_ss = (int64_t)p.Hq * D; p.a_sh = D;
+    p.lse = p_in.ws_lse + (int64_t)ks * p.B * p.Hq * p.Sq;
+    p.lse_sb = (int64_t)p.Hq * p.Sq; p.lse_sh = p.Sq;
+    p.merge_in = 0; p.final_begin = 0; p.final_end = 0; p.out_wide = 0;
   }
 
   const int q0 = qt * kBM;
@@ -584,10 +618,63 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   if (p_in.sched && threadIdx.x == 0) item_queue_release(queue);
 }
 
+// Combines the partial results of a K-split launch: per query row, the `n` cuts' normalised partials (fp32) and
+// LSEs [+ the running result when merge_in] -> what ONE launch would have left behind: lse, and the row in 16 bits
+// (final rows) or fp32 (the others).  HBM-bound: one thread per 4 consecutive head-dim elements of a row.
+template <int DT>
+__global__ __launch_bounds__(256) void split_merge_kernel(const FwdParams p, int D) {
+  using E = Elem<DT>;
+  const int d4 = D >> 2;
+  const int64_t total = (int64_t)p.B * p.Sq * p.Hq * d4;
+  const int64_t slot_o = (int64_t)p.B * p.Sq * p.Hq * D, slot_l = (int64_t)p.B * p.Hq * p.Sq;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % d4);
+    int64_t r = i / d4;
+    const int h = (int)(r % p.Hq); r /= p.Hq;
+    const int s = (int)(r % p.Sq);
+    const int b = (int)(r / p.Sq);
+    const int64_t l_idx = ((int64_t)b * p.Hq + h) * p.Sq + s;
+    const int64_t o_idx = (((int64_t)b * p.Sq + s) * p.Hq + h) * D + 4 * c4;
+    float* lse_p = p.lse + b * p.lse_sb + h * p.lse_sh + s;
+    const int64_t arow = b * p.a_sb + (int64_t)s * p.a_ss + h * p.a_sh + 4 * c4;
+    float mx = p.merge_in ? *lse_p : USP_NEG_INF;
+    float l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      l[j] = j < p.ksplit ? p.ws_lse[j * slot_l + l_idx] : USP_NEG_INF;
+      mx = fmaxf(mx, l[j]);
+    }
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    float new_lse = USP_NEG_INF;
+    if (mx != USP_NEG_INF) {
+      float sum = 0.f, w_old = 0.f;
+      if (p.merge_in) { w_old = exp2f((*lse_p - mx) * kLog2e); sum = w_old; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        l[j] = exp2f((l[j] - mx) * kLog2e);          // 0 for an empty cut (lse = -inf) and for j >= ksplit
+        sum += l[j];
+      }
+      const float inv = 1.f / sum;
+      new_lse = mx + log2f(sum) * kLn2;
+      if (p.merge_in) o = *(const f32x4*)(p.acc + arow) * (w_old * inv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < p.ksplit) o += *(const f32x4*)(p.ws_o + j * slot_o + o_idx) * (l[j] * inv);
+    }
+    if (c4 == 0) *lse_p = new_lse;
+    if (s >= p.final_begin && s < p.final_end) {
+      const u32x2 pk = {E::pack2(o[0], o[1]), E::pack2(o[2], o[3])};
+      *(u32x2*)(p.out + 2 * (b * p.o_sb + (int64_t)s * p.o_ss + h * p.o_sh + 4 * c4)) = pk;
+    } else {
+      *(f32x4*)(p.acc + arow) = o;
+    }
+  }
+}
+
 template <int D, int DT, int NWAVES>
 static int launch_fwd_w(FwdParams p, bool causal, hipStream_t st) {
   p.nq = (p.Sq + 32 * NWAVES - 1) / (32 * NWAVES);
-  p.n_items = p.B * p.Hq * p.nq;
+  p.n_items = p.B * p.Hq * p.nq * p.ksplit;
   // persistent launch: one workgroup per resident slot (8 waves: 1 per CU, 4 waves: 2 per CU)
   static const int cus = [] {
     int dev = 0, n = 0;
@@ -600,10 +687,20 @@ static int launch_fwd_w(FwdParams p, bool causal, hipStream_t st) {
   const int slots = cus * (NWAVES == 8 ? 1 : 2);
   const int grid = (((persist || p.sched) && !p.interleave) && p.n_items > slots) ? slots : p.n_items;
   const size_t lds = 2 * 2 * kBN * D * 2 + (p.sched ? 16 : 0);
-  if (causal)
+  if (p.ksplit > 1) {
+    if (causal)
+      hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true, NWAVES, true>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
+    else
+      hipLaunchKernelGGL((flash_fwd_kernel<D, DT, false, NWAVES, true>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
+  } else if (causal)
     hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
   else
     hipLaunchKernelGGL((flash_fwd_kernel<D, DT, false, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
+  if (p.ksplit > 1) {          // same stream: the partials are complete when this starts
+    const int64_t work = (int64_t)p.B * p.Sq * p.Hq * (D / 4);
+    const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    hipLaunchKernelGGL((split_merge_kernel<DT>), dim3(blocks), dim3(256), 0, st, p, D);
+  }
   return hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
 }
 
@@ -616,7 +713,7 @@ static int launch_fwd(const FwdParams& p, bool causal, hipStream_t st) {
   static const int forced = [] { const char* e = getenv("USP_FWD_WAVES"); return e ? atoi(e) : 0; }();
   int waves = forced;
   if (waves != 4 && waves != 8) {
-    const int64_t grid8 = (int64_t)p.B * p.Hq * ((p.Sq + 255) / 256);
+    const int64_t grid8 = (int64_t)p.B * p.Hq * ((p.Sq + 255) / 256) * p.ksplit;
     // short causal sequences: less diagonal waste (dense only: in packed mode twice the items cost more to fetch)
     // beside a transfer (interleave) RCCL's resident workgroups take a few CUs: with ONE 256-row item per CU a lost
     // CU costs a whole extra round, so halve the granularity there (kbench overlap, 8 resident copy workgroups:
@@ -635,6 +732,12 @@ static bool tensor16_ok(const usp_tensor& t, int esize) {
 }
 
 }  // namespace usp
+
+extern "C" int64_t usp_flash_fwd_workspace_bytes(const usp_fwd_args* a, int32_t k_splits) {
+  if (!a || k_splits <= 1 || k_splits > 8 || a->seq_q || a->seq_k) return 0;
+  const int64_t rows = (int64_t)a->B * a->Sq * a->Hq;
+  return (int64_t)k_splits * (rows * a->D + rows) * 4;         // partial outputs + partial LSEs, fp32 (a->D % 4 == 0)
+}
 
 extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   using namespace usp;
@@ -682,6 +785,15 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   p.seq_q = a->seq_q; p.seq_k = a->seq_k;
   p.sched = packed ? a->sched : nullptr;
   p.interleave = (a->flags & USP_LAUNCH_INTERLEAVE) ? 1 : 0;
+  p.ksplit = 1; p.ws_o = nullptr; p.ws_lse = nullptr;
+  if (a->k_splits > 1 && a->workspace != nullptr) {
+    if (packed) return USP_EUNSUPPORTED;                       // dense launches only
+    if (a->k_splits > 8 || !aligned16(a->workspace)) return USP_EINVAL;
+    if ((any_acc || a->merge_in) && (a->acc.stride_h % 4 != 0)) return USP_EUNSUPPORTED;
+    p.ksplit = a->k_splits;
+    p.ws_o = (float*)a->workspace;
+    p.ws_lse = p.ws_o + (int64_t)p.ksplit * a->B * a->Sq * a->Hq * a->D;
+  }
   if (packed) p.q_sb = p.k_sb = p.v_sb = p.o_sb = p.a_sb = p.lse_sb = 0;
   hipStream_t st = (hipStream_t)stream;
   const bool causal = a->causal != 0;

@@ -19,13 +19,13 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(usp_[a-z0-9_]+)\s*\(", hdr))
     declared -= {"usp_tensor"}
     assert {"usp_flash_fwd", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
-            "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror"} <= declared
+            "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror", "usp_flash_fwd_workspace_bytes"} <= declared
     lib = ctypes.CDLL(_C.lib_path())
     for name in declared:
         assert hasattr(lib, name), f"libusp_hip.so does not export {name}"
     assert set(_C.EXPORTS) == declared
     L = _C.load()
-    assert L.usp_abi_version() == _C.ABI_VERSION == 3
+    assert L.usp_abi_version() == _C.ABI_VERSION == 4
     assert b"head_dim" in L.usp_strerror(-2)
 
 
@@ -289,3 +289,30 @@ def test_zigzag_fetch_plan_and_wave_matching():
                 recvs = {((b - s) % P, b) for b in range(P) for s in zigzag_wave_steps(P, b, front)[1]}
                 assert sends == recvs
                 assert all(any(a == x or b == x for a, b in sends) for x in range(P))
+
+
+def test_forward_k_split_workspace_and_policy(monkeypatch):
+    """ABI v4's K split of few-item forward launches: the workspace size the C side asks for (host code, no GPU), the
+    argument checks that need no launch, and the (staged, opt-in) policy of the Python binding."""
+    import ctypes
+    L = _C.load()
+    a = _C.UspFwdArgs()
+    a.B, a.Sq, a.Hq, a.Hkv, a.D, a.Sk = 2, 300, 4, 2, 64, 712
+    rows = 2 * 300 * 4
+    for n in (2, 3, 8):
+        assert L.usp_flash_fwd_workspace_bytes(ctypes.byref(a), n) == n * (rows * 64 + rows) * 4
+    assert L.usp_flash_fwd_workspace_bytes(ctypes.byref(a), 1) == 0
+    assert L.usp_flash_fwd_workspace_bytes(ctypes.byref(a), 9) == 0
+    a.seq_q = 8                                                      # packed batches are not split
+    assert L.usp_flash_fwd_workspace_bytes(ctypes.byref(a), 2) == 0
+    # the policy: off unless asked for; then only causal launches with fewer than two 256-row items per CU
+    monkeypatch.delenv("USP_FWD_KSPLIT", raising=False)
+    assert _C.fwd_k_splits(1, 16384, 2, True) == 0
+    monkeypatch.setenv("USP_FWD_KSPLIT", "4")
+    assert _C.fwd_k_splits(1, 16384, 2, True) == 4                  # 128 items
+    assert _C.fwd_k_splits(1, 16384, 2, False) == 0                 # not causal
+    assert _C.fwd_k_splits(1, 16384, 8, True) == 0                  # 512 items: fills the part
+    assert _C.fwd_k_splits(2, 8192, 16, True) == 0                  # BASELINE configs[1]
+    monkeypatch.setenv("USP_FWD_KSPLIT", "auto")
+    assert _C.fwd_k_splits(1, 16384, 4, True) == 2 and _C.fwd_k_splits(1, 16384, 2, True) == 4
+    assert _C.fwd_k_splits(1, 2048, 2, True) == 0                   # short sequences: nothing to balance

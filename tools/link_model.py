@@ -42,6 +42,12 @@ def main():
         tot, exp = pipeline(t_in, comp, t_out, ng)
         print("   %d head group(s): %.2f ms per iteration = %5.0f TFLOP/s on 2 GPUs (attention %.2f ms, exposed %.2f ms)"
               % (ng, tot, 2 * 0.2749 / tot * 1e3, comp, exp))
+    # with the forward K split (usp_fwd_args.k_splits; kbench ksplit, profiles/r02_kbench_ksplit.log): a 4-head group
+    # 0.257 ms at n = 2 (0.345 unsplit on that box), a 2-head group 0.147 ms at n = 4 (0.247 unsplit)
+    for ng, comp in ((2, 2 * 0.257), (4, 4 * 0.147)):
+        tot, exp = pipeline(t_in, comp, t_out, ng)
+        print("   %d head group(s), K split: %.2f ms per iteration = %5.0f TFLOP/s on 2 GPUs (attention %.2f ms, exposed %.2f ms)"
+              % (ng, tot, 2 * 0.2749 / tot * 1e3, comp, exp))
 
     # configs[3]: 4 GPUs, ring 4 zigzag, B1 S32768 H16, forward.  K/V 2 x 32 MiB per peer, each peer over its own link.
     # kernel times of a rank (rocprofv3, profiles/r02_rank_emulation.txt): step 0 (causal) 0.294 ms, a half step 0.143 ms
