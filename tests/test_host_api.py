@@ -316,3 +316,54 @@ def test_forward_k_split_workspace_and_policy(monkeypatch):
     monkeypatch.setenv("USP_FWD_KSPLIT", "auto")
     assert _C.fwd_k_splits(1, 16384, 4, True) == 2 and _C.fwd_k_splits(1, 16384, 2, True) == 4
     assert _C.fwd_k_splits(1, 2048, 2, True) == 0                   # short sequences: nothing to balance
+
+
+def test_forward_k_split_glue_of_the_binding(monkeypatch):
+    """_C.flash_fwd's handling of k_splits without a GPU: the launch is intercepted (a stand-in records the argument
+    struct), everything in front of it is the real code -- the policy, the C side's workspace size, the scratch buffer
+    (one per stream, reused, grown on demand), the two ABI v4 fields."""
+    import ctypes
+    real = _C.load()
+    seen = []
+
+    class Lib:
+        usp_flash_fwd_workspace_bytes = real.usp_flash_fwd_workspace_bytes
+        usp_strerror = real.usp_strerror
+
+        @staticmethod
+        def usp_flash_fwd(args, stream):
+            a = ctypes.cast(args, ctypes.POINTER(_C.UspFwdArgs)).contents
+            seen.append((a.k_splits, a.workspace, a.B, a.Sq, a.Hq, a.D, a.causal, a.final_end))
+            return 0
+
+    class Stream:
+        cuda_stream = 7
+
+    monkeypatch.setattr(_C, "load", lambda: Lib)
+    monkeypatch.setattr(_C, "_require_cuda", lambda *t: None)
+    monkeypatch.setattr(_C, "_stream", lambda: ctypes.c_void_p(7))
+    monkeypatch.setattr(_C.torch.cuda, "current_stream", lambda *a: Stream)
+    monkeypatch.setattr(_C, "_FWD_WS", {})
+    monkeypatch.delenv("USP_FWD_KSPLIT", raising=False)
+    B, S, H, D = 1, 4096, 2, 128
+    q = torch.zeros(B, S, H, D, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, S)
+    out = torch.zeros_like(q)
+    _C.flash_fwd(q, q, q, 0.1, True, lse, out)                       # default: no split
+    assert seen[-1][:2] == (0, None)
+    _C.flash_fwd(q, q, q, 0.1, True, lse, out, k_splits=2)
+    n, ws = seen[-1][:2]
+    need2 = 2 * (B * S * H * D + B * H * S) * 4
+    assert n == 2 and ws and ws % 16 == 0
+    (buf,) = _C._FWD_WS.values()
+    assert buf.data_ptr() == ws and buf.numel() >= need2
+    _C.flash_fwd(q, q, q, 0.1, True, lse, out, k_splits=2)           # reused
+    assert seen[-1][1] == ws and len(_C._FWD_WS) == 1
+    _C.flash_fwd(q, q, q, 0.1, True, lse, out, k_splits=4)           # grown
+    (buf,) = _C._FWD_WS.values()
+    assert seen[-1][0] == 4 and buf.numel() >= 2 * need2 and seen[-1][1] == buf.data_ptr()
+    monkeypatch.setenv("USP_FWD_KSPLIT", "auto")                     # the staged policy: 2 heads x 16 tiles -> n = 4
+    _C.flash_fwd(q, q, q, 0.1, True, lse, out)
+    assert seen[-1][0] == 4
+    _C.flash_fwd(q, q, q, 0.1, False, lse, out)                      # not causal -> off
+    assert seen[-1][:2] == (0, None)
