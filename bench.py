@@ -352,11 +352,13 @@ def exchange_mode(attn, lq, lk, cfg, ws):
     cap = attn._packed_exchange(lq, lk)
     if cap is None:
         return "three separate exchanges (reference structure)"
-    from yunchang_amd.hybrid.async_attn_layer import _groups, _link_bound
+    from yunchang_amd.hybrid.async_attn_layer import _groups, _k_split_groups, _link_bound
     S = lq.shape[1] * cfg["ud"]
     lb = _link_bound(cfg["Hq"], cfg["Hkv"], cfg["ud"], cfg["B"], S, lq.shape[-1], lq.element_size(), cfg["rd"], True)
-    ng = _groups(cfg["Hq"], cfg["Hkv"], cfg["ud"], cfg["B"], S, max_groups=cap, link_bound=lb)[0]
-    return f"one packed q|k|v exchange per head group, {ng} group(s)" + (", pipelined on a side stream" if ng > 1 else "")
+    ks = not cfg.get("bwd", False) and _k_split_groups(None, cfg["B"], S, True)
+    ng = _groups(cfg["Hq"], cfg["Hkv"], cfg["ud"], cfg["B"], S, max_groups=cap, link_bound=lb, k_split=ks)[0]
+    return (f"one packed q|k|v exchange per head group, {ng} group(s)" + (", pipelined on a side stream" if ng > 1 else "")
+            + (", sized for the forward K split" if ks else ""))
 
 
 def barrier(ws):

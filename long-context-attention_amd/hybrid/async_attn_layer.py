@@ -90,6 +90,11 @@ _FILL_ITEMS = 512
 # 1.33 ms (the schedule: all input exchanges queued first on the lane, group i's output behind its attention).  The
 # one-GPU rank emulation cannot see this (its wire is an HBM copy): its 0.69 vs 0.86 ms is kernel time only.
 _FILL_ITEMS_LINK_BOUND = 256
+# ... and half of that again where the forward kernel cuts few-item launches along K (usp_fwd_args.k_splits, staged behind
+# USP_FWD_KSPLIT): a 2-head group of the 2-GPU config (128 items) then runs at 936 instead of 557 TFLOP/s (kbench ksplit),
+# and four such groups put the iteration on the wire's floor (1.05 ms against 1.22 with two groups, tools/link_model.py).
+# Forward-only calls: the backward kernels have no such cut.
+_FILL_ITEMS_LINK_BOUND_KSPLIT = 128
 _LINK_BYTES_PER_S = 64e9      # one xGMI link, one direction (MI355X guide: 7 links x ~153 GB/s bidirectional per GPU)
 _KERNEL_FLOPS_PER_S = 1.1e15  # forward flash kernel on large launches (profiles/)
 
@@ -103,25 +108,35 @@ def _link_bound(Hq, Hkv, P, B, S, D, itemsize, ring, causal):
     return t_comm >= 0.5 * flops / _KERNEL_FLOPS_PER_S
 
 
-def _groups(Hq, Hkv, P, B=None, S=None, max_groups=None, link_bound=False):
+def _groups(Hq, Hkv, P, B=None, S=None, max_groups=None, link_bound=False, k_split=False):
     """(number of head groups, kv heads per rank per group, query heads per kv head).  A group is a
     set of whole KV heads (with their query heads) of every rank's post-exchange share.  With the problem
     size (B, S = sequence after the exchange) given, the pipeline is kept shallow enough that every group's
     attention launch still has _FILL_ITEMS 256-row work items (_FILL_ITEMS_LINK_BOUND when the caller found the
-    exchange long against the attention, `_link_bound`)."""
+    exchange long against the attention, `_link_bound`; _FILL_ITEMS_LINK_BOUND_KSPLIT when, in addition, the forward
+    kernel will cut such launches along K, `k_split`)."""
     assert Hq % P == 0 and Hkv % P == 0, f"heads ({Hq}, {Hkv}) not divisible by ulysses degree {P}"
     per_rank = Hkv // P
     ng = 1
     if P > 1:                       # nothing to hide without an exchange
         cap = _MAX_GROUPS if max_groups is None else min(_MAX_GROUPS, max_groups)
         if B is not None and S is not None:
-            fill = min(_FILL_ITEMS, _FILL_ITEMS_LINK_BOUND) if link_bound else _FILL_ITEMS
+            fill = min(_FILL_ITEMS, _FILL_ITEMS_LINK_BOUND_KSPLIT if k_split else _FILL_ITEMS_LINK_BOUND) if link_bound else _FILL_ITEMS
             cap = max(1, min(cap, (B * (Hq // P) * ((S + 255) // 256)) // fill))
         for cand in range(min(cap, per_rank), 0, -1):
             if per_rank % cand == 0:
                 ng = cand
                 break
     return ng, per_rank // ng, Hq // Hkv
+
+
+def _k_split_groups(ctx, B, S, causal):
+    """May the head groups be sized for launches the forward kernel cuts along K?  Only where that cut is on (the staged
+    USP_FWD_KSPLIT policy answers for a 2-head launch of this length) and no backward will follow."""
+    from .. import _C
+    if ctx is not None and any(ctx.needs_input_grad[:3]):
+        return False
+    return _C.fwd_k_splits(B, S, 2, bool(causal)) > 1
 
 
 def _qkv_to_seq(lane, q, k, v, P, ng, kvh, g, i, group):
@@ -181,7 +196,8 @@ class _AsyncUSPFunc(torch.autograd.Function):
         Hkv = k.shape[2]
         ring = dist.get_world_size(ring_pg) if ring_pg is not None else 1
         ng, kvh, g = _groups(Hq, Hkv, P, B, Sl * P, max_groups=ng_cap,
-                             link_bound=P > 1 and _link_bound(Hq, Hkv, P, B, Sl * P, D, q.element_size(), ring, causal))
+                             link_bound=P > 1 and _link_bound(Hq, Hkv, P, B, Sl * P, D, q.element_size(), ring, causal),
+                             k_split=_k_split_groups(ctx, B, Sl * P, causal))
         if softmax_scale is None:
             softmax_scale = D ** (-0.5)
         overlap = ng > 1                # kernels run beside later groups' exchanges

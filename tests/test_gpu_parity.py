@@ -240,7 +240,7 @@ def test_async_layer_on_gpu_streams(dev, single_rank_pg):
     import yunchang_amd.hybrid.async_attn_layer as AL
     B, S, Hq, Hkv, D = 2, 1024, 8, 4, 128
     groups = AL._groups
-    AL._groups = lambda hq, hkv, P, B=None, S=None, max_groups=None, link_bound=False: (4, hkv // P // 4, hq // hkv)   # 4 groups at P = 1
+    AL._groups = lambda hq, hkv, P, B=None, S=None, max_groups=None, link_bound=False, k_split=False: (4, hkv // P // 4, hq // hkv)   # 4 groups at P = 1
     request_restore = groups
     gen = torch.Generator(device="cpu").manual_seed(5)
     q, k, v, do = (torch.randn(B, S, h, D, generator=gen).to(torch.bfloat16).to(dev) for h in (Hq, Hkv, Hkv, Hq))

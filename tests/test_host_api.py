@@ -200,6 +200,9 @@ def test_head_group_cap_is_link_aware():
     assert _groups(32, 4, 2, 1, 16384, link_bound=c5) == (2, 1, 8)
     assert _groups(32, 32, 8, 1, 131072)[0] == 4                      # long sequence: plenty of items, attention-bound
     assert _groups(8, 8, 2, 1, 2048, link_bound=True)[0] == 1         # too small to split at all
+    # with the forward K split on (staged), a link-bound forward-only call takes groups of 128 items: four at configs[2]
+    assert _groups(16, 16, 2, 1, 16384, link_bound=c3, k_split=True)[0] == 4
+    assert _groups(32, 4, 2, 1, 16384, link_bound=c5, k_split=True) == (2, 1, 8)
     assert _groups(16, 16, 1)[0] == 1                                 # no exchange, nothing to hide
     with pytest.raises(AssertionError):
         _groups(6, 6, 4)
