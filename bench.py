@@ -281,18 +281,41 @@ def pmc_traffic():
     taken from the kernel sources of this tree (the summary carries their hash); otherwise null."""
     path = os.path.join(ROOT, "profiles", "r02_rocprof_summary.txt")
     try:
-        rd = wr = sha = None
+        rd = wr = sha = isa = None
         for ln in open(path):
             if ln.startswith("kernel_src_sha16:"):
                 sha = ln.split(":")[1].strip()
+            if ln.startswith("roofline_kernel_isa_sha16:"):
+                isa = ln.split(":")[1].split()[0]
             if "flash_fwd_kernel" in ln and "HBM read bytes/launch" in ln and rd is None:
                 rd = float(ln.split("=")[1].split("MB")[0])
             if "flash_fwd_kernel" in ln and "HBM write bytes/launch" in ln and wr is None:
                 wr = float(ln.split("=")[1].split("MB")[0])
-        if rd is None or wr is None or sha != kernel_source_sha16():
+        if rd is None or wr is None:
             return None
-        return {"read_MB": rd, "write_MB": wr, "algorithmic_MB": 268.4, "kernel_src_sha16": sha,
-                "source": "profiles/r02_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources)"}
+        res = {"read_MB": rd, "write_MB": wr, "algorithmic_MB": 268.4, "kernel_src_sha16": sha,
+               "source": "profiles/r02_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources)"}
+        if sha == kernel_source_sha16():
+            return res
+        # The sources have changed since the profile.  The figures still describe THIS library if the profiled kernel's
+        # machine code is the same (round 2 added the K-split instantiations beside the plain forward kernels):
+        # tools/kernel_isa.py disassembles the shipped library and hashes that kernel's instruction stream.
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import kernel_isa
+            mine = kernel_isa.isa_identity(os.path.join(ROOT, "long-context-attention_amd", "libusp_hip.so"))[0]
+        except Exception as e:                                   # no llvm-objdump, unreadable library ...
+            mine = f"unavailable ({repr(e)[:80]})"
+        if isa is not None and mine == isa:
+            res["source"] = ("profiles/r02_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE); the sources have "
+                             "changed since, the machine code of the profiled kernel has not (tools/kernel_isa.py)")
+            res["roofline_kernel_isa_sha16"] = isa
+            res["kernel_src_sha16_now"] = kernel_source_sha16()
+            return res
+        # a stale number is worse than none: report where the last measurement is and what it was taken from
+        return {"read_MB": None, "write_MB": None, "algorithmic_MB": 268.4, "kernel_src_sha16": kernel_source_sha16(),
+                "stale": f"profiles/r02_rocprof_summary.txt holds {rd} MB read + {wr} MB written per launch, taken from "
+                         f"kernel sources {sha} (kernel machine code {isa}); this library's: {mine} -- no figure is claimed"}
     except OSError:
         return None
 

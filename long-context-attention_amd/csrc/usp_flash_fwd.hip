@@ -40,9 +40,17 @@ struct FwdParams {
   const int* seq_q; const int* seq_k;   // packed variable-length batch: B (first row, rows) pairs, or NULL
   int* sched;                           // packed mode: control block of the dynamic item queue, or NULL
   int interleave;                       // USP_LAUNCH_INTERLEAVE: one workgroup per item (collectives can slip in)
-  int ksplit;                           // dense mode: every (batch, head, query tile) is cut into `ksplit` items along K (1 = off)
-  float* ws_o; float* ws_lse;           // ksplit > 1: partial results, [ksplit][B,Sq,Hq,D] fp32 and [ksplit][B,Hq,Sq] fp32
 };
+
+// K split (dense mode): every (batch, head, query tile) is cut into `ksplit` items along K; partial results go to
+// [ksplit][B,Sq,Hq,D] fp32 and [ksplit][B,Hq,Sq] fp32.  Kernel arguments of the split instantiation ONLY: the plain
+// kernels keep the argument block (and with it the machine code) they were profiled with.
+struct FwdSplit {
+  int ksplit;
+  float* ws_o; float* ws_lse;
+};
+template <bool KS> struct FwdArgsT : FwdParams {};
+template <> struct FwdArgsT<true> : FwdParams, FwdSplit {};
 
 constexpr int kBN = 64;    // keys per KV tile
 
@@ -58,7 +66,7 @@ template <int D> struct KSwz {
 // KSPLIT: the K-split variant is its own instantiation -- the plain kernels sit on the register cliff (256 VGPRs), and
 // with the split code compiled in unconditionally hipcc spilled 16 more bytes in them.
 template <int D, int DT, bool CAUSAL, int NWAVES, bool KSPLIT = false>
-__global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdParams p_in) {
+__global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdArgsT<KSPLIT> p_in) {
   using E = Elem<DT>;
   constexpr int kThreads = 64 * NWAVES;
   constexpr int kBM = 32 * NWAVES;
@@ -87,9 +95,13 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
   int w = p_in.sched ? item_queue_next(queue, qstate, qslots, pass) : walk.at(pass);
   if (w < 0) break;
   FwdParams p = p_in;
-  if (!p_in.sched) w = walk.dealt(w, KSPLIT ? p.nq * p.ksplit : p.nq);    // the K cuts of a tile are dealt like tiles
   int ks = 0;
-  if constexpr (KSPLIT) { ks = w % p_in.ksplit; w /= p_in.ksplit; }
+  if constexpr (KSPLIT) {
+    w = walk.dealt(w, p.nq * p_in.ksplit);                 // the K cuts of a tile are dealt like tiles
+    ks = w % p_in.ksplit; w /= p_in.ksplit;
+  } else {
+    if (!p_in.sched) w = walk.dealt(w, p.nq);
+  }
   const int qt_r = w % p.nq;
   int rest = w / p.nq;
   const int qt = CAUSAL ? (p.nq - 1 - qt_r) : qt_r;      // heavy (late) tiles first
@@ -622,7 +634,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdPara
 // LSEs [+ the running result when merge_in] -> what ONE launch would have left behind: lse, and the row in 16 bits
 // (final rows) or fp32 (the others).  HBM-bound: one thread per 4 consecutive head-dim elements of a row.
 template <int DT>
-__global__ __launch_bounds__(256) void split_merge_kernel(const FwdParams p, int D) {
+__global__ __launch_bounds__(256) void split_merge_kernel(const FwdArgsT<true> p, int D) {
   using E = Elem<DT>;
   const int d4 = D >> 2;
   const int64_t total = (int64_t)p.B * p.Sq * p.Hq * d4;
@@ -672,7 +684,7 @@ __global__ __launch_bounds__(256) void split_merge_kernel(const FwdParams p, int
 }
 
 template <int D, int DT, int NWAVES>
-static int launch_fwd_w(FwdParams p, bool causal, hipStream_t st) {
+static int launch_fwd_w(FwdArgsT<true> p, bool causal, hipStream_t st) {
   p.nq = (p.Sq + 32 * NWAVES - 1) / (32 * NWAVES);
   p.n_items = p.B * p.Hq * p.nq * p.ksplit;
   // persistent launch: one workgroup per resident slot (8 waves: 1 per CU, 4 waves: 2 per CU)
@@ -692,10 +704,14 @@ static int launch_fwd_w(FwdParams p, bool causal, hipStream_t st) {
       hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true, NWAVES, true>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
     else
       hipLaunchKernelGGL((flash_fwd_kernel<D, DT, false, NWAVES, true>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
-  } else if (causal)
-    hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
-  else
-    hipLaunchKernelGGL((flash_fwd_kernel<D, DT, false, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
+  } else {
+    FwdArgsT<false> plain;                                   // the argument block of the plain kernels: FwdParams alone
+    static_cast<FwdParams&>(plain) = p;
+    if (causal)
+      hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, plain);
+    else
+      hipLaunchKernelGGL((flash_fwd_kernel<D, DT, false, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, plain);
+  }
   if (p.ksplit > 1) {          // same stream: the partials are complete when this starts
     const int64_t work = (int64_t)p.B * p.Sq * p.Hq * (D / 4);
     const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
@@ -705,7 +721,7 @@ static int launch_fwd_w(FwdParams p, bool causal, hipStream_t st) {
 }
 
 template <int D, int DT>
-static int launch_fwd(const FwdParams& p, bool causal, hipStream_t st) {
+static int launch_fwd(const FwdArgsT<true>& p, bool causal, hipStream_t st) {
   // Workgroup shape: 8 waves (256 query rows, one workgroup per CU) stage K/V once per 256 rows and win by
   // 3-4 % whenever they can give every CU work; 4 waves (128 rows, two workgroups per CU) are used only
   // when the 8-wave item list is shorter than the CU count, or for short causal sequences (<= 1024 rows:
@@ -763,7 +779,7 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   if ((any_acc || a->merge_in) && !tensor16_ok(a->acc, 4))
     return a->acc.ptr ? USP_EUNSUPPORTED : USP_EINVAL;
 
-  FwdParams p;
+  FwdArgsT<true> p;
   p.q = (const char*)a->q.ptr; p.k = (const char*)a->k.ptr; p.v = (const char*)a->v.ptr;
   p.out = (char*)a->out.ptr; p.acc = (float*)a->acc.ptr; p.lse = a->lse;
   p.q_sb = a->q.stride_b; p.q_ss = a->q.stride_s; p.q_sh = a->q.stride_h;

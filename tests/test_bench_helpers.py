@@ -170,3 +170,26 @@ def test_bench_main_prints_one_contract_line(ws):
     2x4 with GQA and a backward): rank 0 prints exactly ONE JSON line carrying the contract keys, the in-bench
     parity of every rank's shard and -- for N > 1 -- the overlap probe; other ranks print nothing."""
     assert all(run_distributed(_main_worker, ws))
+
+
+def test_profile_is_quoted_only_for_the_kernel_it_was_taken_from(monkeypatch):
+    """bench.pmc_traffic(): the committed PMC figures are quoted when the kernel sources are the profiled ones, or --
+    sources changed -- when the MACHINE CODE of the profiled kernel inside the shipped library is what was profiled
+    (tools/kernel_isa.py: the K-split instantiations were added beside kernels that did not change); otherwise no figure."""
+    import sys
+    b = _bench()
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_isa
+    roof, allp, n = kernel_isa.isa_identity(os.path.join(ROOT, "long-context-attention_amd", "libusp_hip.so"))
+    assert n == 24 and len(roof) == 16
+    recorded = [ln.split(":")[1].split()[0] for ln in open(os.path.join(ROOT, "profiles", "r02_rocprof_summary.txt"))
+                if ln.startswith("roofline_kernel_isa_sha16:")]
+    t = b.pmc_traffic()
+    if recorded == [roof] or t.get("kernel_src_sha16") == b.kernel_source_sha16():
+        assert t["read_MB"] > 100 and t["write_MB"] > 50
+    else:
+        assert t["read_MB"] is None and "stale" in t
+    monkeypatch.setattr(kernel_isa, "isa_identity", lambda lib: ("0" * 16, "0" * 16, 24))      # a different kernel
+    monkeypatch.setattr(b, "kernel_source_sha16", lambda: "f" * 16)
+    t = b.pmc_traffic()
+    assert t["read_MB"] is None and "no figure is claimed" in t["stale"]

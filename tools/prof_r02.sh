@@ -24,6 +24,7 @@ for app in fwd bwd; do
 done
 export USP_KERNEL_SRC_SHA16=$(cd $R && python -c "import bench; print(bench.kernel_source_sha16())")
 python $R/tools/prof_summary.py $OUT $OUT/summary.txt > /dev/null
+python $R/tools/kernel_isa.py | head -1 >> $OUT/summary.txt      # machine-code identity of the profiled forward kernel
 grep -E "^\{" $OUT/bench_stdout.log > $OUT/bench_line.json
 head -12 $OUT/summary.txt
 du -sh $OUT
