@@ -5,6 +5,7 @@ Transport is torch.distributed point-to-point (`batch_isend_irecv` == grouped RC
 xGMI on ROCm; gloo on CPU for the orchestration tests).
 """
 import os
+from collections import OrderedDict
 from typing import List, Optional, Tuple
 
 import torch
@@ -86,6 +87,24 @@ class RingComm:
         self._ops = []
 
 
+_MAX_SLOT_SETS = 8
+
+
+def _cached_slots(cache: "OrderedDict", key, make):
+    """Persistent receive slots, least-recently-used sets dropped beyond _MAX_SLOT_SETS: a training run with a few fixed
+    shapes never reallocates, one with ever-changing token counts (packed batches) does not grow without bound.  Dropping
+    a set is safe at any time: a live relay holds its own reference, and the memory goes back to the caching allocator
+    of the compute stream, on which every kernel that read the slots was queued."""
+    slots = cache.get(key)
+    if slots is None:
+        slots = cache[key] = make()
+        while len(cache) > _MAX_SLOT_SETS:
+            cache.popitem(last=False)
+    else:
+        cache.move_to_end(key)
+    return slots
+
+
 class KVRelay:
     """Brings the K and V of every other ring rank to this rank AHEAD of the attention kernels.
 
@@ -114,7 +133,7 @@ class KVRelay:
     Use as a context manager: `finish` must run on every exit path (it re-joins the side stream).
     """
 
-    _SLOTS = {}          # (shape, dtype, device, P) -> [(k_slot, v_slot)] * (P-1), device tensors only
+    _SLOTS = OrderedDict()   # (shape, dtype, device, P, rank) -> [(k_slot, v_slot)] * (P-1), device tensors only
 
     def __init__(self, process_group, k: torch.Tensor, v: torch.Tensor):
         self.P = dist.get_world_size(process_group)
@@ -191,10 +210,8 @@ class KVRelay:
         if not k.is_cuda:
             return [(torch.empty_like(k), torch.empty_like(v)) for _ in range(self.P - 1)]
         key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index, self.P, rank)
-        slots = KVRelay._SLOTS.get(key)
-        if slots is None:
-            slots = KVRelay._SLOTS[key] = [(torch.empty_like(k), torch.empty_like(v)) for _ in range(self.P - 1)]
-        return slots
+        return _cached_slots(KVRelay._SLOTS, key,
+                             lambda: [(torch.empty_like(k), torch.empty_like(v)) for _ in range(self.P - 1)])
 
     def get(self, step: int) -> Tuple[torch.Tensor, torch.Tensor]:
         """K, V held after `step` hops; makes the current stream wait for that hop."""
@@ -236,7 +253,7 @@ class ZigzagKVFetch:
     shrinks from three ring steps to the launches of the last piece.  All waves run on the "ring" side stream;
     receive slots are persistent like KVRelay's.  Context manager, like KVRelay."""
 
-    _SLOTS = {}
+    _SLOTS = OrderedDict()
 
     def __init__(self, process_group, k: torch.Tensor, v: torch.Tensor, pieces: int = 1):
         P = self.P = dist.get_world_size(process_group)
@@ -254,12 +271,8 @@ class ZigzagKVFetch:
             self._stream = _side_stream(k.device, "ring")
             self._stream.wait_stream(torch.cuda.current_stream())     # k, v are produced on the compute stream
         key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index if cuda else -1, P, r, W)
-        slots = ZigzagKVFetch._SLOTS.get(key) if cuda else None
-        if slots is None:       # slots[w][s - 1] = (k piece, v piece) of source rank r - s
-            slots = [[tuple(torch.empty_like(t) for t in mine[w]) for _ in range(P - 1)] for w in range(2 * W)]
-            if cuda:
-                ZigzagKVFetch._SLOTS[key] = slots
-        self.slots = slots
+        make = lambda: [[tuple(torch.empty_like(t) for t in mine[w]) for _ in range(P - 1)] for w in range(2 * W)]
+        self.slots = _cached_slots(ZigzagKVFetch._SLOTS, key, make) if cuda else make()   # slots[w][s-1] = (k, v) piece of rank r-s
         self.events = [None] * (2 * W)
         # Wave 0 is posted NOW, in front of the caller's step-0 kernels (a transfer kernel queued before an attention
         # launch is resident at once; one that arrives while the launch holds every CU waits for workgroups to drain,

@@ -370,3 +370,16 @@ def test_forward_k_split_glue_of_the_binding(monkeypatch):
     assert seen[-1][0] == 4
     _C.flash_fwd(q, q, q, 0.1, False, lse, out)                      # not causal -> off
     assert seen[-1][:2] == (0, None)
+
+
+def test_receive_slot_cache_is_bounded():
+    """The persistent K/V receive slots are kept per shape; packed batches change shape every step, so the cache drops
+    its least recently used sets instead of growing for ever."""
+    from collections import OrderedDict
+    from yunchang_amd.ring import utils as U
+    cache, made = OrderedDict(), []
+    for i in range(U._MAX_SLOT_SETS + 5):
+        U._cached_slots(cache, ("shape", i), lambda i=i: made.append(i) or [i])
+        U._cached_slots(cache, ("shape", 0), lambda: made.append("again") or ["again"])      # the hot shape stays
+    assert len(cache) == U._MAX_SLOT_SETS and ("shape", 0) in cache and "again" not in made
+    assert ("shape", 1) not in cache and ("shape", U._MAX_SLOT_SETS + 4) in cache
