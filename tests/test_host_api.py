@@ -383,3 +383,29 @@ def test_receive_slot_cache_is_bounded():
         U._cached_slots(cache, ("shape", 0), lambda: made.append("again") or ["again"])      # the hot shape stays
     assert len(cache) == U._MAX_SLOT_SETS and ("shape", 0) in cache and "again" not in made
     assert ("shape", 1) not in cache and ("shape", U._MAX_SLOT_SETS + 4) in cache
+
+
+def test_host_launch_plumbing_without_a_device():
+    """On a box without a GPU a well-formed call must get through the whole host side of usp_flash_fwd -- argument
+    checks, workgroup shape, the plain and the K-split argument blocks -- and come back with USP_ELAUNCH from the
+    launch itself (not crash, not report success).  Skipped where a device exists: the pointers are made up."""
+    import ctypes
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: the made-up pointers would be dereferenced")
+    L = _C.load()
+    B, S, H, D = 1, 512, 2, 128
+    base = 0x7F0000000000
+    t = lambda i: _C.UspTensor(base + i * 0x1000000, S * H * D, H * D, D)
+    a = _C.UspFwdArgs()
+    a.dtype, a.B, a.Sq, a.Sk, a.Hq, a.Hkv, a.D, a.causal = 0, B, S, S, H, H, D, 1
+    a.softmax_scale = D ** -0.5
+    a.q, a.k, a.v, a.out = t(0), t(1), t(2), t(3)
+    a.lse, a.lse_stride_b, a.lse_stride_h = base + 4 * 0x1000000, H * S, S
+    a.final_end = S
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -3                      # USP_ELAUNCH
+    a.k_splits, a.workspace = 2, base + 5 * 0x1000000
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -3
+    a.workspace = base + 5 * 0x1000000 + 4                                   # misaligned scratch: refused before any launch
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
+    a.k_splits, a.workspace = 9, base + 5 * 0x1000000
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
