@@ -271,8 +271,22 @@ class ZigzagKVFetch:
             self._stream = _side_stream(k.device, "ring")
             self._stream.wait_stream(torch.cuda.current_stream())     # k, v are produced on the compute stream
         key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index if cuda else -1, P, r, W)
-        make = lambda: [[tuple(torch.empty_like(t) for t in mine[w]) for _ in range(P - 1)] for w in range(2 * W)]
-        self.slots = _cached_slots(ZigzagKVFetch._SLOTS, key, make) if cuda else make()   # slots[w][s-1] = (k, v) piece of rank r-s
+        # One buffer pair per wave: the pieces of ring ranks r-1 ... r-(P-1) one behind the other along the sequence.
+        # At batch 1 each piece is a contiguous row range of it (what a receive needs), so the pieces of several
+        # source ranks can be handed to ONE attention launch as one K/V (`get_range`): one merge epilogue per wave and
+        # query range instead of one per source rank (+16 / +40 us each at BASELINE's 4-GPU shape, kbench pieces).
+        self.grouped = k.shape[0] == 1
+
+        def make():
+            if not self.grouped:
+                return None, [[tuple(torch.empty_like(t) for t in mine[w]) for _ in range(P - 1)] for w in range(2 * W)]
+            bufs = [tuple(torch.empty((1, (P - 1) * t.shape[1]) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
+                          for t in mine[w]) for w in range(2 * W)]
+            rows = [mine[w][0].shape[1] for w in range(2 * W)]
+            return bufs, [[tuple(b[:, i * rows[w]:(i + 1) * rows[w]] for b in bufs[w]) for i in range(P - 1)]
+                          for w in range(2 * W)]
+        # slots[w][s-1] = (k, v) piece of rank r-s (views into bufs[w] when grouped)
+        self.bufs, self.slots = _cached_slots(ZigzagKVFetch._SLOTS, key, make) if cuda else make()
         self.events = [None] * (2 * W)
         # Wave 0 is posted NOW, in front of the caller's step-0 kernels (a transfer kernel queued before an attention
         # launch is resident at once; one that arrives while the launch holds every CU waits for workgroups to drain,
@@ -321,6 +335,17 @@ class ZigzagKVFetch:
         if self.events[wave] is not None:
             torch.cuda.current_stream().wait_event(self.events[wave])
         return self.slots[wave][step - 1]
+
+    def get_range(self, wave: int, s_lo: int, s_hi: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(K, V) rows of wave `wave` of ring ranks r - s_lo ... r - s_hi as ONE tensor each (batch 1 only: `grouped`);
+        the compute stream waits for that wave."""
+        assert self.grouped and 1 <= s_lo <= s_hi < self.P
+        assert wave < self.pieces or s_lo > self.r, "the zigzag schedule never reads this half"
+        self.post()
+        if self.events[wave] is not None:
+            torch.cuda.current_stream().wait_event(self.events[wave])
+        rows = self.slots[wave][0][0].shape[1]
+        return tuple(b[:, (s_lo - 1) * rows:s_hi * rows] for b in self.bufs[wave])
 
     def finish(self):
         if self._stream is not None:

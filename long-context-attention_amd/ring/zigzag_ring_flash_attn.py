@@ -70,24 +70,35 @@ def zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk):
         be.add(dv_acc, dv_acc, dv_blk)
 
 
-def zigzag_fetch_plan(P, r, pieces, c):
-    """The launches of ring rank r behind step 0 when the K/V arrive through ZigzagKVFetch: (wave, step, all_rows,
-    final_end) in issue order.  One launch per (wave, step that reads it), WAVE-major: whatever needs only the waves that
-    have landed runs before the compute stream waits for the next one (step-major, rank 0 would sit behind the last wave
-    from its first step on while the front-half launches of its other steps were ready).  Steps s <= r read the front
-    waves with every q row (zigzag_ring_flash_attn.py:54-58), steps s > r read all waves with q[c:] (:59-67;
-    final_end then counts rows of q[c:]).  Rows are emitted in 16 bits by the LAST launch that touches them: rows [0,c)
-    by the last all-rows launch, rows [c,2c) by the last launch of all (pure schedule logic; tests/test_host_api.py)."""
-    launches = [(w, step, step <= r) for w in range(2 * pieces) for step in range(1, P) if w < pieces or step > r]
+def zigzag_fetch_plan(P, r, pieces, c, grouped=False):
+    """The launches of ring rank r behind step 0 when the K/V arrive through ZigzagKVFetch: (wave, first step, last step,
+    all_rows, final_end) in issue order; a launch reads the wave's piece of the ring ranks r - first ... r - last.
+    WAVE-major: whatever needs only the waves that have landed runs before the compute stream waits for the next one
+    (step-major, rank 0 would sit behind the last wave from its first step on while the front-half launches of its other
+    steps were ready).  Steps s <= r read the front waves with every q row (zigzag_ring_flash_attn.py:54-58), steps s > r
+    read all waves with q[c:] (:59-67; final_end then counts rows of q[c:]).  `grouped` (batch 1: the pieces of a wave
+    lie one behind the other): the steps of a wave that share a query range are ONE launch -- at most two per wave
+    instead of P - 1, each with one merge epilogue.  Rows are emitted in 16 bits by the LAST launch that touches them:
+    rows [0,c) by the last all-rows launch, rows [c,2c) by the last launch of all (pure schedule logic;
+    tests/test_host_api.py)."""
+    launches = []
+    for w in range(2 * pieces):
+        if grouped:
+            if w < pieces and r >= 1:
+                launches.append((w, 1, r, True))
+            if r < P - 1:
+                launches.append((w, r + 1, P - 1, False))
+        else:
+            launches += [(w, step, step, step <= r) for step in range(1, P) if w < pieces or step > r]
     last_any = len(launches) - 1
-    last_all_rows = max((i for i, l in enumerate(launches) if l[2]), default=-1)
+    last_all_rows = max((i for i, l in enumerate(launches) if l[3]), default=-1)
     plan = []
-    for i, (w, step, all_rows) in enumerate(launches):
+    for i, (w, lo, hi, all_rows) in enumerate(launches):
         if all_rows:
             fe = 2 * c if i == last_any else (c if i == last_all_rows else 0)
         else:
             fe = c if i == last_any else 0
-        plan.append((w, step, all_rows, fe))
+        plan.append((w, lo, hi, all_rows, fe))
     return plan
 
 
@@ -113,8 +124,8 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
         c = S2 // 2
         with ZigzagKVFetch(process_group, k, v, zigzag_fetch_pieces(k)) as fetch:
             zigzag_fwd_step(be, r, P, 0, q, k, v, softmax_scale, lse, out, acc)
-            for w, step, all_rows, fe in zigzag_fetch_plan(P, r, fetch.pieces, c):
-                kp, vp = fetch.get(w, step)
+            for w, lo, hi, all_rows, fe in zigzag_fetch_plan(P, r, fetch.pieces, c, fetch.grouped):
+                kp, vp = fetch.get_range(w, lo, hi) if fetch.grouped else fetch.get(w, lo)
                 if all_rows:
                     be.fwd(q, kp, vp, softmax_scale, False, lse, out, acc, True, 0, fe)
                 else:

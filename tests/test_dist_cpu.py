@@ -94,15 +94,17 @@ def test_zigzag_schedule_block_shapes(pieces, monkeypatch):
     for r in range(g.ws):
         assert_close(res[r]["out"], g.shard(full, r), *[t / 2 for t in TOL[g.dtype]["out"]], f"pieces {pieces} rank {r}")
         fwd = [x for x in res[r]["calls"] if x[0] == "fwd"]
-        # step 0, then per wave: steps <= r read the front waves with every q row, steps > r read all waves with q[c:]
-        assert len(fwd) == 1 + W * (g.rd - 1) + W * (g.rd - 1 - r)
+        # step 0, then per wave (batch 1: the pieces of a wave's source ranks lie one behind the other and the steps
+        # that share a query range are ONE launch): every q row x steps 1..r (front waves), q[c:] x steps r+1..P-1
+        assert len(fwd) == 1 + W * (r >= 1) + 2 * W * (r < g.rd - 1)
         _, qs, ks, causal, merge_in, fb, fe = fwd[0]
         assert causal and not merge_in and qs[1] == ks[1] == 2 * c
         assert sum(x[1][1] * x[2][1] for x in fwd[1:]) == (g.rd - 1) * 2 * c * c
         assert all(not x[3] and x[4] for x in fwd[1:])                      # later launches: full blocks, merged in
         key_rows = [x[2][1] for x in fwd[1:]]                               # wave-major: piece sizes never interleave
         cuts = [(i + 1) * c // W - i * c // W for i in range(W)]
-        want = [n for n in cuts for _ in range(g.rd - 1)] + [n for n in cuts for _ in range(g.rd - 1 - r)]
+        per_wave = lambda n, back: ([n * r] if (r >= 1 and not back) else []) + ([n * (g.rd - 1 - r)] if r < g.rd - 1 else [])
+        want = [x for n in cuts for x in per_wave(n, False)] + [x for n in cuts for x in per_wave(n, True)]
         assert key_rows == want
         done = np.zeros(2 * c, bool)                                        # rows already emitted in 16 bits
         for _, qs, ks, causal, merge_in, fb, fe in fwd:
@@ -429,3 +431,11 @@ def test_direct_dkdv_return_packed_rings(path, monkeypatch):
     for r in range(g.ws):
         for key in ("out", "lse", "dq", "dk", "dv"):
             assert np.array_equal(direct[r][key], relay[r][key]), f"{g.name} {key} rank {r}"
+
+
+@pytest.mark.parametrize("pieces", [2, 3])
+def test_zigzag_fetch_row_ranges_at_batch_2(pieces, monkeypatch):
+    """Batch 2: a wave's pieces are separate buffers (a row range of a batched buffer is not contiguous), one launch
+    per source rank -- the other form of the plan -- with 2 and 3 row ranges per K/V half, against exact attention."""
+    monkeypatch.setenv("USP_ZZ_PIECES", str(pieces))
+    assert all(run_distributed(_async_worker, 4, 1, 4, "zigzag", 4, 2))

@@ -256,9 +256,10 @@ def test_item_deal_is_a_balanced_bijection(tmp_path):
 
 
 def test_zigzag_fetch_plan_and_wave_matching():
-    """Pure schedule logic of the zigzag mesh fetch for every ring degree 3..16, rank and piece count 1..4:
-    * plan: launches come wave by wave; the score entries per step add up to the reference's 2 c^2; every q row is
-      emitted exactly once, by the LAST launch that touches it (a later merge would read a stale running output);
+    """Pure schedule logic of the zigzag mesh fetch for every ring degree 3..16, rank, piece count 1..4, one launch per
+    source rank or one per query range (batch 1):
+    * plan: launches come wave by wave; the score entries per source rank add up to the reference's 2 c^2; every q row
+      is emitted exactly once, by the LAST launch that touches it (a later merge would read a stale running output);
     * waves: what rank a posts as sends to b in a wave is what b posts as receives from a (a grouped send/recv call
       that does not pair up hangs RCCL), and no rank posts an empty call."""
     from yunchang_amd.ring.utils import zigzag_wave_steps
@@ -268,24 +269,29 @@ def test_zigzag_fetch_plan_and_wave_matching():
         for W in (1, 2, 3, 4):
             cuts = [(i + 1) * c // W - i * c // W for i in range(W)]
             for r in range(P):
-                plan = zigzag_fetch_plan(P, r, W, c)
-                assert [w for w, *_ in plan] == sorted(w for w, *_ in plan)                  # wave-major
-                assert len(plan) == W * (P - 1) + W * (P - 1 - r)
-                per_step = {}
-                done = [c if r == 0 else 0, 0]        # rows emitted so far: [front rows, back rows]; step 0 emits the front rows of rank 0
-                for w, step, all_rows, fe in plan:
-                    assert 1 <= step < P and (w < W or step > r) and all_rows == (step <= r)
-                    per_step[step] = per_step.get(step, 0) + (2 * c if all_rows else c) * cuts[w % W]
-                    if all_rows:
-                        assert done == [0, 0], "touches rows that are final"
-                        assert fe in (0, c, 2 * c)
-                        done[0] += min(fe, c); done[1] += max(fe - c, 0)
+                for grouped in (False, True):
+                    plan = zigzag_fetch_plan(P, r, W, c, grouped)
+                    assert [w for w, *_ in plan] == sorted(w for w, *_ in plan)                  # wave-major
+                    if grouped:        # at most two launches per wave: every q row x steps 1..r, q[c:] x steps r+1..P-1
+                        assert len(plan) == W * (r >= 1) + 2 * W * (r < P - 1)
                     else:
-                        assert done[1] == 0, "touches back rows that are final"
-                        assert fe in (0, c)
-                        done[1] += fe
-                assert done == [c, c]
-                assert all(n == 2 * c * c for n in per_step.values()) and len(per_step) == P - 1
+                        assert len(plan) == W * (P - 1) + W * (P - 1 - r)
+                    per_step = {}
+                    done = [c if r == 0 else 0, 0]        # rows emitted so far [front, back]; step 0 emits rank 0's front rows
+                    for w, lo, hi, all_rows, fe in plan:
+                        assert 1 <= lo <= hi < P and (w < W or lo > r) and all_rows == (hi <= r) and (all_rows or lo > r)
+                        for step in range(lo, hi + 1):
+                            per_step[step] = per_step.get(step, 0) + (2 * c if all_rows else c) * cuts[w % W]
+                        if all_rows:
+                            assert done == [0, 0], "touches rows that are final"
+                            assert fe in (0, c, 2 * c)
+                            done[0] += min(fe, c); done[1] += max(fe - c, 0)
+                        else:
+                            assert done[1] == 0, "touches back rows that are final"
+                            assert fe in (0, c)
+                            done[1] += fe
+                    assert done == [c, c]
+                    assert all(n == 2 * c * c for n in per_step.values()) and len(per_step) == P - 1
             # grouped calls pair up: sends of a to b in wave w == receives b expects from a in wave w
             for front in (True, False):
                 sends = {(a, (a + s) % P) for a in range(P) for s in zigzag_wave_steps(P, a, front)[0]}

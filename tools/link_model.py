@@ -59,36 +59,44 @@ def main():
         t = max(t, s * whole) + 2 * half
     print("   hop-by-hop relay (reference order):  %.2f ms per iteration" % t)
     print("   one-wave mesh fetch:                 %.2f ms (steps 1-3 wait for the whole fetch)" % (max(step0, whole) + 6 * half))
-    def waves(W, order):
+    def waves(W, order, grouped=False):
         """Slowest rank's iteration with 2 W waves (W row ranges per K/V half; wave w lands at (w + 1) / (2 W) of the
         transfer).  order "wave": every launch that needs only the landed waves first (what the package issues);
-        "step": a step's launches together (round 2's first form: rank 0 waits for the LAST wave at its first step)."""
+        "step": a step's launches together (round 2's first form: rank 0 waits for the LAST wave at its first step).
+        grouped (batch 1): the source ranks of a wave that share a query range are ONE launch, one merge epilogue."""
+        # every q row x piece, or q[c:] x piece; each launch pays its own merge epilogue (read + write of the fp32
+        # running output of its q rows), which the measured (half) step time holds once.  Measured on MI355X
+        # (`kbench pieces`, profiles/r02_kbench_pieces*.log): +16.4 us per extra q[c:] launch, +39-41 us per extra
+        # all-rows launch at this shape
+        m_all, m_back = 0.040, 0.0165
         worst = 0.0
         for r in range(4):
             land = [(w + 1) * whole / (2 * W) for w in range(2 * W)]
-            # every q row x piece, or q[c:] x piece; each launch pays its own merge epilogue (read + write of the fp32
-            # running output of its q rows), which the measured (half) step time holds once.  Measured on MI355X
-            # (`kbench pieces`, profiles/r02_kbench_pieces*.log): +16.4 us per extra q[c:] launch, +39-41 us per extra
-            # all-rows launch at this shape
-            def cost(w, s):
-                base, merge = (2 * half, 0.040) if (w < W and s <= r) else (half, 0.0165)
-                return (base - merge) / W + merge
             reads = lambda w, s: w < W or s > r
-            if order == "wave":
-                seq = [(w, s) for w in range(2 * W) for s in (1, 2, 3) if reads(w, s)]
+            if grouped:      # (wave, [steps]) launches: steps 1..r with every q row (front waves), steps r+1..3 with q[c:]
+                seq = []
+                for w in range(2 * W):
+                    if w < W and r >= 1:
+                        seq.append((w, list(range(1, r + 1)), True))
+                    if r < 3:
+                        seq.append((w, list(range(r + 1, 4)), False))
+            elif order == "wave":
+                seq = [(w, [s], s <= r) for w in range(2 * W) for s in (1, 2, 3) if reads(w, s)]
             else:
-                seq = [(w, s) for s in (1, 2, 3) for w in range(2 * W) if reads(w, s)]
+                seq = [(w, [s], s <= r) for s in (1, 2, 3) for w in range(2 * W) if reads(w, s)]
             t = step0
-            for w, s in seq:
-                t = max(t, land[w]) + cost(w, s)
+            for w, steps, all_rows in seq:
+                base, merge = (2 * half, m_all) if all_rows else (half, m_back)
+                t = max(t, land[w]) + len(steps) * (base - merge) / W + merge
             worst = max(worst, t)
         return worst
     print("   two-wave fetch, launches step by step: %.2f ms (slowest rank)" % waves(1, "step"))
-    worst = waves(1, "wave")
-    print("   two-wave fetch, launches wave by wave: %.2f ms (front halves land after %.2f ms)" % (worst, whole / 2))
-    worst = waves(2, "wave")
-    print("   four waves (2 row ranges per half):    %.2f ms   [default at this size; eight waves: %.2f ms]" % (worst, waves(4, "wave")))
-    print("   -> %.0f TFLOP/s on 4 GPUs at the four-wave figure, %.0f with the relay" % (4 * 1.0995 / worst * 1e3, 4 * 1.0995 / (3 * whole + 2 * half) * 1e3))
+    print("   two-wave fetch, launches wave by wave: %.2f ms (front halves land after %.2f ms)" % (waves(1, "wave"), whole / 2))
+    print("   four waves (2 row ranges per half):    %.2f ms   [eight waves: %.2f ms]" % (waves(2, "wave"), waves(4, "wave")))
+    worst = waves(2, "wave", True)
+    print("   four waves, one launch per query range: %.2f ms   [default at this size; two waves %.2f, eight waves %.2f ms]"
+          % (worst, waves(1, "wave", True), waves(4, "wave", True)))
+    print("   -> %.0f TFLOP/s on 4 GPUs at the default, %.0f with the relay" % (4 * 1.0995 / worst * 1e3, 4 * 1.0995 / (3 * whole + 2 * half) * 1e3))
 
     # configs[4]: 8 GPUs, ulysses 2 x ring 4, B1 S65536 H32/4, forward + backward.
     fwd, bwd = 16.7 * 0.29, 16.7 * 0.71
