@@ -16,6 +16,16 @@ import torch
 from .. import _C
 
 
+def kernel_operand(t: torch.Tensor) -> torch.Tensor:
+    """A tensor autograd hands to a backward as-is may be anything -- `out.sum().backward()` delivers an EXPANDED scalar
+    (every stride 0), a slice of a bigger gradient has odd strides.  The kernels want unit head-dim stride and 16-byte
+    multiples elsewhere (flash-attn's `maybe_contiguous`, flash_attn_interface.py, does the same for the reference)."""
+    es = t.element_size()
+    ok = t.stride(-1) == 1 and all(t.shape[d] == 1 or (t.stride(d) * es) % 16 == 0 for d in range(t.dim() - 1)) \
+        and (t.storage_offset() * es) % 16 == 0
+    return t if ok else t.contiguous()
+
+
 class HipBlockBackend:
     """The device backend: thin adapter over the C ABI (include/usp_hip.h).  Immutable: `interleave` is fixed
     at construction, so concurrent callers (the autograd thread running one layer's backward while the main
@@ -162,6 +172,7 @@ class _HipAttnFunc(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, softmax_scale, causal, return_lse):
         scale = _default_scale(q, softmax_scale)
+        q, k, v = kernel_operand(q), kernel_operand(k), kernel_operand(v)
         out, lse = hip_attn_forward(q, k, v, softmax_scale=scale, causal=causal)
         ctx.save_for_backward(q, k, v, out, lse)
         ctx.scale, ctx.causal = scale, bool(causal)
@@ -174,7 +185,7 @@ class _HipAttnFunc(torch.autograd.Function):
     def backward(ctx, dout, *_):
         q, k, v, out, lse = ctx.saved_tensors
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        hip_attn_backward(dout, q, k, v, out, lse, dq, dk, dv, 0.0, ctx.scale, ctx.causal)
+        hip_attn_backward(kernel_operand(dout), q, k, v, out, lse, dq, dk, dv, 0.0, ctx.scale, ctx.causal)
         return dq, dk, dv, None, None, None
 
 

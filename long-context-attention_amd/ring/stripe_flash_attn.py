@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 
 from ..kernels import AttnType
-from ..kernels.attention import get_block_backend
+from ..kernels.attention import get_block_backend, kernel_operand
 from .utils import FULL, KVRelay, final_grads, travel_dkdv
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
@@ -107,6 +107,7 @@ class StripeFlashAttnFunc(torch.autograd.Function):
         if softmax_scale is None:
             softmax_scale = q.shape[-1] ** (-0.5)
         assert alibi_slopes is None
+        q, k, v = kernel_operand(q), kernel_operand(k), kernel_operand(v)     # any view a caller holds (maybe_contiguous)
         _check_hot_path_args(dropout_p, window_size, softcap)
         out, softmax_lse = stripe_flash_attn_forward(
             group, q, k, v, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
@@ -126,6 +127,7 @@ class StripeFlashAttnFunc(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, *args):
+        dout = kernel_operand(dout)
         q, k, v, out, softmax_lse = ctx.saved_tensors
         dq, dk, dv = stripe_flash_attn_backward(
             ctx.group, dout, q, k, v, out, softmax_lse, softmax_scale=ctx.softmax_scale,

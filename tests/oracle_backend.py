@@ -15,6 +15,20 @@ def _put(dst, arr):
     dst.copy_(torch.from_numpy(np.ascontiguousarray(arr)).to(dst.dtype))
 
 
+def _operand(t, what, ptr_align=16, stride_align_bytes=16):
+    """The operand constraints of the device kernels (csrc/usp_flash_fwd.hip:tensor16_ok, usp_flash_bwd.hip): unit
+    head-dim stride, pointer and every other stride a multiple of 16 bytes (8 for 16-bit outputs).  Asserted here so
+    that the CPU orchestration tests fail where the HIP path would return USP_EUNSUPPORTED."""
+    if t is None:
+        return
+    es = t.element_size()
+    assert t.stride(-1) == 1, f"{what}: head-dim stride {t.stride(-1)}"
+    assert (t.storage_offset() * es) % ptr_align == 0, f"{what}: view starts {t.storage_offset() * es} bytes into its buffer"
+    for d in range(t.dim() - 1):
+        assert t.shape[d] == 1 or (t.stride(d) * es) % stride_align_bytes == 0, \
+            f"{what}: stride {t.stride(d)} of dim {d} is not a multiple of {stride_align_bytes} bytes"
+
+
 class OracleBlockBackend:
     name = "oracle"
 
@@ -25,6 +39,10 @@ class OracleBlockBackend:
             final_begin=0, final_end=None):
         Sq = q.shape[1]
         fe = Sq if final_end is None else final_end
+        for t, what in ((q, "q"), (k, "k"), (v, "v"), (acc, "acc")):
+            _operand(t, what)
+        _operand(out, "out", 8, 8)
+        assert lse.stride(-1) == 1 or lse.shape[-1] == 1, "lse needs unit stride along the sequence"
         self.calls.append(("fwd", tuple(q.shape), tuple(k.shape), bool(causal), bool(merge_in),
                            final_begin, fe))
         bo, bl = O.block_fwd(_np(q), _np(k), _np(v), softmax_scale, causal)      # (B,Sq,H,D), (B,H,Sq)
@@ -47,6 +65,10 @@ class OracleBlockBackend:
 
     def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
             accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None):
+        for t, what in ((dout, "dout"), (q, "q"), (k, "k"), (v, "v"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+            _operand(t, what)
+        for t, what in ((dq16, "dq16"), (dk16, "dk16"), (dv16, "dv16")):
+            _operand(t, what, 8, 8)
         self.calls.append(("bwd", tuple(q.shape), tuple(k.shape), bool(causal)))
         # block_bwd derives delta from `out`; feed it an `out` whose rowsum(dout*out) equals the
         # supplied delta is not possible in general, so restate with delta directly:

@@ -439,3 +439,45 @@ def test_zigzag_fetch_row_ranges_at_batch_2(pieces, monkeypatch):
     per source rank -- the other form of the plan -- with 2 and 3 row ranges per K/V half, against exact attention."""
     monkeypatch.setenv("USP_ZZ_PIECES", str(pieces))
     assert all(run_distributed(_async_worker, 4, 1, 4, "zigzag", 4, 2))
+
+
+def _odd_views_worker(rank, ws):
+    """What autograd and callers may hand the ring: an EXPANDED gradient (`out.sum().backward()`: every stride 0) and
+    q/k/v views with a non-unit head-dim stride.  The device kernels take neither (unit head-dim stride, 16-byte
+    multiples elsewhere -- asserted by the test backend like the C side does); the functions normalise them like
+    flash-attn's maybe_contiguous does for the reference."""
+    import torch.distributed as dist
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    from oracle import usp_oracle as O
+    set_block_backend(OracleBlockBackend())
+    Y.set_seq_parallel_pg(1, ws, rank, ws)
+    torch.manual_seed(3)
+    B, S, H, D = 1, 64 * ws, 2, 32
+    glob = [torch.randn(B, S, H, D).to(torch.bfloat16) for _ in range(3)]
+    full, _ = O.attention_ref(*(t.float().numpy().astype(np.float64) for t in glob), causal=True)
+    ok = True
+    for impl, fn in (("zigzag", Y.zigzag_ring_flash_attn_func), ("basic", Y.ring_flash_attn_func),
+                     ("strip", Y.stripe_flash_attn_func)):
+        ext = Y.EXTRACT_FUNC_DICT[impl]
+        wide = []
+        for t in glob:                                  # the local shard lives in every other column of a wider tensor
+            loc = ext(t, rank, world_size=ws, rd=ws, ud=1)
+            w = torch.zeros(loc.shape[:-1] + (2 * D,), dtype=loc.dtype)
+            w[..., ::2] = loc
+            wide.append(w.requires_grad_(True))
+        q, k, v = (w[..., ::2] for w in wide)
+        assert q.stride(-1) == 2
+        out = fn(q, k, v, causal=True, group=Y.PROCESS_GROUP.RING_PG)
+        out.float().sum().backward()                    # an expanded gradient reaches the ring backward
+        want = ext(torch.from_numpy(full), rank, world_size=ws, rd=ws, ud=1).float()
+        ok = ok and torch.allclose(out.detach().float(), want, atol=2e-2, rtol=2e-2)
+        for w in wide:
+            ok = ok and w.grad is not None and bool(torch.isfinite(w.grad.float()).all()) and \
+                bool((w.grad[..., 1::2] == 0).all()) and bool((w.grad[..., ::2] != 0).any())
+    return ok
+
+
+def test_expanded_gradients_and_strided_views_are_normalised():
+    assert all(run_distributed(_odd_views_worker, 2))

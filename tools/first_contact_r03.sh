@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/first_contact
 mkdir -p $OUT
 cd $R
 python -m pytest tests -m gpu -x -q                                            > $OUT/1_gpu_suite.log 2>&1; echo "1 suite: $?"
-USP_TEST_STAGED=1 python -m pytest tests/test_gpu_multiproc.py tests/test_gpu_parity.py -k "direct_dkdv or k_split" -x -q > $OUT/2_staged.log 2>&1; echo "2 staged: $?"
+USP_TEST_STAGED=1 python -m pytest tests/test_gpu_multiproc.py tests/test_gpu_parity.py -k "direct_dkdv or k_split or expanded_gradient" -x -q > $OUT/2_staged.log 2>&1; echo "2 staged: $?"
 USP_FWD_KSPLIT=auto python -m pytest tests -m gpu -x -q -k "not fuzz"          > $OUT/2b_suite_ksplit_auto.log 2>&1; echo "2b suite with the K split policy on: $?"
 ./long-context-attention_amd/kbench suite                                      > $OUT/2c_kbench_suite.log 2>&1; echo "2c native suite (incl. ksplit): $?"
 for w in 2 3; do
