@@ -61,6 +61,8 @@ class OracleBlockBackend:
             _put(acc[:, fe:], bo[:, fe:])
 
     def delta(self, dout, out, delta):
+        _operand(dout, "dout"); _operand(out, "out")
+        assert delta.stride(-1) == 1 or delta.shape[-1] == 1
         _put(delta, np.einsum("bshd,bshd->bhs", _np(dout), _np(out)))
 
     def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
