@@ -39,6 +39,11 @@ def _copy_rows(dst: Tensor, src: Tensor, row_elems: int, sizes, dst_strides, src
         get_block_backend().copy_rows(dst, src, row_elems * es, list(sizes),
                                       [s * es for s in dst_strides], [s * es for s in src_strides])
     else:
+        # host tensors (gloo orchestration tests): hold the copy to what usp_copy_rows takes (include/usp_hip.h: row
+        # bytes, every stride and both pointers multiples of 16), so a layout the device path would refuse fails here too
+        assert (row_elems * es) % 16 == 0 and all((st * es) % 16 == 0 for st in list(dst_strides) + list(src_strides)) \
+            and (dst.storage_offset() * es) % 16 == 0 and (src.storage_offset() * es) % 16 == 0, \
+            f"usp_copy_rows needs 16-byte rows / strides / pointers: row {row_elems * es} B, strides {dst_strides} {src_strides}"
         d = torch.as_strided(dst, list(sizes) + [row_elems], list(dst_strides) + [1],
                              dst.storage_offset())
         s = torch.as_strided(src, list(sizes) + [row_elems], list(src_strides) + [1],
