@@ -43,6 +43,15 @@ class OracleBlockBackend:
             _operand(t, what)
         _operand(out, "out", 8, 8)
         assert lse.stride(-1) == 1 or lse.shape[-1] == 1, "lse needs unit stride along the sequence"
+        # what the C side checks before a launch (usp_flash_fwd): shapes, head dims, dtypes
+        B, _, Hq, D = q.shape
+        assert D in (32, 64, 128) and k.shape == v.shape and k.shape[0] == B and k.shape[3] == D and Hq % k.shape[2] == 0
+        assert q.dtype in (torch.bfloat16, torch.float16) and k.dtype == q.dtype == v.dtype
+        assert lse.dtype == torch.float32 and tuple(lse.shape) == (B, Hq, Sq)
+        assert out is None or (out.dtype == q.dtype and out.shape == q.shape)
+        assert acc is None or (acc.dtype == torch.float32 and acc.shape == q.shape)
+        assert (fe <= final_begin or out is not None) and ((final_begin <= 0 and fe >= Sq) or acc is not None) \
+            and (not merge_in or acc is not None), "final rows need `out`, the others (and a merge) need `acc`"
         self.calls.append(("fwd", tuple(q.shape), tuple(k.shape), bool(causal), bool(merge_in),
                            final_begin, fe))
         bo, bl = O.block_fwd(_np(q), _np(k), _np(v), softmax_scale, causal)      # (B,Sq,H,D), (B,H,Sq)
@@ -71,6 +80,12 @@ class OracleBlockBackend:
             _operand(t, what)
         for t, what in ((dq16, "dq16"), (dk16, "dk16"), (dv16, "dv16")):
             _operand(t, what, 8, 8)
+        assert q.shape[3] in (32, 64, 128) and q.dtype in (torch.bfloat16, torch.float16) and dout.dtype == q.dtype
+        assert lse.dtype == torch.float32 and delta.dtype == torch.float32 and lse.shape == delta.shape
+        for g32, g16, ref, nm in ((dq, dq16, q, "dq"), (dk, dk16, k, "dk"), (dv, dv16, v, "dv")):
+            assert g32 is not None or g16 is not None, f"{nm}: no destination"
+            assert g32 is None or (g32.dtype == torch.float32 and g32.shape == ref.shape), nm
+            assert g16 is None or (g16.dtype == q.dtype and g16.shape == ref.shape), nm
         self.calls.append(("bwd", tuple(q.shape), tuple(k.shape), bool(causal)))
         # block_bwd derives delta from `out`; feed it an `out` whose rowsum(dout*out) equals the
         # supplied delta is not possible in general, so restate with delta directly:
