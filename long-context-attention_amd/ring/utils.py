@@ -275,7 +275,7 @@ class ZigzagKVFetch:
         # At batch 1 each piece is a contiguous row range of it (what a receive needs), so the pieces of several
         # source ranks can be handed to ONE attention launch as one K/V (`get_range`): one merge epilogue per wave and
         # query range instead of one per source rank (+16 / +40 us each at BASELINE's 4-GPU shape, kbench pieces).
-        self.grouped = k.shape[0] == 1
+        self.grouped = k.shape[0] == 1 and os.environ.get("USP_ZZ_GROUP", "1") != "0"      # USP_ZZ_GROUP=0: A/B switch
 
         def make():
             if not self.grouped:

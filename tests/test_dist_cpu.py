@@ -481,3 +481,15 @@ def _odd_views_worker(rank, ws):
 
 def test_expanded_gradients_and_strided_views_are_normalised():
     assert all(run_distributed(_odd_views_worker, 2))
+
+
+def test_zigzag_fetch_ungrouped_switch_gives_the_same_result(monkeypatch):
+    """USP_ZZ_GROUP=0 (one launch per source rank also at batch 1: the A/B switch for the grouped launches) against the
+    reference's own run of the 4-GPU grid."""
+    monkeypatch.setenv("USP_ZZ_GROUP", "0")
+    path = [f for f in MULTI if "c4_w4_u1r4" in f][0]
+    g = Golden(path)
+    res = run_distributed(_usp_worker, g.ws, path, True)
+    for r in range(g.ws):
+        assert_close(res[r]["out"], g.out[r], *TOL[g.dtype]["out"], f"out rank {r}")
+        assert len([x for x in res[r]["calls"] if x[0] == "fwd"]) == 1 + (g.rd - 1) + (g.rd - 1 - r)
