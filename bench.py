@@ -144,9 +144,10 @@ def _kernel_inputs(B, S, Hq, Hkv, D, dev, seed=1):
     return q, k, v, do
 
 
-def _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, iters):
+def _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, iters, keep=False):
     """Forward kernel and the backward's kernels (delta + dK/dV [+ head reduce] + dQ) timed alone through the
-    C ABI on N(0,1) data; algorithmic TFLOP/s (forward 4 B Hq S^2 D / 2, backward 2.5x)."""
+    C ABI on N(0,1) data; algorithmic TFLOP/s (forward 4 B Hq S^2 D / 2, backward 2.5x).  `keep`: also return the
+    inputs and results (for sampled_parity)."""
     from yunchang_amd import _C
     q, k, v, do = _kernel_inputs(B, S, Hq, Hkv, D, dev)
     out = torch.empty_like(q)
@@ -163,20 +164,73 @@ def _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, iters):
     ms_b = _time_events(bwd, max(2, iters // 2), warm=2)
     F = fwd_flops(B, Hq, S, D)
     tf = lambda flops, ms: flops / (ms * 1e-3) / 1e12
-    return dict(fwd_ms=round(ms_f, 4), bwd_ms=round(ms_b, 4), fwd=tf(F, ms_f), bwd=tf(2.5 * F, ms_b),
-                fwd_bwd=tf(3.5 * F, ms_f + ms_b))
+    res = dict(fwd_ms=round(ms_f, 4), bwd_ms=round(ms_b, 4), fwd=tf(F, ms_f), bwd=tf(2.5 * F, ms_b),
+               fwd_bwd=tf(3.5 * F, ms_f + ms_b))
+    if keep:
+        res["tensors"] = dict(q=q, k=k, v=v, do=do, out=out, lse=lse, dq=dq, dk=dk, dv=dv)
+    return res
 
 
-def kernel_roofline(cfg, dev, iters=20):
+def sampled_parity(t, n_rows=8, n_keys=8, seed=0):
+    """Sampled rows / keys of a causal forward + backward (batch 0, first and last query head / KV head) against exact
+    attention in fp64 on the device: out, LSE and dQ of `n_rows` query rows, dK and dV of `n_keys` keys (summed over the
+    GQA group's query heads and over every row that sees the key).  Definitions as the block contract's
+    (yunchang/kernels/attention.py:205-250): delta = rowsum(dO * out) with the 16-bit `out` the backward was given;
+    the key columns take softmax probabilities from the kernel's fp32 LSE, which the row samples check against the
+    exact one.  Size-independent: works at the metric's S = 65536.  Returns max-abs errors."""
+    q, k, v, do, out, lse, dq, dk, dv = (t[n] for n in ("q", "k", "v", "do", "out", "lse", "dq", "dk", "dv"))
+    B, S, Hq, D = q.shape
+    Hkv = k.shape[2]
+    G = Hq // Hkv
+    scale = D ** -0.5
+    rs = np.random.RandomState(seed)
+    rows = sorted(r for r in {0, 255, 256, S // 2 - 1, S // 2, S - 1, *rs.randint(0, S, size=n_rows).tolist()} if 0 <= r < S)
+    keys = sorted(j for j in {0, 127, 128, S - 1, *rs.randint(0, S, size=n_keys).tolist()} if 0 <= j < S)
+    err = dict(out=0.0, lse=0.0, dq=0.0, dk=0.0, dv=0.0)
+    up = lambda name, a, b: err.__setitem__(name, max(err[name], float((a.double() - b).abs().max())))
+    for h in sorted({0, Hq - 1}):
+        kd, vd = k[0, :, h // G].double(), v[0, :, h // G].double()
+        for i in rows:
+            sc = (kd[:i + 1] @ q[0, i, h].double()) * scale
+            l_ref = torch.logsumexp(sc, 0)
+            p = torch.exp(sc - l_ref)
+            up("out", out[0, i, h], p @ vd[:i + 1])
+            up("lse", lse[0, h, i], l_ref)
+            doi = do[0, i, h].double()
+            dp = vd[:i + 1] @ doi
+            delta = (doi * out[0, i, h].double()).sum()
+            up("dq", dq[0, i, h], ((p * (dp - delta)) @ kd[:i + 1]) * scale)
+    for hk in sorted({0, Hkv - 1}):
+        kd, vd = k[0, :, hk].double(), v[0, :, hk].double()
+        for j in keys:
+            rdk = torch.zeros(D, dtype=torch.float64, device=q.device)
+            rdv = torch.zeros_like(rdk)
+            for g in range(G):
+                h = hk * G + g
+                qi, doi = q[0, j:, h].double(), do[0, j:, h].double()
+                p = torch.exp((qi @ kd[j]) * scale - lse[0, h, j:].double())
+                rdv += p @ doi
+                ds = p * (doi @ vd[j] - (doi * out[0, j:, h].double()).sum(-1))
+                rdk += (ds @ qi) * scale
+            up("dk", dk[0, j, hk], rdk)
+            up("dv", dv[0, j, hk], rdv)
+    return {"max_abs_err": {n: round(e, 6) for n, e in err.items()}, "rows": len(rows), "keys": len(keys),
+            "heads": sorted({0, Hq - 1}), "kv_heads": sorted({0, Hkv - 1}),
+            "truth": "exact causal attention and its gradients in fp64 on the sampled rows / key columns"}
+
+
+def kernel_roofline(cfg, dev, traffic, iters=20):
     """Dominant kernel of the N=1 workload (flash_fwd_kernel) timed alone, live, with device events on the stream
-    the kernel is launched on, plus the forward+backward kernels of the same shape."""
+    the kernel is launched on, plus the forward+backward kernels of the same shape.  `traffic`: pmc_traffic(), taken
+    by the caller BEFORE any device work -- it may disassemble the library (seconds of host-only time), and nothing
+    host-only may sit between this function's kernels and the timed region (the part would clock down again)."""
     B, S, Hq, Hkv, D = cfg["B"], cfg["S"], cfg["Hq"], cfg["Hkv"], cfg["D"]
     _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, 300)                # ~0.5 s of work first: measure at sustained clocks,
     t = _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, iters)          # not on the DVFS ramp of a device that was idle
     frac = lambda x: round(x / PEAK_BF16_TFLOPS, 4)
     roof = {"bound": "mfma", "kernel": "usp::flash_fwd_kernel<128,bf16,causal>", "achieved": round(t["fwd"], 1),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": frac(t["fwd"]),
-            "kernel_ms": t["fwd_ms"], "traffic": pmc_traffic(),
+            "kernel_ms": t["fwd_ms"], "traffic": traffic,
             "fwd_bwd": {"kernels": "flash_fwd_kernel + delta_kernel + flash_bwd_dkdv_kernel + flash_bwd_kernel<dQ>",
                         "shape_BSHD": [B, S, Hq, D], "kv_heads": Hkv, "fwd_ms": t["fwd_ms"], "bwd_ms": t["bwd_ms"],
                         "bwd_achieved": round(t["bwd"], 1), "bwd_frac": frac(t["bwd"]),
@@ -192,12 +246,16 @@ def seq64k_single_gpu(dev):
     roof = {}
     try:
         c5 = WORKLOADS[8]
-        t64 = _fwd_bwd_kernels(c5["B"], c5["S"], c5["Hq"], c5["Hkv"], c5["D"], dev, 3)
+        t64 = _fwd_bwd_kernels(c5["B"], c5["S"], c5["Hq"], c5["Hkv"], c5["D"], dev, 3, keep=True)
+        try:                                                 # parity AT the metric's size (sampled: fp64 rows / key columns)
+            parity = sampled_parity(t64.pop("tensors"))
+        except Exception as e:
+            parity = {"error": repr(e)[:200]}
         roof["seq64k_single_gpu"] = {
             "shape_BSHD": [c5["B"], c5["S"], c5["Hq"], c5["D"]], "kv_heads": c5["Hkv"], "pass": "fwd+bwd, causal",
             "fwd_ms": t64["fwd_ms"], "bwd_ms": t64["bwd_ms"], "iter_ms": round(t64["fwd_ms"] + t64["bwd_ms"], 3),
             "achieved": round(t64["fwd_bwd"], 1), "frac": frac(t64["fwd_bwd"]),
-            "fwd_achieved": round(t64["fwd"], 1), "bwd_achieved": round(t64["bwd"], 1)}
+            "fwd_achieved": round(t64["fwd"], 1), "bwd_achieved": round(t64["bwd"], 1), "sampled_parity": parity}
     except Exception as e:                                   # informative entry: never kill the measurement
         roof["seq64k_single_gpu"] = {"error": repr(e)[:200]}
     return roof["seq64k_single_gpu"]
@@ -397,23 +455,43 @@ def _sync(dev):
         torch.cuda.synchronize()
 
 
-def timed(step, steps, ws, dev):
-    """K steps bracketed by barrier + synchronize on both sides; max over ranks; seconds per step."""
+def timed(step, steps, ws, dev, device_ms=None):
+    """K steps bracketed by barrier + synchronize on both sides; max over ranks; seconds per step (host clock).
+    `device_ms`: a list that receives this rank's per-step time between two device events recorded on the compute
+    stream around the same K steps (diagnostic: host clock minus device clock = launch latency of the first step +
+    the wake-up of the final synchronize)."""
     _sync(dev)
     barrier(ws)
     _sync(dev)
+    ev = None
+    if device_ms is not None and dev.type == "cuda":
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
     t0 = time.perf_counter()
+    if ev:
+        ev[0].record()
     for _ in range(steps):
         step()
+    if ev:
+        ev[1].record()
     _sync(dev)
     barrier(ws)
     _sync(dev)
     dt = time.perf_counter() - t0
+    if ev:
+        device_ms.append(ev[0].elapsed_time(ev[1]) / steps)
     if ws > 1:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     return dt / steps
+
+
+def heat_steps(cfg, ws):
+    """Untimed steps in front of the W warm-up steps: ~0.3 s of the step itself (same count on every rank: the step
+    holds collectives), so that W + K steps as short as 5 + 20 = 12 ms do not run on the DVFS ramp of an idle part."""
+    flops = fwd_flops(cfg["B"], cfg["Hq"], cfg["S"], cfg["D"]) * (3.5 if cfg["bwd"] else 1.0)
+    est_s = flops / ws / 0.8e15
+    return int(min(400, max(5, 0.3 / est_s)))
 
 
 class _NoCompute:
@@ -589,31 +667,36 @@ def main(argv=None, dev=None):
             parity_op, parity_rows = (None if parity_op is None else float(pt[0].item())), float(pt[1].item())
     del q, k, v, do, out
 
-    # N = 1: the kernel timings of this workload run BEFORE the timed region.  They keep the GPU busy for ~1 s, so the
-    # W warm-up + K timed steps (which may be as few as 5 + 20 = 13 ms of work) run at sustained clocks instead of
-    # on the DVFS ramp of a cold device, and in the same power state as the kernel they are compared with.
+    # Order of what follows (round 3; the driver's W=5 / K=20 run is 12 ms of device work): everything that is HOST-ONLY
+    # comes first -- the PMC-traffic lookup (it may disassemble the library: seconds) and the collector freeze (a full
+    # collection walks ~170 k torch objects: 40-60 ms, tools/host_cost.py) -- then device work only, back to back:
+    # the kernel timings (N = 1, ~1 s), ~0.3 s of the step itself, the W warm-up steps, the K timed steps.  Round 2 had
+    # the lookup and the freeze BEHIND the kernel timings: the part sat idle for seconds, clocked down, and the driver's
+    # 20 steps read 22 % slower than the kernel they consist of (BENCH_r02.json: 0.5813 vs 0.4768 ms).
+    traffic = pmc_traffic() if (ws == 1 and rank == 0) else None
+    gc.collect()
+    gc.freeze()          # the documented pattern: the collector keeps running, over new objects only
+
     roofline = None
     if ws == 1 and rank == 0:
-        roofline = kernel_roofline(cfg, dev)
-
-    for _ in range(args.warmup):
-        step()
-
-    # Python's cyclic collector: a FULL collection walks every object torch has created (~170 k: 40-60 ms measured on
-    # the N > 1 step, tools/host_cost.py) -- longer than the whole timed region of the short configs, and the N > 1 step
-    # allocates enough containers to trigger one now and then.  Collect once and move what exists to the permanent
-    # generation (the documented gc.freeze() pattern): the collector keeps running, but only over new objects.
-    gc.collect()
-    gc.freeze()
-
-    dt = timed(step, args.steps, ws, dev) * args.steps
-
-    ms = dt / args.steps * 1e3
+        roofline = kernel_roofline(cfg, dev, traffic)
+    n_heat = heat_steps(cfg, ws) if dev.type == "cuda" else 0      # host tensors: the CPU tests drive main()
     flops = fwd_flops(cfg["B"], cfg["Hq"], cfg["S"], cfg["D"]) * (3.5 if cfg["bwd"] else 1.0)
-    value = flops / (ms * 1e-3) / 1e12
 
-    line = None
-    if rank == 0:
+    def measure():
+        """n_heat untimed steps, W warm-up steps, K timed steps, back to back -> (ms per step, device-event ms)."""
+        for _ in range(n_heat):
+            step()
+        for _ in range(args.warmup):
+            step()
+        dms = []
+        sec = timed(step, args.steps, ws, dev, dms)
+        return sec * 1e3, (round(dms[0], 4) if dms else None)
+
+    def make_line(ms, dms, comm_mode):
+        value = flops / (ms * 1e-3) / 1e12
+        if rank != 0:
+            return None
         line = {
             "metric": "attention TFLOP/s (algorithmic, causal) of LongContextAttention ulysses x ring",
             "value": round(value, 2), "unit": "TFLOP/s", "n_gpus": ws, "steps": args.steps,
@@ -624,15 +707,56 @@ def main(argv=None, dev=None):
                        "layout": cfg["impl"], "pass": "fwd+bwd" if cfg["bwd"] else "fwd",
                        "layer": "AsyncLongContextAttention" if args.async_ulysses else "LongContextAttention",
                        "ulysses_exchange": exchange_mode(attn, lq, lk, cfg, ws),
+                       "comm_mode": comm_mode,
                        "tokens_per_gpu": cfg["S"] * cfg["B"] // ws,
                        "assumed": "B=1 and causal=True where BASELINE.json's config string is silent",
-                       "host": "gc.collect() + gc.freeze() in front of the timed region (no full-heap GC pause inside it)"},
+                       "host": f"host-only work (gc.collect + gc.freeze, PMC lookup) first, then device work only: kernel "
+                               f"timings, {n_heat} untimed steps, W warm-up steps, K timed steps"},
+            "ms_per_step_device_events": dms,
             "frac_of_mfma_roofline": round(value / (ws * PEAK_BF16_TFLOPS), 4),
             "parity_max_abs_err_vs_reference_op": parity_op,
             "parity_max_abs_err_vs_fp64_rows": parity_rows,
         }
         if smoke:
             line["smoke"] = f"backend={backend}, all ranks on {dev} -- NOT a measurement"
+        return line
+
+    # A ulysses x ring grid has TWO communicators.  The library's default keeps one of them in flight at a time beside a
+    # ring ("safe": one packed exchange in front of the ring attention, one behind it); USP_PIPELINE_ULYSSES=1 pipelines
+    # the exchange over head groups beside the ring traffic (both communicators in flight, each on its own side stream).
+    # The second mode has never met real multi-GPU RCCL, so the measurement is staged: the safe mode is measured FIRST
+    # and its line is complete; the overlapped mode then runs under a deadline -- if it finishes, the faster of the two
+    # is reported (and named, with the other's figure beside it); if it stalls, rank 0 prints the safe line and every
+    # rank leaves with exit code 0.
+    import yunchang_amd.hybrid.async_attn_layer as AL
+    two_comms = cfg["ud"] > 1 and cfg["rd"] > 1 and not args.async_ulysses and "USP_PIPELINE_ULYSSES" not in os.environ \
+        and "USP_SAFE_COMM" not in os.environ
+    if two_comms:
+        AL._COMM_OVERRIDE.update(safe=True)
+    ms, dms = measure()
+    comm_mode = ("safe: one communicator in flight at a time" if (two_comms or AL.safe_comm()) else
+                 "library default" + (" (USP_PIPELINE_ULYSSES=%s)" % os.environ["USP_PIPELINE_ULYSSES"]
+                                      if "USP_PIPELINE_ULYSSES" in os.environ else ""))
+    line = make_line(ms, dms, comm_mode)
+    if two_comms:
+        safe_ms = ms
+        fallback = _LineOnce(None if line is None else
+                             {**line, "comm_mode_note": "the overlapped mode (USP_PIPELINE_ULYSSES=1) did not finish "
+                                                        "before its deadline; this is the safe mode's measurement"})
+        budget = float(os.environ.get("USP_BENCH_MODE_DEADLINE_S", str(60 + 20 * safe_ms * 1e-3 * (n_heat + args.warmup + args.steps))))
+        with _Deadline(budget, fallback, None):
+            AL._COMM_OVERRIDE.update(safe=False, pipeline="1")
+            ms2, dms2 = measure()
+        if ms2 < ms:
+            ms, dms = ms2, dms2
+            line = make_line(ms, dms, "overlapped: Ulysses exchange pipelined over head groups beside the ring "
+                                      "(USP_PIPELINE_ULYSSES=1), two communicators in flight")
+        else:
+            AL._COMM_OVERRIDE.update(safe=True)
+            AL._COMM_OVERRIDE.pop("pipeline", None)
+        if line is not None:
+            line["comm_modes_ms_per_step"] = {"safe": round(safe_ms, 4), "overlapped": round(ms2, 4)}
+    value = flops / (ms * 1e-3) / 1e12
 
     # The measurement is complete here.  What follows is informative and must never cost the line: the overlap probe
     # re-runs the step with patched transports on every rank, so it runs under a deadline -- if it has not returned

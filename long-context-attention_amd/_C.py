@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import threading
 from typing import Optional
 
 import torch
@@ -152,23 +153,93 @@ def _lse3(t: torch.Tensor):
 _FWD_WS = {}
 
 
+def _parse_ksplit(raw) -> object:
+    """USP_FWD_KSPLIT -> "auto" | 0 | n in 2..8.  Anything else counts as off, with one warning (a typo in an
+    environment variable must not raise on every launch)."""
+    raw = (raw or "auto").strip().lower()
+    if raw in ("auto", "0"):
+        return "auto" if raw == "auto" else 0
+    try:
+        n = int(raw)
+    except ValueError:
+        import warnings
+        warnings.warn(f"USP_FWD_KSPLIT={raw!r} is neither 'auto', 0 nor an integer: the K split stays off")
+        return 0
+    return 0 if n < 2 else min(n, 8)
+
+
+# Read ONCE, at import (a launch does not touch os.environ); set_fwd_ksplit changes it in-process (tests, A/B runs).
+_KSPLIT_MODE = _parse_ksplit(os.environ.get("USP_FWD_KSPLIT"))
+
+
+def set_fwd_ksplit(mode) -> object:
+    """Set the K-split policy of dense forward launches ("auto" | 0 | n); returns the previous one."""
+    global _KSPLIT_MODE
+    prev, _KSPLIT_MODE = _KSPLIT_MODE, _parse_ksplit(str(mode))
+    return prev
+
+
 def fwd_k_splits(B: int, Sq: int, Hq: int, causal: bool) -> int:
-    """How many work items a dense forward launch cuts every query tile's keys into (usp_fwd_args.k_splits).
-    The kernel path is checked and timed natively on MI355X (`kbench ksplit`, profiles/r02_kbench_ksplit*.log: B1 S16384
-    D128 causal, 2 heads 557 -> 936 TFLOP/s at n = 4, 4 heads 798 -> 1070 at n = 2, merge launch included; 8 heads fill
-    the part and gain nothing).  THIS binding's use of it is STAGED -- built after round 2's GPU budget was spent, not
-    yet through the GPU tests -- so it is off unless USP_FWD_KSPLIT is set:
-        USP_FWD_KSPLIT=auto  causal launches of >= 4096 rows with fewer than two 256-row items per CU: n = 2 from 256
-                             items up, 4 below (the measured optima);
-        USP_FWD_KSPLIT=n     n cuts (2..8) for every causal launch with fewer than two 256-row items per CU."""
-    mode = os.environ.get("USP_FWD_KSPLIT", "0") or "0"
+    """How many work items a dense forward launch cuts every query tile's keys into (usp_fwd_args.k_splits).  A causal
+    launch with fewer than two 256-row items per CU lasts as long as its heaviest item; cutting every item's keys into n
+    equal runs (partials + one HBM-bound merge launch) fills the part.  Measured natively on MI355X (`kbench ksplit`,
+    profiles/r02_kbench_ksplit*.log: B1 S16384 D128 causal, 2 heads 557 -> 936 TFLOP/s at n = 4, 4 heads 798 -> 1070 at
+    n = 2, merge launch included; 8 heads fill the part and gain nothing) and, through this binding, by
+    tests/test_gpu_parity.py::test_forward_k_split_through_the_binding.  Policy (USP_FWD_KSPLIT, read at import):
+        auto (default)  causal launches of >= 4096 rows with fewer than two 256-row items per CU: n = 2 from 256 items
+                        up, 4 below (the measured optima);
+        n               n cuts (2..8) for every causal launch with fewer than two 256-row items per CU;
+        0               off."""
+    mode = _KSPLIT_MODE
+    if mode == 0 or not causal:
+        return 0
     items = B * Hq * ((Sq + 255) // 256)
-    if mode == "0" or not causal or items >= 512:
+    if items >= 512:
         return 0
     if mode == "auto":
         return 0 if Sq < 4096 else (2 if items >= 256 else 4)
-    n = int(mode)
-    return 0 if n < 2 else min(n, 8)
+    return mode
+
+
+_TLS = threading.local()      # per-thread cache of filled argument blocks (the autograd thread launches too)
+_ARGS_CACHE_MAX = 64
+
+
+def _strides(t):
+    return None if t is None else t.stride()
+
+
+def _fwd_args(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end, interleave, n):
+    """The filled usp_fwd_args block of a dense launch.  Everything but the seven pointers is a function of
+    (dtype, shapes, strides, flags), and a training loop issues the same few launches over and over: the block is
+    cached per thread under that signature and only the pointers are patched (filling 27 ctypes fields and five
+    usp_tensor structs costs ~35 us of host time per launch, tools/host_step_cpu.py; a hit costs ~8)."""
+    key = (q.dtype, q.shape, q.stride(), k.shape, k.stride(), v.stride(), lse.stride(), _strides(out), _strides(acc),
+           softmax_scale, causal, merge_in, final_begin, final_end, interleave, n)
+    cache = _TLS.__dict__.setdefault("fwd", {})
+    a = cache.get(key)
+    if a is None:
+        B, Sq, Hq, D = q.shape
+        a = UspFwdArgs()
+        a.dtype = dtype_code(q.dtype)
+        a.B, a.Sq, a.Sk, a.Hq, a.Hkv, a.D = B, Sq, k.shape[1], Hq, k.shape[2], D
+        a.causal = 1 if causal else 0
+        a.softmax_scale = float(softmax_scale)
+        a.q, a.k, a.v, a.out, a.acc = _t4(q), _t4(k), _t4(v), _t4(out), _t4(acc)
+        a.lse, a.lse_stride_b, a.lse_stride_h = _lse3(lse)
+        a.merge_in = 1 if merge_in else 0
+        a.final_begin = final_begin
+        a.final_end = Sq if final_end is None else final_end
+        a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
+        a.k_splits = n if n > 1 else 0
+        if len(cache) >= _ARGS_CACHE_MAX:
+            cache.clear()
+        cache[key] = a
+        return a
+    a.q.ptr, a.k.ptr, a.v.ptr, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), lse.data_ptr()
+    a.out.ptr = None if out is None else out.data_ptr()
+    a.acc.ptr = None if acc is None else acc.data_ptr()
+    return a
 
 
 def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=None,
@@ -179,29 +250,20 @@ def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=No
     every query tile into that many work items (None: fwd_k_splits decides; 0 / 1: off)."""
     _require_cuda(q, k, v, lse, out, acc)
     B, Sq, Hq, D = q.shape
-    Sk, Hkv = k.shape[1], k.shape[2]
-    a = UspFwdArgs()
-    a.dtype = dtype_code(q.dtype)
-    a.B, a.Sq, a.Sk, a.Hq, a.Hkv, a.D = B, Sq, Sk, Hq, Hkv, D
-    a.causal = 1 if causal else 0
-    a.softmax_scale = float(softmax_scale)
-    a.q, a.k, a.v, a.out, a.acc = _t4(q), _t4(k), _t4(v), _t4(out), _t4(acc)
-    a.lse, a.lse_stride_b, a.lse_stride_h = _lse3(lse)
-    a.merge_in = 1 if merge_in else 0
-    a.final_begin = final_begin
-    a.final_end = Sq if final_end is None else final_end
-    a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
     n = fwd_k_splits(B, Sq, Hq, causal) if k_splits is None else int(k_splits)
+    a = _fwd_args(q, k, v, softmax_scale, bool(causal), lse, out, acc, bool(merge_in), final_begin, final_end,
+                  bool(interleave), n)
+    L = load()
     if n > 1:
         # scratch for the partial results: one buffer per (device, stream), grown on demand; launches on one stream
         # are ordered, so the buffer is free again when the next launch on that stream starts
-        need = load().usp_flash_fwd_workspace_bytes(ctypes.byref(a), n)
+        need = L.usp_flash_fwd_workspace_bytes(ctypes.byref(a), n)
         key = (q.device.index, torch.cuda.current_stream().cuda_stream)
         ws = _FWD_WS.get(key)
         if ws is None or ws.numel() < need:
             ws = _FWD_WS[key] = torch.empty(need, dtype=torch.uint8, device=q.device)
-        a.k_splits, a.workspace = n, ws.data_ptr()
-    _check(load().usp_flash_fwd(ctypes.byref(a), _stream()), "usp_flash_fwd")
+        a.workspace = ws.data_ptr()
+    _check(L.usp_flash_fwd(ctypes.byref(a), _stream()), "usp_flash_fwd")
 
 
 def _t3(t: Optional[torch.Tensor]) -> UspTensor:

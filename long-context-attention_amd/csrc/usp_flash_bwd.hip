@@ -794,16 +794,26 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
             if (ROLE == 0 && (r & 3) == 0) st4 = stq[r >> 2];
             float val;
             if (ROLE == 0) {
+#ifdef USP_ABLATE_A_NOEXP        // A/B builds (tools/abl_bwd.sh): which role is the straggler of the per-tile barrier?
+              val = __builtin_fmaf(sc[h][r], c, -st4[r & 3]);
+#else
               val = fast_exp2(__builtin_fmaf(sc[h][r], c, -st4[r & 3]));
+#endif
             } else {
+#ifdef USP_ABLATE_B_NOELEM
+              val = sc[h][r];
+#else
               const uint32_t wd = pin[h][r >> 3][(r & 7) >> 1];
               const float pr = (r & 1) ? E::hi(wd) : E::lo(wd);
               val = pr * sc[h][r];
+#endif
             }
             sc[h][r] = val;
             if (r & 1) pk[h][r >> 3][(r & 7) >> 1] = E::pack2(sc[h][r - 1], sc[h][r]);
+#ifndef USP_ABLATE_NOPX
             if (ROLE == 0 && (r & 7) == 7)                        // 8 elements done: hand one k-step of P to B
               *(USP_LDS u32x4*)(pslot + (2 * h + (r >> 3)) * 1024) = pk[h][r >> 3];
+#endif
           };
           auto chain_phase = [&](int h, int vh) {
             u32x4 f[NKT];
@@ -819,8 +829,12 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
             rd(0);
             if (NKT > 1) rd(1);
             if (ROLE == 1) {                                     // fetch A's P of this half early
+#ifdef USP_ABLATE_NOPX
+              pin[h][0] = rf[2 * h]; pin[h][1] = rf[2 * h + 1];
+#else
               pin[h][0] = *(USP_LDS const u32x4*)(pslot + (2 * h) * 1024);
               pin[h][1] = *(USP_LDS const u32x4*)(pslot + (2 * h + 1) * 1024);
+#endif
             }
             if (ROLE == 0 && vh >= 0) load_stats(vh);
             __builtin_amdgcn_sched_barrier(0);
@@ -879,7 +893,9 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
       buf_b = buf_a;
       buf_a = buf_n;
       dma_drain();            // this wave's DMA pieces of the staged tile have landed (usp_common.hpp)
+#ifndef USP_ABLATE_DKDV_NOBAR
       __syncthreads();
+#endif
     }
 
   };

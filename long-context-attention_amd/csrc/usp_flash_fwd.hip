@@ -649,7 +649,11 @@ __global__ __launch_bounds__(256) void split_merge_kernel(const FwdArgsT<true> p
     const int64_t o_idx = (((int64_t)b * p.Sq + s) * p.Hq + h) * D + 4 * c4;
     float* lse_p = p.lse + b * p.lse_sb + h * p.lse_sh + s;
     const int64_t arow = b * p.a_sb + (int64_t)s * p.a_ss + h * p.a_sh + 4 * c4;
-    float mx = p.merge_in ? *lse_p : USP_NEG_INF;
+    // The D/4 lanes of a row all read the running LSE here and lane c4 == 0 stores the new one below: a row's lanes sit
+    // in ONE wavefront (launch_fwd_w asserts 64 % (D/4) == 0 and launches 256-thread blocks), so every load is issued
+    // before the store in program order -- the value is read once, into a register.
+    const float lse_old = p.merge_in ? *lse_p : USP_NEG_INF;
+    float mx = lse_old;
     float l[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(256) void split_merge_kernel(const FwdArgsT<true> p
     float new_lse = USP_NEG_INF;
     if (mx != USP_NEG_INF) {
       float sum = 0.f, w_old = 0.f;
-      if (p.merge_in) { w_old = exp2f((*lse_p - mx) * kLog2e); sum = w_old; }
+      if (p.merge_in) { w_old = exp2f((lse_old - mx) * kLog2e); sum = w_old; }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         l[j] = exp2f((l[j] - mx) * kLog2e);          // 0 for an empty cut (lse = -inf) and for j >= ksplit
@@ -713,6 +717,7 @@ static int launch_fwd_w(FwdArgsT<true> p, bool causal, hipStream_t st) {
       hipLaunchKernelGGL((flash_fwd_kernel<D, DT, false, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, plain);
   }
   if (p.ksplit > 1) {          // same stream: the partials are complete when this starts
+    static_assert(64 % (D / 4) == 0 && 256 % (D / 4) == 0, "split_merge_kernel: the D/4 lanes of a row must share a wavefront");
     const int64_t work = (int64_t)p.B * p.Sq * p.Hq * (D / 4);
     const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
     hipLaunchKernelGGL((split_merge_kernel<DT>), dim3(blocks), dim3(256), 0, st, p, D);

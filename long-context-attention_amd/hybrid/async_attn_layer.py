@@ -11,6 +11,7 @@ Beyond the reference (which is forward-only `:199-202`, needs Hkv == Hq `:78` an
 in a group): GQA, a backward pass (same pipeline, mirrored), and results that are bit-identical in head
 placement to LongContextAttention (group i of rank p = kv head p*Hkv/P + i).
 """
+import os
 from typing import Any
 
 import torch
@@ -42,7 +43,7 @@ class _Lane:
         self.cuda = ref.is_cuda
         if self.cuda:
             self.main = torch.cuda.current_stream()
-            self.side = _side_stream(ref.device, "ulysses")
+            self.side = _side_stream(ref.device, "ring" if safe_comm() else "ulysses")
 
     def exchange(self, send: Tensor, group) -> tuple:
         """Queue all_to_all_single(send) behind everything currently on the main stream; returns
@@ -75,6 +76,43 @@ class _Lane:
         self.finish()
         return False
 
+
+_COMM_OVERRIDE = {}      # bench.py / tests: {"safe": bool, "pipeline": "0" | "1" | "auto"} instead of the environment
+
+
+def safe_comm() -> bool:
+    """USP_SAFE_COMM=1: never more than ONE RCCL communicator in flight -- beside a ring (degree > 1) the Ulysses
+    exchange is not pipelined (one packed exchange in front of the ring attention, one behind it) and the exchange lane
+    shares the ring's side stream, so every collective of a rank is issued in ONE program order on ONE stream.  The
+    escape hatch for a first contact with a multi-GPU box: if two communicators with kernels in flight ever stall each
+    other (ranks whose kernels reach the device in different orders), this flag costs overlap, not the run."""
+    if "safe" in _COMM_OVERRIDE:
+        return bool(_COMM_OVERRIDE["safe"])
+    return os.environ.get("USP_SAFE_COMM", "0") == "1"
+
+
+def pipeline_mode(ring_degree: int) -> bool:
+    """Is the Ulysses exchange pipelined over head groups (USP_PIPELINE_ULYSSES)?
+        0     never: one packed exchange in front of the attention, one behind it;
+        1     always, also beside a ring: two communicators (ulysses all-to-all, ring p2p) have kernels in flight at the
+              same time, each on its own side stream, every rank issuing them in the same program order;
+        auto  (default) at ring degree 1 -- ONE communicator -- always; beside a ring only when USP_SAFE_COMM is not
+              set (see `_PIPELINE_BESIDE_RING_DEFAULT`)."""
+    mode = _COMM_OVERRIDE.get("pipeline", os.environ.get("USP_PIPELINE_ULYSSES", "auto"))
+    if mode == "0":
+        return False
+    if ring_degree > 1 and safe_comm():
+        return False
+    if mode == "1" or ring_degree == 1:
+        return True
+    return _PIPELINE_BESIDE_RING_DEFAULT
+
+
+# The default beside a ring.  False until the two-communicator schedule has run on real multi-GPU RCCL or through the
+# RCCL virtual-grid test (tests/test_gpu_rccl_order.py::test_pipelined_exchange_beside_a_ring_through_rccl): round 2
+# had it on by default without either (ADVICE.md, round 2).  bench.py --gpus 8 measures BOTH modes (safe first, the
+# pipelined one under a deadline) and reports the faster, naming it.
+_PIPELINE_BESIDE_RING_DEFAULT = False
 
 _MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer workgroups per launch)
 

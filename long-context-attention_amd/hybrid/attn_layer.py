@@ -18,7 +18,7 @@ from ..comm.all_to_all import SeqAllToAll4D, SeqAllToAll5D
 from ..globals import PROCESS_GROUP
 from ..kernels import AttnType
 from ..ring.zigzag_ring_flash_attn import _check_hot_path_args
-from .async_attn_layer import _AsyncUSPFunc, _MAX_GROUPS, _RING_FWD_BWD
+from .async_attn_layer import _AsyncUSPFunc, _MAX_GROUPS, _RING_FWD_BWD, pipeline_mode
 from .utils import RING_IMPL_DICT, RING_IMPL_QKVPACKED_DICT
 
 
@@ -38,7 +38,7 @@ class _USPLayer(torch.nn.Module):
         ), f"use set_seq_parallel_pg() first. Now ulysses pg {self.ulysses_pg} and ring pg {self.ring_pg}"
         self.scatter_idx, self.gather_idx = scatter_idx, gather_idx
         self.use_sync, self.attn_type = use_sync, attn_type
-        self._ulysses_size = None
+        self._ulysses_size = self._ring_size = None
 
     @property
     def ulysses_size(self) -> int:
@@ -47,6 +47,12 @@ class _USPLayer(torch.nn.Module):
         if self._ulysses_size is None:
             self._ulysses_size = dist.get_world_size(self.ulysses_pg)
         return self._ulysses_size
+
+    @property
+    def ring_size(self) -> int:
+        if self._ring_size is None:
+            self._ring_size = dist.get_world_size(self.ring_pg) if self.ring_pg is not None else 1
+        return self._ring_size
 
     def _ring_options(self, dropout_p, softmax_scale, causal, window_size, softcap, alibi_slopes, deterministic,
                       return_attn_probs):
@@ -69,7 +75,9 @@ class LongContextAttention(_USPLayer):
             reference)
         attn_type (AttnType): any dense type; all are served by the gfx950 kernel
     Beside packing, the exchange is PIPELINED over head groups on a side HIP stream behind the attention
-    kernels whenever there is more than one group to pipeline (USP_PIPELINE_ULYSSES=0 disables it).
+    kernels whenever there is more than one group to pipeline (hybrid/async_attn_layer.py:pipeline_mode:
+    USP_PIPELINE_ULYSSES=0 disables it, =1 enables it also beside a ring, USP_SAFE_COMM=1 keeps ONE communicator
+    in flight at any time).
     """
 
     def __init__(self, scatter_idx: int = 2, gather_idx: int = 1, ring_impl_type: str = "basic",
@@ -85,8 +93,7 @@ class LongContextAttention(_USPLayer):
         """None: exchange q, k, v separately (the reference's structure); otherwise the cap on the number of
         head groups of the packed exchange (1 = one packed exchange in front of the attention and one behind
         it; more = pipelined over head groups on the side stream, hybrid/async_attn_layer.py -- identical
-        results).  Pipelining is the default also beside a ring (two communicators in flight, each on its own
-        side stream); USP_PIPELINE_ULYSSES=0 keeps the exchange sequential."""
+        results).  See `pipeline_mode` for when the exchange is pipelined."""
         if self.ulysses_size == 1:
             return None
         if os.environ.get("USP_PACK_QKV", "1") == "0" or self.use_sync or self.attn_processor is not None:
@@ -96,7 +103,7 @@ class LongContextAttention(_USPLayer):
         P = self.ulysses_size
         if query.shape[2] % P or key.shape[2] % P:
             return None
-        return 1 if os.environ.get("USP_PIPELINE_ULYSSES", "auto") == "0" else _MAX_GROUPS
+        return _MAX_GROUPS if pipeline_mode(self.ring_size) else 1
 
     def forward(self, query: Tensor, key: Tensor, value: Tensor, dropout_p=0.0, softmax_scale=None,
                 causal=False, window_size=(-1, -1), softcap=0.0, alibi_slopes=None,

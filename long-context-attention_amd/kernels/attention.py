@@ -20,10 +20,17 @@ def kernel_operand(t: torch.Tensor) -> torch.Tensor:
     """A tensor autograd hands to a backward as-is may be anything -- `out.sum().backward()` delivers an EXPANDED scalar
     (every stride 0), a slice of a bigger gradient has odd strides.  The kernels want unit head-dim stride and 16-byte
     multiples elsewhere (flash-attn's `maybe_contiguous`, flash_attn_interface.py, does the same for the reference)."""
+    if t.is_contiguous() and t.storage_offset() == 0:       # the common case, one C++ call
+        return t
     es = t.element_size()
     ok = t.stride(-1) == 1 and all(t.shape[d] == 1 or (t.stride(d) * es) % 16 == 0 for d in range(t.dim() - 1)) \
         and (t.storage_offset() * es) % 16 == 0
     return t if ok else t.contiguous()
+
+
+def needs_grad(*tensors) -> bool:
+    """Does autograd have to record this call?  (The ring functions skip their autograd.Function otherwise.)"""
+    return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
 
 
 class HipBlockBackend:

@@ -10,8 +10,8 @@ import torch
 import torch.distributed as dist
 
 from ..kernels import AttnType
-from ..kernels.attention import get_block_backend, kernel_operand
-from .utils import FULL, KVRelay, final_grads, travel_dkdv
+from ..kernels.attention import get_block_backend, kernel_operand, needs_grad
+from .utils import FULL, KVRelay, group_info, final_grads, travel_dkdv
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
 
@@ -39,8 +39,7 @@ def basic_bwd_block(be, r, P, step, causal, dout, q, kk, vv, lse, delta, softmax
 def ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, causal=True,
                             window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
                             attn_type: AttnType = AttnType.HIP, attn_processor=None, overlap=False):
-    P = dist.get_world_size(process_group)
-    r = dist.get_rank(process_group)
+    P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S, H, D = q.shape
     dev = q.device
@@ -59,8 +58,7 @@ def ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, sof
                              dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
                              alibi_slopes=None, deterministic=False,
                              attn_type: AttnType = AttnType.HIP, overlap=False):
-    P = dist.get_world_size(process_group)
-    r = dist.get_rank(process_group)
+    P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S, H, D = q.shape
     dev = q.device
@@ -147,6 +145,14 @@ def ring_flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=Fals
                          window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
                          return_attn_probs=False, group=None, attn_type: AttnType = AttnType.HIP,
                          attn_processor=None):
+    if not needs_grad(q, k, v):      # inference / forward-only benchmarks: no autograd node, no saved tensors (~25 us)
+        assert alibi_slopes is None
+        _check_hot_path_args(dropout_p, window_size, softcap)
+        out, lse = ring_flash_attn_forward(
+            group, kernel_operand(q), kernel_operand(k), kernel_operand(v),
+            softmax_scale=q.shape[-1] ** (-0.5) if softmax_scale is None else softmax_scale, causal=causal,
+            attn_type=attn_type, attn_processor=attn_processor)
+        return out if not return_attn_probs else (out, lse, None)
     return RingFlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap,
                                    alibi_slopes, deterministic, return_attn_probs, group, attn_type,
                                    attn_processor)

@@ -12,7 +12,7 @@ import torch
 import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
-from .utils import FULL, KVRelay, final_grads, travel_dkdv
+from .utils import FULL, KVRelay, group_info, final_grads, travel_dkdv
 from .varlen_utils import SeqTables, unflatten_lse
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
@@ -39,8 +39,7 @@ def ring_flash_attn_varlen_forward(process_group, q, k, v, cu_seqlens, max_seqle
                                    dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
                                    alibi_slopes=None, deterministic=False):
     """Returns (out (T,H,D), lse (H,T) fp32)."""
-    P = dist.get_world_size(process_group)
-    r = dist.get_rank(process_group)
+    P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1)
     T, H, D = q.shape
     tb = SeqTables(cu_seqlens, max_seqlen, q.device)
@@ -59,8 +58,7 @@ def ring_flash_attn_varlen_backward(process_group, dout, q, k, v, out, softmax_l
                                     max_seqlen, softmax_scale, dropout_p=0, causal=True,
                                     window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
                                     deterministic=False):
-    P = dist.get_world_size(process_group)
-    r = dist.get_rank(process_group)
+    P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1)
     T, H, D = q.shape
     dev, f32 = q.device, torch.float32

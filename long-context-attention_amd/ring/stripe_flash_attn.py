@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 from ..kernels import AttnType
 from ..kernels.attention import get_block_backend, kernel_operand
-from .utils import FULL, KVRelay, final_grads, travel_dkdv
+from .utils import FULL, KVRelay, group_info, final_grads, travel_dkdv
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
 
@@ -53,8 +53,7 @@ def stripe_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0
                               window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
                               attn_type: AttnType = AttnType.HIP, overlap=False):
     assert causal, "stripe flash attn only supports causal attention, if not causal, use ring flash attn instead"
-    P = dist.get_world_size(process_group)
-    r = dist.get_rank(process_group)
+    P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S, H, D = q.shape
     dev = q.device
@@ -73,8 +72,7 @@ def stripe_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, s
                                alibi_slopes=None, deterministic=False, attn_type: AttnType = AttnType.HIP,
                                overlap=False):
     assert causal, "stripe flash attn only supports causal attention, if not causal, ring flash attn instead"
-    P = dist.get_world_size(process_group)
-    r = dist.get_rank(process_group)
+    P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S, H, D = q.shape
     dev = q.device

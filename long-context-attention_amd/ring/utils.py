@@ -10,10 +10,11 @@ from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+import torch.distributed as _torch_dist      # `dist` is what the virtual-rank tests swap; this name never is
 
 from ..kernels.attention import get_block_backend
 
-__all__ = ["update_out_and_lse", "RingComm", "KVRelay", "ZigzagKVFetch", "zigzag_fetch_pieces", "zigzag_wave_steps", "kv_relay_mode", "travel_dkdv", "return_dkdv_direct",
+__all__ = ["update_out_and_lse", "group_info", "RingComm", "KVRelay", "ZigzagKVFetch", "zigzag_fetch_pieces", "zigzag_wave_steps", "clear_slot_caches", "kv_relay_mode", "travel_dkdv", "return_dkdv_direct",
            "dkdv_return_mode", "FULL", "final_grads"]
 
 
@@ -49,6 +50,24 @@ def update_out_and_lse(out: Optional[torch.Tensor], lse: Optional[torch.Tensor],
     if lse_c is not lse_bhs:
         lse = lse_c.transpose(1, 2).unsqueeze(-1)
     return out, lse
+
+
+_GROUP_INFO = {}
+
+
+def group_info(dist_mod, process_group):
+    """(size, this rank) of a process group.  A group's shape never changes, so torch.distributed is asked once per
+    group object (two python-level lookups per launch otherwise, ~10 us of the N = 1 step's 65, tools/host_step_cpu.py).
+    `dist_mod` is the CALLER's `dist`: the virtual-rank tests swap that attribute for a stand-in whose rank is per
+    thread -- anything but the real module is asked every time; so is the default group (None), which tests re-create."""
+    if dist_mod is not _torch_dist or process_group is None:
+        return dist_mod.get_world_size(process_group), dist_mod.get_rank(process_group)
+    info = _GROUP_INFO.get(process_group)
+    if info is None:
+        if len(_GROUP_INFO) >= 64:
+            _GROUP_INFO.clear()
+        info = _GROUP_INFO[process_group] = (_torch_dist.get_world_size(process_group), _torch_dist.get_rank(process_group))
+    return info
 
 
 class RingComm:
@@ -136,7 +155,7 @@ class KVRelay:
     _SLOTS = OrderedDict()   # (shape, dtype, device, P, rank) -> [(k_slot, v_slot)] * (P-1), device tensors only
 
     def __init__(self, process_group, k: torch.Tensor, v: torch.Tensor):
-        self.P = dist.get_world_size(process_group)
+        self.P = group_info(dist, process_group)[0]
         if self.P > 1:
             # point-to-point transfers need contiguous buffers (the reference makes K/V contiguous at
             # zigzag_ring_flash_attn.py:208-209); views stay views at ring degree 1
@@ -209,7 +228,10 @@ class KVRelay:
     def _recv_slots(self, k, v, rank):
         if not k.is_cuda:
             return [(torch.empty_like(k), torch.empty_like(v)) for _ in range(self.P - 1)]
-        key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index, self.P, rank)
+        # the compute stream is part of the key: the no-rewrite guarantee (side stream ordered behind the compute stream
+        # at the start of a relay, the compute stream behind the side stream at its end) holds between calls on ONE stream
+        key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index, self.P, rank,
+               torch.cuda.current_stream().cuda_stream)
         return _cached_slots(KVRelay._SLOTS, key,
                              lambda: [(torch.empty_like(k), torch.empty_like(v)) for _ in range(self.P - 1)])
 
@@ -270,12 +292,13 @@ class ZigzagKVFetch:
         if cuda:
             self._stream = _side_stream(k.device, "ring")
             self._stream.wait_stream(torch.cuda.current_stream())     # k, v are produced on the compute stream
-        key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index if cuda else -1, P, r, W)
         # One buffer pair per wave: the pieces of ring ranks r-1 ... r-(P-1) one behind the other along the sequence.
         # At batch 1 each piece is a contiguous row range of it (what a receive needs), so the pieces of several
         # source ranks can be handed to ONE attention launch as one K/V (`get_range`): one merge epilogue per wave and
         # query range instead of one per source rank (+16 / +40 us each at BASELINE's 4-GPU shape, kbench pieces).
         self.grouped = k.shape[0] == 1 and os.environ.get("USP_ZZ_GROUP", "1") != "0"      # USP_ZZ_GROUP=0: A/B switch
+        key = (tuple(k.shape), tuple(v.shape), k.dtype, k.device.index if cuda else -1, P, r, W, self.grouped,
+               torch.cuda.current_stream().cuda_stream if cuda else 0)      # per compute stream, as KVRelay's
 
         def make():
             if not self.grouped:
@@ -348,6 +371,10 @@ class ZigzagKVFetch:
         return tuple(b[:, (s_lo - 1) * rows:s_hi * rows] for b in self.bufs[wave])
 
     def finish(self):
+        # every rank issues the same sequence of grouped calls on every exit path: a rank that leaves before its first
+        # get() (an exception in the step-0 launch, a plan without launches) must still post its sends, or its peers
+        # hang in RCCL instead of failing
+        self.post()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
             self._stream = None
@@ -358,6 +385,13 @@ class ZigzagKVFetch:
     def __exit__(self, *exc):
         self.finish()
         return False
+
+
+def clear_slot_caches():
+    """Drop the persistent K/V receive slots (they return to the caching allocator): for callers that change shapes for
+    good, e.g. between a long-sequence phase and a packed-batch phase."""
+    KVRelay._SLOTS.clear()
+    ZigzagKVFetch._SLOTS.clear()
 
 
 def zigzag_wave_steps(P: int, r: int, front: bool):

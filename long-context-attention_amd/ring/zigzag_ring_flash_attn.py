@@ -22,8 +22,8 @@ import torch
 import torch.distributed as dist
 
 from ..kernels import AttnType
-from ..kernels.attention import get_block_backend, kernel_operand
-from .utils import FULL, KVRelay, ZigzagKVFetch, final_grads, kv_relay_mode, travel_dkdv, zigzag_fetch_pieces
+from ..kernels.attention import get_block_backend, kernel_operand, needs_grad
+from .utils import FULL, KVRelay, group_info, ZigzagKVFetch, final_grads, kv_relay_mode, travel_dkdv, zigzag_fetch_pieces
 
 
 
@@ -108,8 +108,7 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
     """`overlap`: the caller has transfers of its own in flight (pipelined Ulysses exchange), so the kernels are
     launched so that collectives can run beside them even at ring degree 1."""
     assert causal == True, "zigzag ring is meaningless for causal=False"
-    P = dist.get_world_size(process_group)
-    r = dist.get_rank(process_group)
+    P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S2, H, D = q.shape
     assert S2 % 2 == 0, "zigzag layout needs an even local sequence length"
@@ -143,8 +142,7 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
                                     alibi_slopes=None, deterministic=False,
                                     attn_type: AttnType = AttnType.HIP, overlap=False):
     assert causal == True, "zigzag ring is meaningless for causal=False"
-    P = dist.get_world_size(process_group)
-    r = dist.get_rank(process_group)
+    P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S2, H, D = q.shape
     c = S2 // 2
@@ -238,6 +236,14 @@ def zigzag_ring_flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, caus
                                 window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
                                 deterministic=False, return_attn_probs=False, group=None,
                                 attn_type: AttnType = AttnType.HIP, attn_processor=None):
+    if not needs_grad(q, k, v):      # inference / forward-only benchmarks: no autograd node, no saved tensors
+        assert alibi_slopes is None
+        _check_hot_path_args(dropout_p, window_size, softcap)
+        out, lse = zigzag_ring_flash_attn_forward(
+            group, kernel_operand(q), kernel_operand(k), kernel_operand(v),
+            softmax_scale=q.shape[-1] ** (-0.5) if softmax_scale is None else softmax_scale, causal=causal,
+            attn_type=attn_type)
+        return out if not return_attn_probs else (out, lse, None)
     return ZigZagRingFlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size,
                                          softcap, alibi_slopes, deterministic, return_attn_probs,
                                          group, attn_type)

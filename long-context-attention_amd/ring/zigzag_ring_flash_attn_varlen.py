@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 
 from ..kernels.attention import get_block_backend
-from .utils import FULL, KVRelay, final_grads, travel_dkdv
+from .utils import FULL, KVRelay, group_info, final_grads, travel_dkdv
 from .varlen_utils import SeqTables, unflatten_lse
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
@@ -65,8 +65,7 @@ def zigzag_ring_flash_attn_varlen_forward(process_group, q, k, v, cu_seqlens, ma
                                           alibi_slopes=None, deterministic=False):
     """Returns (out (T,H,D), lse (H,T) fp32)."""
     assert causal == True, "zigzag ring is meaningless for causal=False"
-    P = dist.get_world_size(process_group)
-    r = dist.get_rank(process_group)
+    P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1)
     T, H, D = q.shape
     tb = SeqTables(cu_seqlens, max_seqlen, q.device)
@@ -86,8 +85,7 @@ def zigzag_ring_flash_attn_varlen_backward(process_group, dout, q, k, v, out, so
                                            deterministic=False):
     """`softmax_lse` is the flattened (H,T) fp32 LSE of the forward."""
     assert causal == True, "zigzag ring is meaningless for causal=False"
-    P = dist.get_world_size(process_group)
-    r = dist.get_rank(process_group)
+    P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1)
     T, H, D = q.shape
     dev, f32 = q.device, torch.float32

@@ -72,7 +72,8 @@ def _probe_worker(rank, ws, ud, rd):
     b = _bench()
     set_block_backend(OracleBlockBackend())
     Y.set_seq_parallel_pg(ud, rd, rank, ws)
-    AL._FILL_ITEMS = 1                       # tiny problem: let the head-group pipeline form (the layer's default)
+    AL._FILL_ITEMS = 1                       # tiny problem: let the head-group pipeline form
+    AL._COMM_OVERRIDE.update(pipeline="1")   # ... also beside a ring (what bench.py's second, overlapped pass runs)
     torch.manual_seed(0)
     B, S, H, D = 1, 32 * ws, 4, 32
     glob = [torch.randn(B, S, H, D).to(torch.bfloat16) for _ in range(3)]
@@ -139,7 +140,7 @@ def _main_worker(rank, ws):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(ws), LOCAL_RANK=str(rank), USP_BENCH_BACKEND="gloo")
     for n, w in b.WORKLOADS.items():
         w.update(B=1, S=64 * n, Hq=4, Hkv=4 if n < 8 else 2, D=32)
-    b.kernel_roofline = lambda cfg, dev: {"achieved": 1.0, "stub": True}
+    b.kernel_roofline = lambda cfg, dev, traffic=None: {"achieved": 1.0, "stub": True}
     b.seq64k_single_gpu = lambda dev: {"stub": True}
     b.reference_kernel = lambda cfg, dev, ours: {"stub": True}
     b.cpu_baseline = lambda cfg: {"stub": True}
@@ -161,6 +162,12 @@ def _main_worker(rank, ws):
         assert line["roofline"]["seq64k_single_gpu"] == {"stub": True}
     else:
         assert set(line["overlap"]) >= {"value", "ms_iter", "ms_compute_only", "ms_comm_only"}
+    if ws == 8:       # ulysses 2 x ring 4: two communicators -> the safe mode is measured first, then the overlapped one
+        assert set(line["comm_modes_ms_per_step"]) == {"safe", "overlapped"}
+        assert line["config"]["comm_mode"].startswith(("safe", "overlapped"))
+        assert line["ms_per_step"] == min(line["comm_modes_ms_per_step"].values())
+    else:
+        assert "comm_modes_ms_per_step" not in line
     return True
 
 
@@ -193,3 +200,25 @@ def test_profile_is_quoted_only_for_the_kernel_it_was_taken_from(monkeypatch):
     monkeypatch.setattr(b, "kernel_source_sha16", lambda: "f" * 16)
     t = b.pmc_traffic()
     assert t["read_MB"] is None and "no figure is claimed" in t["stale"]
+
+
+def test_sampled_parity_reference_equals_autograd():
+    """bench.sampled_parity (the fp64 rows / key columns the 64K entry of the bench line and the full-size GPU tests are
+    checked against) on a small GQA problem where the whole answer is affordable: exact attention through autograd in
+    fp64 must come out with zero error, a perturbed gradient with exactly its perturbation."""
+    b = _bench()
+    torch.manual_seed(0)
+    B, S, Hq, Hkv, D = 1, 300, 4, 2, 32
+    q, k, v, do = (torch.randn(B, S, h, D, dtype=torch.float64) for h in (Hq, Hkv, Hkv, Hq))
+    qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
+    ke, ve = (t.repeat_interleave(Hq // Hkv, dim=2) for t in (kk, vv))
+    s = torch.einsum("bihd,bjhd->bhij", qq, ke) * D ** -0.5
+    s = s.masked_fill(~torch.ones(S, S, dtype=torch.bool).tril(), float("-inf"))
+    o = torch.einsum("bhij,bjhd->bihd", torch.softmax(s, -1), ve)
+    o.backward(do)
+    t = dict(q=q, k=k, v=v, do=do, out=o.detach(), lse=torch.logsumexp(s, -1).detach(), dq=qq.grad, dk=kk.grad, dv=vv.grad)
+    res = b.sampled_parity(t)
+    assert max(res["max_abs_err"].values()) < 1e-9, res
+    t["dk"] = t["dk"].clone()
+    t["dk"][0, 0, 0, 3] += 0.25                      # key 0 of kv head 0 is always sampled
+    assert abs(b.sampled_parity(t)["max_abs_err"]["dk"] - 0.25) < 1e-6

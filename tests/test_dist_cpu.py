@@ -167,8 +167,10 @@ def _async_worker(rank, ws, ud, rd, impl, Hq, Hkv):
              for t in (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, True))]
     res = []
     # the pipelined packed exchange (default), one packed exchange, the reference's three exchanges, the async layer
-    for cls, env in ((Y.LongContextAttention, {}), (Y.LongContextAttention, {"USP_PIPELINE_ULYSSES": "0"}),
-                     (Y.LongContextAttention, {"USP_PACK_QKV": "0"}), (Y.AsyncLongContextAttention, {})):
+    # (+ the layer's default and USP_SAFE_COMM=1, which beside a ring are the one-exchange form)
+    for cls, env in ((Y.LongContextAttention, {"USP_PIPELINE_ULYSSES": "1"}), (Y.LongContextAttention, {"USP_PIPELINE_ULYSSES": "0"}),
+                     (Y.LongContextAttention, {"USP_PACK_QKV": "0"}), (Y.AsyncLongContextAttention, {}),
+                     (Y.LongContextAttention, {}), (Y.LongContextAttention, {"USP_SAFE_COMM": "1", "USP_PIPELINE_ULYSSES": "1"})):
         lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=rd, ud=ud).detach().clone() for t in (q, k, v, do))
         for t in (lq, lk, lv):
             t.requires_grad_(True)
@@ -493,3 +495,47 @@ def test_zigzag_fetch_ungrouped_switch_gives_the_same_result(monkeypatch):
     for r in range(g.ws):
         assert_close(res[r]["out"], g.out[r], *TOL[g.dtype]["out"], f"out rank {r}")
         assert len([x for x in res[r]["calls"] if x[0] == "fwd"]) == 1 + (g.rd - 1) + (g.rd - 1 - r)
+
+
+GRID = [f for f in golden_files() if Golden(f).ud > 1 and Golden(f).rd > 1 and Golden(f).layer == "hybrid"]
+
+
+@pytest.mark.parametrize("mode", ["pipelined", "safe"])
+@pytest.mark.parametrize("path", GRID, ids=lambda p: p.split("/")[-1][:-4])
+def test_virtual_grid_runs_the_layer_for_every_rank_in_one_process(monkeypatch, path, mode):
+    """tests/virtual_grid.py on host tensors (the harness the RCCL ordering test uses on the GPU): all ranks of a
+    ulysses x ring grid as threads of ONE process through the layer's real autograd Function, the packed exchange
+    pipelined over head groups beside the ring (two communicators' traffic interleaved) or in the safe one-exchange
+    form, against the reference's goldens -- and the same sequence of collectives on every member of a group."""
+    from golden_util import grad_tol
+    from oracle_backend import OracleBlockBackend
+    from virtual_grid import Ctx, VirtualGrid, patch_dist, run_grid
+    from yunchang_amd.kernels import set_block_backend
+    g = Golden(path)
+    grid = VirtualGrid(g.ud, g.rd)
+    AL = patch_dist(monkeypatch, grid)
+    monkeypatch.setattr(AL, "_FILL_ITEMS", 1)
+    monkeypatch.setitem(AL._COMM_OVERRIDE, "safe", mode == "safe")
+    dtype = getattr(torch, g.dtype)
+    loc = [[torch.from_numpy(np.ascontiguousarray(g.shard(x, r))).to(dtype) for x in (g.q, g.k, g.v, g.dout)]
+           for r in range(g.ws)]
+    prev = set_block_backend(OracleBlockBackend())
+    try:
+        def rank_fn(r):
+            q, k, v, do = loc[r]
+            upg, rpg = grid.groups_of(r)
+            ctx = Ctx()
+            cap = AL._MAX_GROUPS if AL.pipeline_mode(g.rd) or mode == "pipelined" and not AL.safe_comm() else 1
+            out = AL._AsyncUSPFunc.forward(ctx, q, k, v, None, g.causal, upg, rpg, g.impl, cap)
+            grads = AL._AsyncUSPFunc.backward(ctx, do)[:3] if g.bwd else ()
+            return (out,) + tuple(grads), ctx.meta[6]
+        res = run_grid(grid, g.ws, rank_fn)
+    finally:
+        set_block_backend(prev)
+    ng = {n for _, n in res}
+    assert ng == ({1} if mode == "safe" else {min(AL._MAX_GROUPS, g.Hkv // g.ud)}), ng
+    assert {k for k, _ in grid.calls} == {"ulysses", "ring"}
+    for r in range(g.ws):
+        for t, name in zip(res[r][0], ("out", "dq", "dk", "dv")):
+            tol = TOL[g.dtype]["out"] if name == "out" else grad_tol(g.dtype, g.Hq // g.Hkv if name != "dq" else 1)
+            assert_close(t.float().numpy(), getattr(g, name)[r], *tol, f"{g.name} {name} rank {r}")

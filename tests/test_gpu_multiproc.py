@@ -38,10 +38,11 @@ def _order_p2p_like_rccl():
 def _usp_gpu_worker(rank, ws, path, pipelined=False):
     import yunchang_amd as Y
     _order_p2p_like_rccl()
-    if pipelined:        # the DEFAULT exchange mode (USP_PIPELINE_ULYSSES unset): head groups pipelined on the side
-        import os        # stream, also beside a ring; the fixtures are tiny, so let the groups form anyway
+    if pipelined:        # head groups pipelined on the "ulysses" side stream, ALSO beside a ring (USP_PIPELINE_ULYSSES=1;
+        import os        # the default at ring degree 1); the fixtures are tiny, so let the groups form anyway
         import yunchang_amd.hybrid.async_attn_layer as AL
-        assert "USP_PIPELINE_ULYSSES" not in os.environ and "USP_PACK_QKV" not in os.environ
+        assert "USP_PACK_QKV" not in os.environ and "USP_SAFE_COMM" not in os.environ
+        os.environ["USP_PIPELINE_ULYSSES"] = "1"
         AL._FILL_ITEMS = 1
     from yunchang_amd.kernels import get_block_backend
     assert get_block_backend().name == "hip"
@@ -156,9 +157,9 @@ PIPE = [f for f in DENSE if "c3_w2_u2r1" in f or "c5_w8_u2r4_gqa_bf16" in f or "
 
 @pytest.mark.parametrize("path", PIPE, ids=lambda p: p.split("/")[-1][:-4])
 def test_long_context_attention_with_pipelined_exchange(gloo_cuda, path):
-    """LongContextAttention in its DEFAULT mode -- packed q|k|v exchange pipelined over head groups on the
-    "ulysses" side stream, beside the ring relay on the "ring" side stream, kernels launched interleavable --
-    with USP_PIPELINE_ULYSSES unset, against the reference goldens (incl. ulysses 2 x ring 4, GQA)."""
+    """LongContextAttention with the packed q|k|v exchange pipelined over head groups on the "ulysses" side stream,
+    beside the ring relay on the "ring" side stream, kernels launched interleavable (USP_PIPELINE_ULYSSES=1; the
+    default at ring degree 1), against the reference goldens (incl. ulysses 2 x ring 4, GQA)."""
     g = Golden(path)
     res = run_distributed(_usp_gpu_worker, g.ws, path, True)
     for r in range(g.ws):
@@ -211,13 +212,9 @@ def test_varlen_ring_multiprocess_one_gpu(gloo_cuda, path):
             assert_close(res[r][key], getattr(g, key)[r], *TOL[g.dtype]["grad"], f"{g.name} {key} rank {r}")
 
 
-# ---- staged: written without a GPU (round 2's GPU budget was spent); run with USP_TEST_STAGED=1 on first GPU contact ----
-_staged = pytest.mark.skipif(__import__("os").environ.get("USP_TEST_STAGED") != "1",
-                             reason="staged for the next GPU session (USP_TEST_STAGED=1): not yet run on hardware")
 RING_BWD = [f for f in DENSE if Golden(f).rd > 1 and Golden(f).bwd]
 
 
-@_staged
 @pytest.mark.parametrize("path", RING_BWD, ids=lambda p: p.split("/")[-1][:-4])
 def test_direct_dkdv_return_on_the_gpu(gloo_cuda, path, monkeypatch):
     """USP_DKDV_RETURN=direct through the HIP kernels and the real streams: the owner adds the arriving blocks in

@@ -169,3 +169,70 @@ def test_ring_backward_ordering_through_rccl_self_sendrecv(nccl_single, monkeypa
             for r in range(P):
                 for t, t0, name in zip(got[r], first[r], ("out", "dq", "dk", "dv")):
                     assert torch.equal(t, t0), f"iteration {it}: {name} of rank {r} differs from iteration 0"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A ulysses x ring GRID of virtual ranks: the pipelined Ulysses exchange ("ulysses" lane) beside the ring traffic ("ring"
+# lane + the travelling dK/dV posted from the compute streams) -- TWO communicators' worth of traffic in flight, every
+# transfer a real RCCL self send/recv, no host synchronisation.
+# ---------------------------------------------------------------------------------------------------------------------
+from virtual_grid import VirtualGrid as _VirtualGrid, Ctx as _Ctx
+
+
+GRID = [f for f in golden_files() if Golden(f).ud > 1 and Golden(f).rd > 1 and Golden(f).layer == "hybrid"
+        and Golden(f).dtype == "bfloat16"]
+
+
+@pytest.mark.timeout(1200)
+@pytest.mark.parametrize("pieces", [1, 2])
+@pytest.mark.parametrize("path", GRID, ids=lambda p: p.split("/")[-1][:-4])
+def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch, path, pieces):
+    """The two-communicator schedule (USP_PIPELINE_ULYSSES=1 beside a ring: BASELINE's 8-GPU grid ulysses 2 x ring 4,
+    GQA, zigzag, forward + backward; and the 2 x 2 grids) with every exchange and every ring transfer going through real
+    RCCL, stream-ordered only: head group i's ring attention starts behind ITS exchange, its output exchange runs
+    behind group i+1's kernels, the zigzag fetch posts its waves (USP_ZZ_PIECES) beside them, the dK/dV accumulators
+    travel from the compute streams.  Iterations must be bit-identical and equal to the reference's run."""
+    from golden_util import grad_tol
+    from virtual_grid import patch_dist, run_grid
+    dev = torch.device("cuda:0")
+    g = Golden(path)
+    if pieces > 1 and not (g.impl == "zigzag" and g.rd > 2):
+        pytest.skip("row-range waves exist for the zigzag mesh fetch (ring degree > 2) only")
+    grid = _VirtualGrid(g.ud, g.rd, nccl_single)
+    AL = patch_dist(monkeypatch, grid)
+    monkeypatch.setattr(AL, "_FILL_ITEMS", 1)                # tiny fixture: let the head groups form
+    monkeypatch.setenv("USP_ZZ_PIECES", str(pieces))
+    dtype = getattr(torch, g.dtype)
+    ws = g.ws
+    loc = [[torch.from_numpy(np.ascontiguousarray(g.shard(x, r))).to(dtype).to(dev) for x in (g.q, g.k, g.v, g.dout)]
+           for r in range(ws)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ws)]
+    torch.cuda.synchronize()
+
+    def rank_fn(r):
+        torch.cuda.set_device(dev)
+        q, k, v, do = loc[r]
+        upg, rpg = grid.groups_of(r)
+        ctx = _Ctx()
+        with torch.cuda.stream(streams[r]):
+            out = AL._AsyncUSPFunc.forward(ctx, q, k, v, None, g.causal, upg, rpg, g.impl, AL._MAX_GROUPS)
+            grads = AL._AsyncUSPFunc.backward(ctx, do)[:3] if g.bwd else ()
+        return (out,) + tuple(grads)
+
+    names = ("out", "dq", "dk", "dv")
+    first = None
+    for it in range(8):
+        res = run_grid(grid, ws, rank_fn)
+        torch.cuda.synchronize()
+        got = [[t.clone() for t in res[r]] for r in range(ws)]
+        if first is None:
+            first = got
+            assert {k for k, _ in grid.calls} == {"ulysses", "ring"}          # both communicators carried traffic
+            for r in range(ws):
+                for t, name in zip(got[r], names):
+                    tol = TOL[g.dtype]["out"] if name == "out" else grad_tol(g.dtype, g.Hq // g.Hkv if name != "dq" else 1)
+                    assert_close(t.float().cpu().numpy(), getattr(g, name)[r], *tol, f"{g.name} {name} rank {r}")
+        else:
+            for r in range(ws):
+                for t, t0, name in zip(got[r], first[r], names):
+                    assert torch.equal(t, t0), f"iteration {it}: {name} of rank {r} differs from iteration 0"

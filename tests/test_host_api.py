@@ -302,7 +302,7 @@ def test_zigzag_fetch_plan_and_wave_matching():
 
 def test_forward_k_split_workspace_and_policy(monkeypatch):
     """ABI v4's K split of few-item forward launches: the workspace size the C side asks for (host code, no GPU), the
-    argument checks that need no launch, and the (staged, opt-in) policy of the Python binding."""
+    argument checks that need no launch, and the policy of the Python binding."""
     import ctypes
     L = _C.load()
     a = _C.UspFwdArgs()
@@ -314,15 +314,19 @@ def test_forward_k_split_workspace_and_policy(monkeypatch):
     assert L.usp_flash_fwd_workspace_bytes(ctypes.byref(a), 9) == 0
     a.seq_q = 8                                                      # packed batches are not split
     assert L.usp_flash_fwd_workspace_bytes(ctypes.byref(a), 2) == 0
-    # the policy: off unless asked for; then only causal launches with fewer than two 256-row items per CU
-    monkeypatch.delenv("USP_FWD_KSPLIT", raising=False)
+    # the policy (read from USP_FWD_KSPLIT at import; set_fwd_ksplit in-process): only causal launches with fewer than
+    # two 256-row items per CU
+    monkeypatch.setattr(_C, "_KSPLIT_MODE", _C._parse_ksplit("0"))
     assert _C.fwd_k_splits(1, 16384, 2, True) == 0
-    monkeypatch.setenv("USP_FWD_KSPLIT", "4")
+    with pytest.warns(UserWarning):
+        assert _C._parse_ksplit("fast") == 0                        # a typo must not raise on every launch
+    assert _C._parse_ksplit(None) == "auto" and _C._parse_ksplit("1") == 0 and _C._parse_ksplit("99") == 8
+    assert _C.set_fwd_ksplit(4) == 0
     assert _C.fwd_k_splits(1, 16384, 2, True) == 4                  # 128 items
     assert _C.fwd_k_splits(1, 16384, 2, False) == 0                 # not causal
     assert _C.fwd_k_splits(1, 16384, 8, True) == 0                  # 512 items: fills the part
     assert _C.fwd_k_splits(2, 8192, 16, True) == 0                  # BASELINE configs[1]
-    monkeypatch.setenv("USP_FWD_KSPLIT", "auto")
+    assert _C.set_fwd_ksplit("auto") == 4
     assert _C.fwd_k_splits(1, 16384, 4, True) == 2 and _C.fwd_k_splits(1, 16384, 2, True) == 4
     assert _C.fwd_k_splits(1, 2048, 2, True) == 0                   # short sequences: nothing to balance
 
@@ -353,12 +357,12 @@ def test_forward_k_split_glue_of_the_binding(monkeypatch):
     monkeypatch.setattr(_C, "_stream", lambda: ctypes.c_void_p(7))
     monkeypatch.setattr(_C.torch.cuda, "current_stream", lambda *a: Stream)
     monkeypatch.setattr(_C, "_FWD_WS", {})
-    monkeypatch.delenv("USP_FWD_KSPLIT", raising=False)
+    monkeypatch.setattr(_C, "_KSPLIT_MODE", 0)
     B, S, H, D = 1, 4096, 2, 128
     q = torch.zeros(B, S, H, D, dtype=torch.bfloat16)
     lse = torch.zeros(B, H, S)
     out = torch.zeros_like(q)
-    _C.flash_fwd(q, q, q, 0.1, True, lse, out)                       # default: no split
+    _C.flash_fwd(q, q, q, 0.1, True, lse, out)                       # policy off: no split
     assert seen[-1][:2] == (0, None)
     _C.flash_fwd(q, q, q, 0.1, True, lse, out, k_splits=2)
     n, ws = seen[-1][:2]
@@ -371,7 +375,7 @@ def test_forward_k_split_glue_of_the_binding(monkeypatch):
     _C.flash_fwd(q, q, q, 0.1, True, lse, out, k_splits=4)           # grown
     (buf,) = _C._FWD_WS.values()
     assert seen[-1][0] == 4 and buf.numel() >= 2 * need2 and seen[-1][1] == buf.data_ptr()
-    monkeypatch.setenv("USP_FWD_KSPLIT", "auto")                     # the staged policy: 2 heads x 16 tiles -> n = 4
+    monkeypatch.setattr(_C, "_KSPLIT_MODE", "auto")                  # the default policy: 2 heads x 16 tiles -> n = 4
     _C.flash_fwd(q, q, q, 0.1, True, lse, out)
     assert seen[-1][0] == 4
     _C.flash_fwd(q, q, q, 0.1, False, lse, out)                      # not causal -> off

@@ -81,3 +81,20 @@ def test_varlen_sharded_sim_equals_per_sequence_attention(path):
     for r in range(g.ws):
         np.testing.assert_allclose(outs[r], g.shard(full, r), atol=1e-12, rtol=1e-10)
         np.testing.assert_allclose(lses[r], g.shard(full_lse.T, r).T, atol=1e-12, rtol=1e-10)
+
+
+@pytest.mark.parametrize("path", [f for f in golden_files() if Golden(f).ws == 1], ids=lambda p: p.split("/")[-1][:-4])
+def test_cpu_baseline_port_equals_the_reference_single_rank_run(path):
+    """oracle/ref_cpu_path.py (bench.py's `cpu_baseline`, kind "port": the reference cannot be imported on the GPU box)
+    against the reference's OWN single-rank runs (fixtures made by tests/golden/make_golden.py importing the reference
+    with the same CPU attention op in the efficient op's place): the same calls on the same data must give the same
+    bits -- C1 in fp32 and bf16, and the B = 2 fixture of configs[1]'s topology."""
+    import torch
+    from oracle import ref_cpu_path as R
+    g = Golden(path)
+    dtype = getattr(torch, g.dtype)
+    q, k, v = (torch.from_numpy(x).to(dtype) for x in (g.q, g.k, g.v))
+    out, _ = R.long_context_attention_forward_cpu(q, k, v, g.causal)
+    got = out.float().numpy()
+    assert got.shape == g.out[0].shape
+    assert np.array_equal(got, g.out[0]), f"{g.name}: max abs diff {np.abs(got - g.out[0]).max():.3e}"
