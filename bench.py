@@ -634,6 +634,13 @@ def main(argv=None, dev=None):
         _commit = _U.RingComm.commit
         _U.RingComm.commit = lambda self: (torch.cuda.synchronize(), _commit(self))[1]
     Y.set_seq_parallel_pg(cfg["ud"], cfg["rd"], rank, ws)
+    # two communicators (ulysses x ring grid): everything up to and including the first measurement runs in the SAFE
+    # mode (one communicator in flight at a time); the overlapped mode is tried afterwards, under a deadline (below)
+    import yunchang_amd.hybrid.async_attn_layer as AL
+    two_comms = cfg["ud"] > 1 and cfg["rd"] > 1 and not args.async_ulysses and "USP_PIPELINE_ULYSSES" not in os.environ \
+        and "USP_SAFE_COMM" not in os.environ
+    if two_comms:
+        AL._COMM_OVERRIDE.update(safe=True)
     q, k, v, do = make_global(cfg, dev)
     ext = Y.EXTRACT_FUNC_DICT[cfg["impl"]]
     lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=cfg["rd"], ud=cfg["ud"]).detach().clone()
@@ -721,18 +728,13 @@ def main(argv=None, dev=None):
             line["smoke"] = f"backend={backend}, all ranks on {dev} -- NOT a measurement"
         return line
 
-    # A ulysses x ring grid has TWO communicators.  The library's default keeps one of them in flight at a time beside a
-    # ring ("safe": one packed exchange in front of the ring attention, one behind it); USP_PIPELINE_ULYSSES=1 pipelines
-    # the exchange over head groups beside the ring traffic (both communicators in flight, each on its own side stream).
-    # The second mode has never met real multi-GPU RCCL, so the measurement is staged: the safe mode is measured FIRST
+    # A ulysses x ring grid has TWO communicators.  USP_SAFE_COMM=1 keeps one of them in flight at a time beside a ring
+    # (one packed exchange in front of the ring attention, one behind it); the library's default pipelines the exchange
+    # over head groups beside the ring traffic (both communicators in flight, each on its own side stream).  The
+    # default has run through RCCL on one device only (tests/test_gpu_rccl_order.py), so the measurement is staged: the safe mode is measured FIRST
     # and its line is complete; the overlapped mode then runs under a deadline -- if it finishes, the faster of the two
     # is reported (and named, with the other's figure beside it); if it stalls, rank 0 prints the safe line and every
     # rank leaves with exit code 0.
-    import yunchang_amd.hybrid.async_attn_layer as AL
-    two_comms = cfg["ud"] > 1 and cfg["rd"] > 1 and not args.async_ulysses and "USP_PIPELINE_ULYSSES" not in os.environ \
-        and "USP_SAFE_COMM" not in os.environ
-    if two_comms:
-        AL._COMM_OVERRIDE.update(safe=True)
     ms, dms = measure()
     comm_mode = ("safe: one communicator in flight at a time" if (two_comms or AL.safe_comm()) else
                  "library default" + (" (USP_PIPELINE_ULYSSES=%s)" % os.environ["USP_PIPELINE_ULYSSES"]
@@ -741,7 +743,7 @@ def main(argv=None, dev=None):
     if two_comms:
         safe_ms = ms
         fallback = _LineOnce(None if line is None else
-                             {**line, "comm_mode_note": "the overlapped mode (USP_PIPELINE_ULYSSES=1) did not finish "
+                             {**line, "comm_mode_note": "the overlapped mode (the library default) did not finish "
                                                         "before its deadline; this is the safe mode's measurement"})
         budget = float(os.environ.get("USP_BENCH_MODE_DEADLINE_S", str(60 + 20 * safe_ms * 1e-3 * (n_heat + args.warmup + args.steps))))
         with _Deadline(budget, fallback, None):
@@ -749,9 +751,9 @@ def main(argv=None, dev=None):
             ms2, dms2 = measure()
         if ms2 < ms:
             ms, dms = ms2, dms2
-            line = make_line(ms, dms, "overlapped: Ulysses exchange pipelined over head groups beside the ring "
-                                      "(USP_PIPELINE_ULYSSES=1), two communicators in flight")
-        else:
+            line = make_line(ms, dms, "overlapped (the library default): Ulysses exchange pipelined over head groups beside "
+                                      "the ring, two communicators in flight")
+        else:                                       # the overlap probe below runs in the mode that was reported
             AL._COMM_OVERRIDE.update(safe=True)
             AL._COMM_OVERRIDE.pop("pipeline", None)
         if line is not None:

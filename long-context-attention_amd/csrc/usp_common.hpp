@@ -123,6 +123,13 @@ template <typename Rsrc> USP_DEV void lds_dma16(Rsrc rsrc, USP_LDS char* lds_dst
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (USP_LDS void*)lds_dst, 16, voffset, 0, 0, 0);
 #endif
 }
+// ... at rsrc.base + soffset + voffset, `soffset` wave-uniform (an SGPR operand of the instruction): a streaming loop
+// keeps ONE descriptor and advances a scalar byte offset instead of rebuilding the descriptor per tile.
+template <typename Rsrc> USP_DEV void lds_dma16(Rsrc rsrc, USP_LDS char* lds_dst, int voffset, int soffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (USP_LDS void*)lds_dst, 16, voffset, soffset, 0, 0);
+#endif
+}
 
 // Pin a value to the accumulator (AGPR) register file at this point.
 USP_DEV void pin_agpr(f32x16& acc) {

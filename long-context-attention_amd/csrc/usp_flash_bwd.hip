@@ -648,7 +648,14 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   const int heads_here = p.split ? 1 : p.G;
   const int n_iter = per_head * heads_here;
 
-  // ---- LDS-DMA staging of the Q / dO tiles (as in flash_bwd_kernel) -------------------------------
+  // ---- LDS-DMA staging of the Q / dO tiles -----------------------------------------------------------------
+  // ONE buffer descriptor pair per (item, query head), based on row 0 of that head; a tile is addressed by a scalar byte
+  // offset (the instruction's soffset operand).  Per tile that is two s_add and the loads.  (Round 2 kept 64-bit tile
+  // pointers / remaining-bytes counters and rebuilt both descriptors -- clamps included -- for every tile, and every
+  // tile recomputed the 64-bit addresses of its row statistics: ~170 scalar instructions and 40-50 SGPR-spill reloads
+  // (v_readlane) at the head of EVERY iteration of EVERY wave, 40 % of a wave's instruction stream -- the kernel was
+  // bound by instruction issue, not by the MFMA pipe: with every element operation removed it still ran at 973 of
+  // 1071 us, profiles/r03_bwd_ablations.txt.)  The host guarantees that a head's rows span less than 2^31 bytes.
   int dma_voff1[CPW], dma_voff2[CPW];
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {
@@ -659,56 +666,55 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
     dma_voff2[i] = r * (int)p.do_ss * 2 + c8 * 16;
   }
   float st_lse = 0.f, st_delta = 0.f;
+  bool st_in = false;
   decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0)) rs1, rs2;
-  int dma_buf = 0;
-  const int64_t tb1 = (int64_t)kTile * p.q_ss * 2, tb2 = (int64_t)kTile * p.do_ss * 2;
-  int pf_tile = t_begin, pf_hh = 0;
-  const char *pf_p1 = nullptr, *pf_p2 = nullptr;
-  int64_t pf_rem1 = 0, pf_rem2 = 0;
-  auto pf_head = [&]() {
+  const int tb1 = kTile * (int)p.q_ss * 2, tb2 = kTile * (int)p.do_ss * 2;     // bytes per tile step
+  int pf_tile = t_begin, pf_hh = 0, soff1 = 0, soff2 = 0;
+  const float *lse_h = nullptr, *dl_h = nullptr;                             // row statistics of the cursor's head
+  const bool stat_wave = wave == 4;              // a role-B wave fetches the tile's statistics: role A is the longer stream
+  auto pf_head = [&]() {                         // (re)base the cursor on head h0 + pf_hh, tile t_begin
+    auto clampu = [](int64_t r) { return (int)(uint32_t)(r < 0 ? 0 : (r > 0xffffffffLL ? 0xffffffffLL : r)); };
+    const int h = h0 + pf_hh;
+    rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q + 2 * (b * p.q_sb + h * p.q_sh)), 0,
+                                            clampu(((int64_t)(p.Sq - 1) * p.q_ss + D) * 2), 0x00020000);
+    rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.dout + 2 * (b * p.do_sb + h * p.do_sh)), 0,
+                                            clampu(((int64_t)(p.Sq - 1) * p.do_ss + D) * 2), 0x00020000);
+    lse_h = p.lse + b * p.lse_sb + h * p.lse_sh;
+    dl_h = p.delta + b * p.dl_sb + h * p.dl_sh;
     pf_tile = t_begin;
-    pf_p1 = p.q + 2 * (b * p.q_sb + (h0 + pf_hh) * p.q_sh) + t_begin * tb1;
-    pf_p2 = p.dout + 2 * (b * p.do_sb + (h0 + pf_hh) * p.do_sh) + t_begin * tb2;
-    pf_rem1 = ((int64_t)(p.Sq - 1 - t_begin * kTile) * p.q_ss + D) * 2;
-    pf_rem2 = ((int64_t)(p.Sq - 1 - t_begin * kTile) * p.do_ss + D) * 2;
+    soff1 = t_begin * tb1;
+    soff2 = t_begin * tb2;
   };
   pf_head();
-  auto stage_setup = [&](int buf) {
-    auto clampu = [](int64_t r) { return (int)(uint32_t)(r < 0 ? 0 : (r > 0xffffffffLL ? 0xffffffffLL : r)); };
-    rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)pf_p1, 0, clampu(pf_rem1), 0x00020000);
-    rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)pf_p2, 0, clampu(pf_rem2), 0x00020000);
-    dma_buf = buf;
-    if (tid < kTile) {
-      const int r = pf_tile * kTile + tid;
-      if (r < p.Sq) {
-        const float l_ = p.lse[b * p.lse_sb + (h0 + pf_hh) * p.lse_sh + r];
-        st_lse = (l_ == USP_NEG_INF) ? __builtin_inff() : l_ * kLog2e;
-        st_delta = -p.delta[b * p.dl_sb + (h0 + pf_hh) * p.dl_sh + r];     // NEGATED: role B folds it into the dP chain
-      } else {
-        st_lse = __builtin_inff();
-        st_delta = 0.f;
-      }
+  // issue the cursor's tile into LDS buffer `buf`, fetch its row statistics, advance the cursor
+  auto stage_next = [&](int buf) {
+    if (stat_wave) {                             // raw loads only: the values are consumed by stage_stats, a tile later
+      const int r = pf_tile * kTile + lane;
+      st_in = r < p.Sq;                          // rows past the end: P = 0 (their Q / dO rows read as zero)
+      const int rc = st_in ? r : p.Sq - 1;
+      st_lse = lse_h[rc];
+      st_delta = dl_h[rc];
     }
-    ++pf_tile;
-    pf_p1 += tb1; pf_p2 += tb2; pf_rem1 -= tb1; pf_rem2 -= tb2;
-    if (heads_here > 1 && pf_tile == t_end) { ++pf_hh; pf_head(); }
-  };
-  auto stage_all = [&]() {
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       const int cidx = wave + NW * i;
       if (CHUNKS % NW == 0 || cidx < CHUNKS) {
-        USP_LDS char* d1 = smem + dma_buf * BUFB + cidx * 1024;
-        lds_dma16(rs1, d1, dma_voff1[i]);
-        lds_dma16(rs2, d1 + TILEB, dma_voff2[i]);
+        USP_LDS char* d1 = smem + buf * BUFB + cidx * 1024;
+        lds_dma16(rs1, d1, dma_voff1[i], soff1);
+        lds_dma16(rs2, d1 + TILEB, dma_voff2[i], soff2);
       }
     }
+    ++pf_tile;
+    soff1 += tb1;
+    soff2 += tb2;
+    if (heads_here > 1 && pf_tile == t_end) { ++pf_hh; pf_head(); }
   };
   auto stage_stats = [&](int buf) {
-    if (tid < kTile) {
-      *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * tid) = st_lse;
-      *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * kTile + 4 * tid) = st_delta;
-    }
+    if (stat_wave) {
+      const float l2 = (st_in && st_lse != USP_NEG_INF) ? st_lse * kLog2e : __builtin_inff();
+      *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * lane) = l2;
+      *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * kTile + 4 * lane) = st_in ? -st_delta : 0.f;   // NEGATED:
+    }                                                                          // role B folds it into the dP chain
   };
 
   // ---- per-lane LDS addresses ------------------------------------------------------------------------
@@ -736,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   const float c = p.scale_log2;
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
-  if (n_iter > 0) { stage_setup(0); stage_all(); stage_stats(0); }
+  if (n_iter > 0) { stage_next(0); stage_stats(0); }
   dma_drain();            // this wave's DMA pieces of the staged tile have landed (usp_common.hpp)
   __syncthreads();
 
@@ -753,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
     for (int it = 0; it <= n_iter; ++it) {
       const bool prefetch = it + 1 < n_iter;
       const int buf_n = buf_a + 1 == NBUF ? 0 : buf_a + 1;      // (it + 1) % NBUF
-      if (prefetch) { stage_setup(buf_n); stage_all(); }
+      if (prefetch) stage_next(buf_n);
 
       const int my_it = it - ROLE;
       const int buf_of_my = ROLE == 0 ? buf_a : buf_b;
@@ -1077,6 +1083,9 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   };
   if (!ok16(a->dout, 2) || !ok16(a->q, 2) || !ok16(a->k, 2) || !ok16(a->v, 2) || !ok32(a->dq) ||
       !ok32(a->dk) || !ok32(a->dv) || !okh(a->dq16) || !okh(a->dk16) || !okh(a->dv16))
+    return USP_EUNSUPPORTED;
+  // the dK/dV kernel addresses the Q / dO tiles of a head by a 32-bit byte offset from the head's first row
+  if ((int64_t)a->Sq * a->q.stride_s * 2 >= (1LL << 31) || (int64_t)a->Sq * a->dout.stride_s * 2 >= (1LL << 31))
     return USP_EUNSUPPORTED;
   BwdParams p;
   p.dout = (const char*)a->dout.ptr; p.q = (const char*)a->q.ptr;

@@ -45,15 +45,21 @@ class _Lane:
             self.main = torch.cuda.current_stream()
             self.side = _side_stream(ref.device, "ring" if safe_comm() else "ulysses")
 
-    def exchange(self, send: Tensor, group) -> tuple:
+    def exchange(self, send: Tensor, group, before=None) -> tuple:
         """Queue all_to_all_single(send) behind everything currently on the main stream; returns
-        (recv, event).  `send` must stay referenced until `wait` (the caller keeps it)."""
+        (recv, event).  `send` must stay referenced until `wait` (the caller keeps it).  `before(side_stream)`: work
+        to queue on the lane in front of the collective (it finishes filling `send` from data the MAIN stream does
+        not have to wait for: the ring backward's last dK/dV hop)."""
         if not self.cuda:
+            if before is not None:
+                before(None)
             return A._exchange(send, group, False), None
         ready = torch.cuda.Event()
         ready.record(self.main)
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
+            if before is not None:
+                before(self.side)
             recv = A._exchange(send, group, False)       # (module attribute: bench.py's overlap probe swaps it)
             done = torch.cuda.Event()
             done.record(self.side)
@@ -96,8 +102,8 @@ def pipeline_mode(ring_degree: int) -> bool:
         0     never: one packed exchange in front of the attention, one behind it;
         1     always, also beside a ring: two communicators (ulysses all-to-all, ring p2p) have kernels in flight at the
               same time, each on its own side stream, every rank issuing them in the same program order;
-        auto  (default) at ring degree 1 -- ONE communicator -- always; beside a ring only when USP_SAFE_COMM is not
-              set (see `_PIPELINE_BESIDE_RING_DEFAULT`)."""
+        auto  (default) everywhere, unless USP_SAFE_COMM=1 (then only at ring degree 1, where there is ONE communicator);
+              see `_PIPELINE_BESIDE_RING_DEFAULT`."""
     mode = _COMM_OVERRIDE.get("pipeline", os.environ.get("USP_PIPELINE_ULYSSES", "auto"))
     if mode == "0":
         return False
@@ -108,11 +114,14 @@ def pipeline_mode(ring_degree: int) -> bool:
     return _PIPELINE_BESIDE_RING_DEFAULT
 
 
-# The default beside a ring.  False until the two-communicator schedule has run on real multi-GPU RCCL or through the
-# RCCL virtual-grid test (tests/test_gpu_rccl_order.py::test_pipelined_exchange_beside_a_ring_through_rccl): round 2
-# had it on by default without either.  bench.py --gpus 8 measures BOTH modes (safe first, the
-# pipelined one under a deadline) and reports the faster, naming it.
-_PIPELINE_BESIDE_RING_DEFAULT = False
+# The default beside a ring.  Round 2 turned it on without any run through RCCL; round 3 first
+# built tests/test_gpu_rccl_order.py::test_pipelined_exchange_beside_a_ring_through_rccl -- BASELINE's 8-GPU grid
+# (ulysses 2 x ring 4, GQA, zigzag, forward + backward) and the 2 x 2 grids as virtual ranks whose every exchange and
+# every ring transfer is a real RCCL call, stream-ordered only, bit-identical over iterations and equal to the
+# reference's run -- and turned it on when that was green on an MI355X (gpurun_out/r03/5_rccl_order.log).  What the
+# test cannot show is two communicators across eight DEVICES: USP_SAFE_COMM=1 is the escape hatch, and bench.py
+# --gpus 8 measures the safe mode first and the overlapped mode under a deadline.
+_PIPELINE_BESIDE_RING_DEFAULT = True
 
 _MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer workgroups per launch)
 
@@ -222,6 +231,31 @@ def _to_heads_issue(lane, xs, P, group):
     return lane.exchange(send, group)
 
 
+def _grads_to_heads_issue(lane, dq, dk, dv, tail, P, group):
+    """ONE exchange dq | dk | dv of a head group back to sequence sharding, with the ring backward's LAST dK/dV hop
+    still in flight (`tail`: the pending RingComm of travel_dkdv's `defer`): dq is packed on the compute stream, which
+    then goes on to the next group's kernels; the lane waits for the hop, packs dk and dv behind it and runs the
+    collective.  What the compute stream used to wait for (16 MiB of fp32 per KV head over one link, 0.26 ms at 64 GB/s
+    per group at BASELINE's 8-GPU config) now runs beside the next group's first ring step."""
+    B, S, hq, D = dq.shape
+    kvh = dk.shape[2]
+    send = torch.empty((P, S // P, B, hq + 2 * kvh, D), dtype=dq.dtype, device=dq.device)
+    A.pack_seq_into(send, 0, dq)
+
+    def before(side):
+        for comm in tail:
+            comm.wait()                                  # stream-wise on a GPU: the LANE waits for the hop
+            if side is not None:
+                for t in getattr(comm, "keep", ()):      # the hop's send buffers: not to be reused before it is through
+                    t.record_stream(side)
+        if side is not None:
+            dk.record_stream(side)
+            dv.record_stream(side)
+        A.pack_seq_into(send, hq, dk)
+        A.pack_seq_into(send, hq + kvh, dv)
+    return lane.exchange(send, group, before)
+
+
 class _AsyncUSPFunc(torch.autograd.Function):
     """forward/backward of the USP layer with packed, optionally pipelined exchanges.  `ng_cap` = 1 keeps the
     sequential order (one packed exchange in, attention, one exchange out)."""
@@ -272,9 +306,10 @@ class _AsyncUSPFunc(torch.autograd.Function):
                 qi, ki, vi, oi, lse_i = saved[5 * i:5 * i + 5]
                 doi, ev = douts[i]
                 lane.wait(ev)
+                tail = []                      # the ring backward's last dK/dV hop, left pending (ring/utils.py:travel_dkdv)
                 dqi, dki, dvi = bwd(ring_pg, doi, qi, ki, vi, oi, lse_i, softmax_scale=softmax_scale,
-                                    causal=causal, overlap=overlap)
-                pend.append(_to_heads_issue(lane, [dqi, dki, dvi], P, ulysses_pg))   # ONE exchange: dq | dk | dv
+                                    causal=causal, overlap=overlap, tail=tail)
+                pend.append(_grads_to_heads_issue(lane, dqi, dki, dvi, tail, P, ulysses_pg))   # ONE exchange: dq | dk | dv
             dq = torch.empty((B, Sl, Hq, D), dtype=dout.dtype, device=dout.device)
             dk = torch.empty((B, Sl, Hkv, D), dtype=dout.dtype, device=dout.device)
             dv = torch.empty_like(dk)

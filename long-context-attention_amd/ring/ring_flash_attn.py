@@ -57,7 +57,7 @@ def ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, 
 def ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, softmax_scale,
                              dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
                              alibi_slopes=None, deterministic=False,
-                             attn_type: AttnType = AttnType.HIP, overlap=False):
+                             attn_type: AttnType = AttnType.HIP, overlap=False, tail=None):
     P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S, H, D = q.shape
@@ -80,7 +80,7 @@ def ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, sof
         be.add(dv_acc, dv_acc, dv_blk)
 
     # under causal only steps <= rank compute (:93-122)
-    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be,
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be, final_dtype=k.dtype, defer=tail,
                                  extent=lambda rank, step: None if (causal and step > rank) else FULL)
     return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 

@@ -82,7 +82,7 @@ def ring_flash_attn_varlen_backward(process_group, dout, q, k, v, out, softmax_l
         be.add(dk_acc, dk_acc, dk_blk)
         be.add(dv_acc, dv_acc, dv_blk)
 
-    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, zero=True, be=be,
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, zero=True, be=be, final_dtype=k.dtype,
                                  extent=lambda rank, step: None if (causal and step > rank) else FULL)
     return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 

@@ -70,7 +70,7 @@ def stripe_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0
 def stripe_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, softmax_scale,
                                dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
                                alibi_slopes=None, deterministic=False, attn_type: AttnType = AttnType.HIP,
-                               overlap=False):
+                               overlap=False, tail=None):
     assert causal, "stripe flash attn only supports causal attention, if not causal, ring flash attn instead"
     P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
@@ -93,7 +93,7 @@ def stripe_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, s
         stripe_bwd_fold(be, r, step, dk_acc, dv_acc, dk_blk, dv_blk)
 
     # steps > rank see k[:, :-1] only (:137-160, :179-181); a one-token shard has nothing to do there
-    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be,
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be, final_dtype=k.dtype, defer=tail,
                                  extent=lambda rank, step: FULL if step <= rank else (slice(0, S - 1) if S > 1 else None))
     return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 

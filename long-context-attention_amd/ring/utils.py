@@ -430,7 +430,13 @@ def dkdv_return_mode() -> str:
 FULL = slice(None)
 
 
-def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=None, be=None):
+def last_hop_16bit() -> bool:
+    """USP_DKDV_LAST_HOP=fp32 keeps the reference's fp32 payload on the last hop of the travelling dK/dV (A/B switch)."""
+    return os.environ.get("USP_DKDV_LAST_HOP", "16") != "fp32"
+
+
+def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=None, be=None, final_dtype=None,
+                defer=None):
     """The travelling dK/dV of every ring backward (zigzag_ring_flash_attn.py:139-183, ring_flash_attn.py:
     86-147): the fp32 accumulators of K/V block j visit every rank that attends to it, one hop per step,
     each rank adding its block result; after P hops they are back home.
@@ -444,16 +450,26 @@ def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=Non
             the K/V rows (dim 1) the block of `step` on ring rank `rank` carries gradients for (None: that step
             computes nothing there; FULL: all rows).  Given together with `be`, USP_DKDV_RETURN=direct is honoured
             (`return_dkdv_direct`).
+        final_dtype (with `be`): the LAST hop carries the accumulators already rounded to that 16-bit type.  Nothing is
+            added after the last hop -- the owner only rounds what arrives (the reference: `dk.to(q.dtype)`,
+            zigzag_ring_flash_attn.py:181-183) -- so rounding in front of the hop is bit-identical and halves the
+            one hop no kernel can hide (it follows the last step's kernels): 16 -> 8 MiB per KV head at BASELINE's
+            8-GPU config.  The function then returns the 16-bit tensors (final_grads passes them through).
+        defer: a list.  The wait for the last hop is NOT queued on the calling stream; the pending RingComm is appended
+            to `defer` and whoever consumes dK/dV calls its wait() on the consuming stream (the head-group pipeline
+            consumes it on the exchange lane, so the next group's kernels start behind this group's last kernels, not
+            behind its last hop).
 
     The hop of step s is posted from the compute stream right after the kernels of step s, and runs beside
     the kernels of step s+1.  `zero`: start every buffer from zeros (packed batches: the kernels do not touch
     rows outside every sequence's range, which would otherwise travel -- and be summed -- uninitialised).
-    Returns the final (dk, dv) fp32 accumulators."""
-    P = dist.get_world_size(process_group)
+    Returns the final (dk, dv): fp32 accumulators, or `final_dtype` tensors."""
+    P = group_info(dist, process_group)[0]
     if P > 1 and extent is not None and be is not None and dkdv_return_mode() == "direct":
         return return_dkdv_direct(process_group, k, v, block, extent, be, zero)
     new = (lambda t: torch.zeros(t.shape, dtype=torch.float32, device=t.device)) if zero else \
           (lambda t: torch.empty(t.shape, dtype=torch.float32, device=t.device))
+    round_last = P > 1 and be is not None and final_dtype is not None and final_dtype != torch.float32 and last_hop_16bit()
     dk_blk, dv_blk = new(k), new(v)
     d_comm = None
     dk_acc = dv_acc = next_dk = next_dv = None
@@ -469,12 +485,24 @@ def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=Non
                 dk_acc, dv_acc = next_dk, next_dv
                 if computed is not False:
                     fold(step, dk_acc, dv_acc, dk_blk, dv_blk)
+            if round_last and step == P - 1:        # the hop home: rounded here instead of at its destination
+                dk_acc, dv_acc = (_rounded(be, t, final_dtype) for t in (dk_acc, dv_acc))
             d_comm = RingComm(process_group)
             next_dk = d_comm.send_recv(dk_acc)
             next_dv = d_comm.send_recv(dv_acc)
             d_comm.commit()
-        d_comm.wait()
+        if defer is None or not round_last:      # (an fp32 arrival still has to be rounded on this stream)
+            d_comm.wait()
+        else:
+            d_comm.keep = (dk_acc, dv_acc)          # the send buffers live until the consumer has waited
+            defer.append(d_comm)
     return next_dk, next_dv
+
+
+def _rounded(be, acc, dtype):
+    out = torch.empty(acc.shape, dtype=dtype, device=acc.device)
+    be.cast(out, acc)
+    return out
 
 
 def return_dkdv_direct(process_group, k, v, block, extent, be, zero: bool = False):
@@ -535,9 +563,12 @@ def return_dkdv_direct(process_group, k, v, block, extent, be, zero: bool = Fals
 def final_grads(be, refs, accs):
     """16-bit gradients from the fp32 accumulators of a ring backward: fresh CONTIGUOUS tensors (the cast
     kernel takes rows; `empty_like` would inherit the seq-major strides the Ulysses exchange hands the ring
-    for batch > 1)."""
+    for batch > 1).  Accumulators that arrived rounded (travel_dkdv's `final_dtype`) pass through."""
     out = []
     for ref, acc in zip(refs, accs):
+        if acc.dtype == ref.dtype:
+            out.append(acc)
+            continue
         g = torch.empty(ref.shape, dtype=ref.dtype, device=ref.device)
         be.cast(g, acc)
         out.append(g)

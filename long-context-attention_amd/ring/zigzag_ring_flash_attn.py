@@ -140,7 +140,7 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
 def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, softmax_scale,
                                     dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
                                     alibi_slopes=None, deterministic=False,
-                                    attn_type: AttnType = AttnType.HIP, overlap=False):
+                                    attn_type: AttnType = AttnType.HIP, overlap=False, tail=None):
     assert causal == True, "zigzag ring is meaningless for causal=False"
     P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
@@ -163,7 +163,7 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
         zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk)
 
     # steps s <= rank carry gradients for the front-half K/V rows only (:151-155, :161-170)
-    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be,
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be, final_dtype=k.dtype, defer=tail,
                                  extent=lambda rank, step: slice(0, c) if step <= rank else FULL)
     return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 

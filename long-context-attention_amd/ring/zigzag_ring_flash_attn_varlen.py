@@ -112,7 +112,7 @@ def zigzag_ring_flash_attn_varlen_backward(process_group, dout, q, k, v, out, so
         be.add(dv_acc, dv_acc, dv_blk)
 
     # the front halves of a packed batch are not one row range: every block travels whole (zeros elsewhere)
-    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, zero=True, be=be,
+    dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, zero=True, be=be, final_dtype=k.dtype,
                                  extent=lambda rank, step: FULL)
     return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
 

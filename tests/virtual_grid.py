@@ -56,6 +56,8 @@ class VirtualGrid:
         self.ulysses = [Group("ulysses", [r * ud + u for u in range(ud)]) for r in range(rd)]
         self.ring = [Group("ring", [r * ud + u for r in range(rd)]) for u in range(ud)]
         self.calls = []                                         # (kind, first member) in issue order
+        self.issue = threading.Lock()                           # torch's coalescing manager keeps per-group global state:
+                                                                # one real grouped call at a time
 
     def groups_of(self, rank):
         return self.ulysses[rank // self.ud], self.ring[rank % self.ud]
@@ -98,7 +100,9 @@ class VirtualGrid:
                 ops = []
                 for src, dst in pairs:
                     ops += [self.d.P2POp(self.d.isend, src, 0), self.d.P2POp(self.d.irecv, dst, 0)]
-                for req in self.d.batch_isend_irecv(ops):
+                with self.issue:
+                    reqs = self.d.batch_isend_irecv(ops)
+                for req in reqs:
                     req.wait()
                 group.done = torch.cuda.Event()
                 group.done.record(cur)
