@@ -700,6 +700,8 @@ def main(argv=None, dev=None):
         sec = timed(step, args.steps, ws, dev, dms)
         return sec * 1e3, (round(dms[0], 4) if dms else None)
 
+    from yunchang_amd.comm import link as _link
+
     def make_line(ms, dms, comm_mode):
         value = flops / (ms * 1e-3) / 1e12
         if rank != 0:
@@ -715,6 +717,8 @@ def main(argv=None, dev=None):
                        "layer": "AsyncLongContextAttention" if args.async_ulysses else "LongContextAttention",
                        "ulysses_exchange": exchange_mode(attn, lq, lk, cfg, ws),
                        "comm_mode": comm_mode,
+                       "link_rate_GBs": round(_link.link_bytes_per_s() / 1e9, 1),
+                       "link_rate_source": "measured at set_seq_parallel_pg (comm/link.py)" if _link.measured() else "constant / USP_LINK_GBS",
                        "tokens_per_gpu": cfg["S"] * cfg["B"] // ws,
                        "assumed": "B=1 and causal=True where BASELINE.json's config string is silent",
                        "host": f"host-only work (gc.collect + gc.freeze, PMC lookup) first, then device work only: kernel "

@@ -61,6 +61,9 @@ def set_seq_parallel_pg(sp_ulysses_degree, sp_ring_degree, rank, world_size, use
 
     PROCESS_GROUP.ULYSSES_PG = ulysses_pg
     PROCESS_GROUP.RING_PG = ring_pg
+    # every rank is here by contract: the one collective moment to measure what the schedules size themselves by
+    from .comm.link import probe_link_rate
+    probe_link_rate(rank, world_size)
 
 
 # Feature flags of the reference (globals.py:83-135), kept so `from yunchang.globals import HAS_*`

@@ -19,6 +19,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from ..comm import all_to_all as A
+from ..comm.link import link_bytes_per_s
 from ..globals import PROCESS_GROUP
 from ..kernels import AttnType
 from ..ring.ring_flash_attn import ring_flash_attn_backward, ring_flash_attn_forward
@@ -142,7 +143,7 @@ _FILL_ITEMS_LINK_BOUND = 256
 # and four such groups put the iteration on the wire's floor (1.05 ms against 1.22 with two groups, tools/link_model.py).
 # Forward-only calls: the backward kernels have no such cut.
 _FILL_ITEMS_LINK_BOUND_KSPLIT = 128
-_LINK_BYTES_PER_S = 64e9      # one xGMI link, one direction (MI355X guide: 7 links x ~153 GB/s bidirectional per GPU)
+_LINK_BYTES_PER_S = None      # tests pin a rate here; otherwise comm/link.py: measured at set_seq_parallel_pg time, or 64 GB/s
 _KERNEL_FLOPS_PER_S = 1.1e15  # forward flash kernel on large launches (profiles/)
 
 
@@ -150,7 +151,7 @@ def _link_bound(Hq, Hkv, P, B, S, D, itemsize, ring, causal):
     """Is the Ulysses exchange of one forward pass at least half as long as the attention it surrounds?  Every rank
     sends 1/P of its local q|k|v to each of its P-1 peers over that peer's own link, and gets 1/P of the output back."""
     rows = B * (S // P)                                              # local rows before the exchange
-    t_comm = rows * (2 * Hq + 2 * Hkv) * D * itemsize / P / _LINK_BYTES_PER_S
+    t_comm = rows * (2 * Hq + 2 * Hkv) * D * itemsize / P / (_LINK_BYTES_PER_S or link_bytes_per_s())
     flops = 4.0 * B * (Hq // P) * S * (S * ring) * D * (0.5 if causal else 1.0)
     return t_comm >= 0.5 * flops / _KERNEL_FLOPS_PER_S
 

@@ -419,3 +419,23 @@ def test_host_launch_plumbing_without_a_device():
     assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
     a.k_splits, a.workspace = 9, base + 5 * 0x1000000
     assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
+
+
+def test_link_rate_probe_is_inert_without_rccl(monkeypatch):
+    """comm/link.py: the rate the head-group sizing uses is the 64 GB/s constant unless measured (RCCL, > 1 rank) or
+    pinned (USP_LINK_GBS); on gloo / one rank the probe does nothing (no collective is posted), and the figure feeds
+    `_link_bound` -- a fast link turns BASELINE's 2-GPU config from link-bound to attention-bound."""
+    from yunchang_amd.comm import link
+    from yunchang_amd.hybrid.async_attn_layer import _link_bound
+    monkeypatch.delenv("USP_LINK_GBS", raising=False)
+    monkeypatch.setattr(link, "_measured", None)
+    assert link.probe_link_rate(0, 1) is None and link.probe_link_rate(0, 8) is None and not link.measured()
+    assert link.link_bytes_per_s() == 64e9
+    assert _link_bound(16, 16, 2, 1, 16384, 128, 2, 1, True)
+    monkeypatch.setenv("USP_LINK_GBS", "400")
+    assert link.link_bytes_per_s() == 400e9 and not _link_bound(16, 16, 2, 1, 16384, 128, 2, 1, True)
+    monkeypatch.setenv("USP_LINK_GBS", "fast")                   # a typo falls back to the constant
+    assert link.link_bytes_per_s() == 64e9
+    monkeypatch.delenv("USP_LINK_GBS")
+    monkeypatch.setattr(link, "_measured", 90e9)
+    assert link.link_bytes_per_s() == 90e9
