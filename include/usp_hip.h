@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USP_ABI_VERSION 4
+#define USP_ABI_VERSION 5
 
 enum { USP_BF16 = 0, USP_FP16 = 1 };
 
@@ -47,6 +47,9 @@ enum {
  * on another stream gets its workgroups resident at once.  Use it whenever a transfer is meant to overlap
  * the kernel (ring steps, pipelined Ulysses exchange). */
 #define USP_LAUNCH_INTERLEAVE 1
+/* USP_ATTN_WINDOW (ABI v5): the window_left / window_right fields are valid (without the bit they are ignored, so a
+ * zero-initialised struct means "no window", not "window (0, 0)"). */
+#define USP_ATTN_WINDOW 2
 
 typedef struct usp_tensor {
   void* ptr;
@@ -112,6 +115,11 @@ typedef struct usp_fwd_args {
                                     (2..8; 0 or 1 = off); needs `workspace`, see usp_flash_fwd_workspace_bytes() */
   void* workspace;               /* device scratch of usp_flash_fwd_workspace_bytes(args, k_splits) bytes, 16-byte
                                     aligned; NULL = no split */
+  int32_t window_left, window_right; /* read only with USP_ATTN_WINDOW in `flags` (ABI v5): sliding-window (local)
+                                    attention as flash-attn defines it (kernels/attention.py:165-202 passes
+                                    `window_size` through): query row i sees key j iff
+                                    i + (Sk - Sq) - window_left <= j <= i + (Sk - Sq) + window_right; a negative value =
+                                    unbounded on that side; `causal` caps window_right at 0 */
 } usp_fwd_args;
 
 int usp_flash_fwd(const usp_fwd_args* args, void* stream);
@@ -170,16 +178,28 @@ typedef struct usp_bwd_args {
   const int32_t* seq_k;
   int64_t total_k;               /* packed mode: rows of the k/v/dk/dv token tensors (sizes the workspace) */
   int32_t* sched;                /* packed mode, optional: 64-byte device control block (as usp_fwd_args) */
-  int32_t flags;                 /* USP_LAUNCH_* bits */
+  int32_t flags;                 /* USP_LAUNCH_* / USP_ATTN_* bits */
+  int32_t dq_splits;             /* dense mode, optional (ABI v5): cut every (head, 256-row query block) item of the dQ
+                                    launch into this many items along the keys it sees (2..8; 0 / 1 = off) */
+  int32_t dkdv_splits;           /* ... and every (query head, 128-key block) item of the dK/dV launch along the query
+                                    rows that see it.  Both need `workspace`, see usp_flash_bwd_workspace_bytes() */
+  int32_t window_left, window_right; /* as usp_fwd_args; read only with USP_ATTN_WINDOW in `flags` */
 } usp_bwd_args;
 
 int usp_flash_bwd(const usp_bwd_args* args, void* stream);
 
-/* GQA (Hq > Hkv) only: bytes of scratch with which the dK/dV launch gives every query head of a KV
- * group its own workgroups (per-head fp32 partials + one deterministic reduce) instead of looping the
- * group inside one workgroup -- Hq/Hkv times more parallelism, which is what balances the causal
- * triangle when B*Hkv*ceil(Sk/128) is small.  Returns 0 when Hq == Hkv.  Passing less (or NULL) is
- * valid and selects the in-workgroup loop; results are identical up to fp32 summation order. */
+/* Bytes of scratch with which the backward launches get more, smaller work items (fp32 partials + one deterministic,
+ * HBM-bound reduce launch each; results identical up to fp32 summation order):
+ *   - GQA (Hq > Hkv): the dK/dV launch gives every query head of a KV group its own workgroups instead of looping the
+ *     group inside one workgroup -- Hq/Hkv times more parallelism, which is what balances the causal triangle when
+ *     B*Hkv*ceil(Sk/128) is small;
+ *   - dkdv_splits = n (ABI v5): every such item is cut into n items over equal runs of the query tiles that see its keys;
+ *   - dq_splits = n (ABI v5): every (head, 256-row query block) item of the dQ launch is cut into n items over equal runs
+ *     of the key tiles it sees -- for launches with few heads (a small head group, a high Ulysses degree), where a causal
+ *     launch otherwise lasts as long as its heaviest item.
+ * = 2 * (Hq/Hkv) * max(1, dkdv_splits) * rows_k * Hkv * D * 4  (0 when that is a single slab)
+ *   + dq_splits * B * Sq * Hq * D * 4                           (0 when dq_splits <= 1); the cuts are ignored for packed
+ * batches.  Passing less (or NULL) is valid and selects the in-workgroup loop without cuts. */
 int64_t usp_flash_bwd_workspace_bytes(const usp_bwd_args* args);
 
 /* delta[b,h,s] = sum_d dout[b,s,h,d] * out[b,s,h,d]   (fp32; delta is (B,H,S), seq stride 1).

@@ -19,7 +19,8 @@ _lib = None
 
 USP_BF16, USP_FP16 = 0, 1
 USP_LAUNCH_INTERLEAVE = 1      # include/usp_hip.h: launch so that collectives on other streams can slip in
-ABI_VERSION = 4
+USP_ATTN_WINDOW = 2            # the window_left / window_right fields are valid
+ABI_VERSION = 5
 
 
 class UspTensor(ctypes.Structure):
@@ -39,7 +40,8 @@ class UspFwdArgs(ctypes.Structure):
                 ("merge_in", ctypes.c_int32), ("final_begin", ctypes.c_int32),
                 ("final_end", ctypes.c_int32),
                 ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("sched", ctypes.c_void_p),
-                ("flags", ctypes.c_int32), ("k_splits", ctypes.c_int32), ("workspace", ctypes.c_void_p)]
+                ("flags", ctypes.c_int32), ("k_splits", ctypes.c_int32), ("workspace", ctypes.c_void_p),
+                ("window_left", ctypes.c_int32), ("window_right", ctypes.c_int32)]
 
 
 class UspBwdArgs(ctypes.Structure):
@@ -57,7 +59,9 @@ class UspBwdArgs(ctypes.Structure):
                 ("dq16", UspTensor), ("dk16", UspTensor), ("dv16", UspTensor),
                 ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
                 ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("total_k", ctypes.c_int64),
-                ("sched", ctypes.c_void_p), ("flags", ctypes.c_int32)]
+                ("sched", ctypes.c_void_p), ("flags", ctypes.c_int32),
+                ("dq_splits", ctypes.c_int32), ("dkdv_splits", ctypes.c_int32),
+                ("window_left", ctypes.c_int32), ("window_right", ctypes.c_int32)]
 
 
 EXPORTS = ("usp_flash_fwd", "usp_flash_fwd_workspace_bytes", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
@@ -199,6 +203,38 @@ def fwd_k_splits(B: int, Sq: int, Hq: int, causal: bool) -> int:
     if mode == "auto":
         return 0 if Sq < 4096 else (2 if items >= 256 else 4)
     return mode
+
+
+_BWD_SPLIT_MODE = _parse_ksplit(os.environ.get("USP_BWD_SPLIT"))      # same grammar as USP_FWD_KSPLIT
+
+
+def set_bwd_split(mode) -> object:
+    """Set the cut policy of dense backward launches ("auto" | 0 | n); returns the previous one."""
+    global _BWD_SPLIT_MODE
+    prev, _BWD_SPLIT_MODE = _BWD_SPLIT_MODE, _parse_ksplit(str(mode))
+    return prev
+
+
+def bwd_splits(B: int, Sq: int, Sk: int, Hq: int, causal: bool):
+    """(dq_splits, dkdv_splits) of a dense backward call (usp_bwd_args, ABI v5): the dQ launch has B*Hq*ceil(Sq/256) work
+    items and the dK/dV launch B*Hq*ceil(Sk/128) (one per query head and key block); with fewer than two per CU a
+    causal launch lasts as long as its heaviest item, with fewer than one per CU any launch leaves CUs idle -- such items
+    are cut (dQ along the keys, dK/dV along the query rows; partials + one reduce launch).  Measured on MI355X
+    (`kbench bwd` with USP_KBENCH_BWD_SPLITS, profiles/r03_kbench_bwd_cuts.log), B1 S16384 D128 causal: 2 query heads
+    394 -> 737 TFLOP/s at (4, 2), 4 heads 688 -> 808 at (2, 1); 8 heads (827) and 4 heads at S32768 (847) fill the part
+    and lose 3-6 % to any cut.  Policy (USP_BWD_SPLIT = auto | 0 | n, read at import): auto = per launch, n = 2 from
+    256 items up (causal only), 4 below; rows >= 4096 only."""
+    mode = _BWD_SPLIT_MODE
+    if mode == 0:
+        return 0, 0
+
+    def cuts(items, rows):
+        if rows < 4096 or items >= 512 or (items >= 256 and not causal):
+            return 0
+        if mode != "auto":
+            return mode
+        return 2 if items >= 256 else 4
+    return cuts(B * Hq * ((Sq + 255) // 256), Sq), cuts(B * Hq * ((Sk + 127) // 128), Sk)
 
 
 _TLS = threading.local()      # per-thread cache of filled argument blocks (the autograd thread launches too)
@@ -373,10 +409,10 @@ def bwd_delta(dout, out, delta):
 
 def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causal: bool,
               accum_dq=False, accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None,
-              interleave: bool = False):
+              interleave: bool = False, splits=None):
     """usp_flash_bwd.  dq/dk/dv are fp32 (B,S,H,D) views, written or accumulated; a 16-bit
     dq16/dk16/dv16 receives the FINAL rounded result instead (the fp32 tensor may then be None
-    unless it is accumulated from)."""
+    unless it is accumulated from).  `splits` = (dq_splits, dkdv_splits), None: bwd_splits decides."""
     _require_cuda(dout, q, k, v, lse, delta, dq, dk, dv, dq16, dk16, dv16)
     B, Sq, Hq, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
@@ -395,8 +431,9 @@ def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causa
     a.dq16, a.dk16, a.dv16 = _t4(dq16), _t4(dk16), _t4(dv16)
     a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
     a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
+    a.dq_splits, a.dkdv_splits = bwd_splits(B, Sq, Sk, Hq, bool(causal)) if splits is None else splits
     L = load()
-    need = L.usp_flash_bwd_workspace_bytes(ctypes.byref(a))     # > 0 only for GQA (head split)
+    need = L.usp_flash_bwd_workspace_bytes(ctypes.byref(a))     # GQA head split and / or cuts of few-item launches
     ws = None
     if need > 0:
         ws = torch.empty(need, dtype=torch.uint8, device=q.device)   # caching allocator; stream-ordered

@@ -403,14 +403,19 @@ static int run_bwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, in
   a.lse = dlse; a.delta = ddelta;
   a.lse_stride_b = a.delta_stride_b = (int64_t)Hq * Sq; a.lse_stride_h = a.delta_stride_h = Sq;
   a.dq = bshd(gdq, Sq, Hq, D); a.dk = bshd(gdk, Sk, Hkv, D); a.dv = bshd(gdv, Sk, Hkv, D);
+  if (const char* e = getenv("USP_KBENCH_BWD_SPLITS")) {           // "dq,dkdv": cuts of the two launches (ABI v5)
+    int x = 0, y = 0;
+    if (sscanf(e, "%d,%d", &x, &y) == 2) { a.dq_splits = x; a.dkdv_splits = y; }
+  }
   const int64_t wsb = getenv("USP_NO_WORKSPACE") ? 0 : usp_flash_bwd_workspace_bytes(&a);
   if (wsb > 0) { a.workspace = dev_alloc<char>((size_t)wsb); a.workspace_bytes = wsb; }
   rc |= usp_flash_bwd(&a, nullptr);
   if (rc) { printf("BWD launch failed: %s\n", usp_strerror(rc)); return 1; }
   HIP_OK(hipDeviceSynchronize());
   char tag[160];
-  snprintf(tag, sizeof tag, "bwd B%d Sq%d Sk%d Hq%d Hkv%d D%d %s %s", B, Sq, Sk, Hq, Hkv, D,
-           causal ? "causal" : "full", dt ? "fp16" : "bf16");
+  snprintf(tag, sizeof tag, "bwd B%d Sq%d Sk%d Hq%d Hkv%d D%d %s %s%s%s", B, Sq, Sk, Hq, Hkv, D,
+           causal ? "causal" : "full", dt ? "fp16" : "bf16", getenv("USP_KBENCH_BWD_SPLITS") ? " cuts " : "",
+           getenv("USP_KBENCH_BWD_SPLITS") ? getenv("USP_KBENCH_BWD_SPLITS") : "");
   int fail = 0;
   if (check) {
     std::vector<float> ro(nq), rl(nl), rdq(nq), rdk(nk), rdv(nk);
@@ -468,6 +473,12 @@ static int suite(bool with_bwd) {
                     {1, 384, 640, 4, 2, 64, 0, 1},  {1, 200, 333, 3, 1, 128, 1, 0}, {1, 333, 200, 2, 2, 64, 1, 0},
                     {2, 77, 77, 2, 2, 32, 1, 0},    {1, 1024, 1024, 8, 8, 64, 1, 0}};
     for (const C& c : bs) f += run_bwd(c.B, c.Sq, c.Sk, c.Hq, c.Hkv, c.D, c.causal, c.dt, 1, 0);
+    // cuts of few-item launches (ABI v5): every shape again with the dQ launch cut along K and the dK/dV launch along Q
+    for (const char* cuts : {"2,2", "3,4", "8,8", "4,1", "1,3"}) {
+      setenv("USP_KBENCH_BWD_SPLITS", cuts, 1);
+      for (const C& c : bs) f += run_bwd(c.B, c.Sq, c.Sk, c.Hq, c.Hkv, c.D, c.causal, c.dt, 1, 0);
+    }
+    unsetenv("USP_KBENCH_BWD_SPLITS");
   }
   printf("SUITE %s (%d failing groups)\n", f ? "FAIL" : "PASS", f);
   // timings at BASELINE shapes (C2 = B2 S8192 H16 D128 bf16 causal) and the C5 per-rank ring blocks

@@ -43,7 +43,12 @@ struct BwdParams {
   int64_t dq16_sb, dq16_ss, dq16_sh, dk16_sb, dk16_ss, dk16_sh, dv16_sb, dv16_ss, dv16_sh;
   float* ws_dk; float* ws_dv;        // head-split partials [G][ws_rows][Hkv][D] fp32 (G > 1)
   int64_t ws_rows;                    // key rows per head-group slab: B*Sk, packed mode: rows of k
-  int split;                          // 1: one workgroup per (query head, key block)
+  int split;                          // 1: one workgroup per (query head, key block), partials to the workspace
+  int qsplit;                         // dK/dV launch: every (head, key block) item is cut into this many items over equal
+                                      // runs of the query tiles it sees (>= 1; > 1 only with `split`)
+  int ksplit;                         // dQ launch: every (head, query block) item is cut along the key tiles it sees
+  int nslab;                          // dK/dV partial slabs the reduce sums: (split ? G : 1) * qsplit
+  float* ws_dq;                       // dQ partials [ksplit][B*Sq][Hq][D] fp32 (ksplit > 1)
   const int* seq_q; const int* seq_k; // packed variable-length batch: B (first row, rows) pairs, or NULL
   int* sched;                         // packed mode: control block of the dynamic item queue, or NULL
   int sched_lds;                      // byte offset of the queue's two LDS slots
@@ -120,9 +125,10 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   if (!p_in.sched) w = walk.dealt(w, p.nblk);
   const int blk_r = w % p.nblk;
   int rest = w / p.nblk;
-  int b, hkv, h0, blk, split_g = 0;
+  int b, hkv, h0, blk, split_g = 0, cut = 0;
   if (MODE == 0) {
     blk = CAUSAL ? (p.nblk - 1 - blk_r) : blk_r;          // late query blocks see most keys
+    if (p.ksplit > 1) { cut = rest % p.ksplit; rest /= p.ksplit; }
     const int g = rest % p.G; rest /= p.G;
     hkv = rest % p.Hkv; b = rest / p.Hkv;
     h0 = hkv * p.G + g;
@@ -183,6 +189,11 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
       t_begin = first_q / kTile;
       if (t_begin > t_end) t_begin = t_end;
     }
+  }
+  if (MODE == 0 && p.ksplit > 1) {             // this item's cut of the key tiles [0, t_end): equal runs
+    const int per = (t_end + p.ksplit - 1) / p.ksplit;
+    t_begin = cut * per < t_end ? cut * per : t_end;
+    t_end = t_begin + per < t_end ? t_begin + per : t_end;
   }
   const int per_head = t_end - t_begin;
   const int n_iter = (MODE == 0 || p.split) ? per_head : per_head * p.G;
@@ -521,7 +532,9 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
     float* o1; float* o2 = nullptr;
     char* h1 = nullptr; char* h2 = nullptr;      // 16-bit final destinations (row base), if any
     int acc_f1, acc_f2 = 0;
-    if (MODE == 0) {
+    if (MODE == 0 && p.ksplit > 1) {   // partial of this cut, combined (deterministically) by reduce_cuts_kernel
+      o1 = p.ws_dq + ((((int64_t)cut * p.B + b) * p.Sq + orow) * p.Hq + h0) * D; acc_f1 = 0;
+    } else if (MODE == 0) {
       o1 = p.dq + b * p.dq_sb + (int64_t)orow * p.dq_ss + h0 * p.dq_sh; acc_f1 = p.accum_dq;
       if (p.dq16) h1 = p.dq16 + 2 * (b * p.dq16_sb + (int64_t)orow * p.dq16_ss + h0 * p.dq16_sh);
     } else {
@@ -616,8 +629,9 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   if (!p_in.sched) w = walk.dealt(w, p.nblk);
   const int blk = w % p.nblk;                    // early key blocks are seen by most rows: first
   int rest = w / p.nblk;
-  int g = 0;
-  if (p.split) { g = rest % p.G; rest /= p.G; }
+  int g = 0, cut = 0;
+  if (p.qsplit > 1) { cut = rest % p.qsplit; rest /= p.qsplit; }
+  if (p.split && p.G > 1) { g = rest % p.G; rest /= p.G; }
   const int hkv = rest % p.Hkv, b = rest / p.Hkv;
   const int h0 = hkv * p.G + g;
   int64_t ws_row0;
@@ -643,6 +657,11 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
     const int first_q = own0 - off > 0 ? own0 - off : 0;
     t_begin = first_q / kTile;
     if (t_begin > t_end) t_begin = t_end;
+  }
+  if (p.qsplit > 1) {                            // this item's cut of the query tiles [t_begin, t_end): equal runs
+    const int per = (t_end - t_begin + p.qsplit - 1) / p.qsplit;
+    t_begin = t_begin + cut * per < t_end ? t_begin + cut * per : t_end;
+    t_end = t_begin + per < t_end ? t_begin + per : t_end;
   }
   const int per_head = t_end - t_begin;
   const int heads_here = p.split ? 1 : p.G;
@@ -978,7 +997,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
     int accf;
     const float mul = role == 0 ? 1.f : p.scale;
     if (p.split) {
-      const int64_t wo = (((int64_t)g * p.ws_rows + ws_row0 + orow) * p.Hkv + hkv) * D;
+      const int64_t wo = (((int64_t)(g * p.qsplit + cut) * p.ws_rows + ws_row0 + orow) * p.Hkv + hkv) * D;
       o32 = (role == 0 ? p.ws_dv : p.ws_dk) + wo; accf = 0;
     } else if (role == 0) {
       o32 = p.dv + b * p.dv_sb + (int64_t)orow * p.dv_ss + hkv * p.dv_sh; accf = p.accum_dv;
@@ -1032,7 +1051,7 @@ __global__ __launch_bounds__(256) void reduce_heads_kernel(const BwdParams p) {
     f32x4 ak = p.accum_dk ? *(const f32x4*)pk : f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 av = p.accum_dv ? *(const f32x4*)pv : f32x4{0.f, 0.f, 0.f, 0.f};
     const int64_t o = (wrow * H + h) * D + e;
-    for (int g = 0; g < p.G; ++g) {
+    for (int g = 0; g < p.nslab; ++g) {
       ak += *(const f32x4*)(p.ws_dk + g * gstride + o);
       av += *(const f32x4*)(p.ws_dv + g * gstride + o);
     }
@@ -1051,6 +1070,33 @@ __global__ __launch_bounds__(256) void reduce_heads_kernel(const BwdParams p) {
   }
 }
 
+// dq[b,s,h,:] (+)= sum_cut ws_dq[cut][b][s][h][:]   -- combines the dQ partials of a key-cut launch (dense only).
+template <int D, int DT>
+__global__ __launch_bounds__(256) void reduce_cuts_kernel(const BwdParams p) {
+  using E = Elem<DT>;
+  constexpr int C4 = D / 4;
+  const int64_t total = (int64_t)p.B * p.Sq * p.Hq * C4;
+  const int64_t cstride = (int64_t)p.B * p.Sq * p.Hq * D;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c4 = (int)(i % C4);
+    int64_t r = i / C4;
+    const int h = (int)(r % p.Hq); r /= p.Hq;
+    const int sidx = (int)(r % p.Sq);
+    const int b = (int)(r / p.Sq);
+    const int64_t e = 4 * c4;
+    float* pq = p.dq ? p.dq + b * p.dq_sb + (int64_t)sidx * p.dq_ss + h * p.dq_sh + e : nullptr;
+    f32x4 a = p.accum_dq ? *(const f32x4*)pq : f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t o = (((int64_t)b * p.Sq + sidx) * p.Hq + h) * D + e;
+    for (int c = 0; c < p.ksplit; ++c) a += *(const f32x4*)(p.ws_dq + c * cstride + o);
+    if (p.dq16) {
+      char* hq = p.dq16 + 2 * (b * p.dq16_sb + (int64_t)sidx * p.dq16_ss + h * p.dq16_sh + e);
+      *(u32x2*)hq = u32x2{E::pack2(a[0], a[1]), E::pack2(a[2], a[3])};
+    } else {
+      *(f32x4*)pq = a;
+    }
+  }
+}
+
 template <int D, int DT>
 static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   constexpr size_t lds0 = 2 * (2 * kTile * D * 2);
@@ -1065,7 +1111,7 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   }();
   static const bool persist = [] { const char* e = getenv("USP_BWD_PERSIST"); return !(e && e[0] == '0'); }();
   p.nblk = (p.Sk + 127) / 128;
-  p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1);
+  p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1) * p.qsplit;
   const bool pers = (persist || p.sched) && !p.interleave;
   int grid = (pers && p.n_items > cus) ? cus : p.n_items;
   const size_t qx = p.sched ? 16 : 0;            // LDS for the item queue's two slots
@@ -1096,13 +1142,20 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   }
   // dQ
   p.nblk = (p.Sq + 255) / 256;
-  p.n_items = p.B * p.Hq * p.nblk;
+  p.n_items = p.B * p.Hq * p.nblk * p.ksplit;
   grid = (pers && p.n_items > cus) ? cus : p.n_items;
   p.sched_lds = (int)lds0;
   if (causal)
     hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 0>), dim3(grid), dim3(512), lds0 + qx, st, p);
   else
     hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 0>), dim3(grid), dim3(512), lds0 + qx, st, p);
+  if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
+  if (p.ksplit > 1) {            // same stream: the partials are complete when this starts
+    const int64_t items = (int64_t)p.B * p.Sq * p.Hq * (D / 4);
+    int64_t rg = (items + 255) / 256;
+    rg = rg > 2048 ? 2048 : rg;
+    hipLaunchKernelGGL((reduce_cuts_kernel<D, DT>), dim3((int)rg), dim3(256), 0, st, p);
+  }
   return hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
 }
 
@@ -1118,9 +1171,19 @@ static int64_t ws_rows_of(const usp_bwd_args* a) {
   return (a->seq_q || a->seq_k) ? a->total_k : (int64_t)a->B * a->Sk;
 }
 
+static int cuts_of(int32_t n, bool packed) { return (packed || n < 2) ? 1 : (n > 8 ? 8 : n); }
+
+// [dK partials | dV partials | dQ partials]: (G * dkdv_splits) slabs of ws_rows x Hkv x D each for dK and for dV (none when
+// there is one slab: Hq == Hkv and no cut), dq_splits slabs of B x Sq x Hq x D for dQ (none without a cut)
+static int64_t dkdv_part_bytes(const usp_bwd_args* a) {
+  const int64_t slabs = (int64_t)(a->Hq / a->Hkv) * cuts_of(a->dkdv_splits, a->seq_q || a->seq_k);
+  return slabs > 1 ? 2 * slabs * ws_rows_of(a) * a->Hkv * a->D * 4 : 0;
+}
+
 extern "C" int64_t usp_flash_bwd_workspace_bytes(const usp_bwd_args* a) {
-  if (!a || a->Hkv <= 0 || a->Hq <= a->Hkv || a->Hq % a->Hkv != 0) return 0;
-  return 2LL * a->Hq / a->Hkv * ws_rows_of(a) * a->Hkv * a->D * 4;   // dK and dV partials, fp32
+  if (!a || a->Hkv <= 0 || a->Hq < a->Hkv || a->Hq % a->Hkv != 0) return 0;
+  const int nq = cuts_of(a->dq_splits, a->seq_q || a->seq_k);
+  return dkdv_part_bytes(a) + (nq > 1 ? (int64_t)nq * a->B * a->Sq * a->Hq * a->D * 4 : 0);
 }
 
 extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
@@ -1147,6 +1210,9 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   if (!ok16(a->dout, 2) || !ok16(a->q, 2) || !ok16(a->k, 2) || !ok16(a->v, 2) || !ok32(a->dq) ||
       !ok32(a->dk) || !ok32(a->dv) || !okh(a->dq16) || !okh(a->dk16) || !okh(a->dv16))
     return USP_EUNSUPPORTED;
+  if ((a->flags & USP_ATTN_WINDOW) && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)))
+    return USP_EUNSUPPORTED;                      // sliding windows: not in this build's backward
+  if (a->dq_splits < 0 || a->dq_splits > 8 || a->dkdv_splits < 0 || a->dkdv_splits > 8) return USP_EINVAL;
   // the dK/dV kernel addresses the Q / dO tiles of a head by a 32-bit byte offset from the head's first row
   if ((int64_t)a->Sq * a->q.stride_s * 2 >= (1LL << 31) || (int64_t)a->Sq * a->dout.stride_s * 2 >= (1LL << 31))
     return USP_EUNSUPPORTED;
@@ -1185,13 +1251,22 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
     p.do_sb = p.q_sb = p.k_sb = p.v_sb = p.lse_sb = p.dl_sb = 0;
     p.dq_sb = p.dk_sb = p.dv_sb = p.dq16_sb = p.dk16_sb = p.dv16_sb = 0;
   }
+  // Workspace present and large enough: GQA head split and / or the requested cuts; otherwise neither (the in-workgroup
+  // loop over the group's heads, one item per block) -- results are identical up to fp32 summation order either way.
   const int64_t need = usp_flash_bwd_workspace_bytes(a);
-  p.split = 0; p.ws_dk = nullptr; p.ws_dv = nullptr;
+  p.split = 0; p.qsplit = 1; p.ksplit = 1; p.nslab = 1; p.ws_dk = nullptr; p.ws_dv = nullptr; p.ws_dq = nullptr;
   if (need > 0 && a->workspace && a->workspace_bytes >= need &&
       (reinterpret_cast<uintptr_t>(a->workspace) & 15) == 0) {
-    p.split = 1;
-    p.ws_dk = (float*)a->workspace;
-    p.ws_dv = p.ws_dk + need / 8;
+    const int64_t part = dkdv_part_bytes(a);
+    if (part > 0) {
+      p.split = 1;
+      p.qsplit = cuts_of(a->dkdv_splits, packed);
+      p.nslab = p.G * p.qsplit;
+      p.ws_dk = (float*)a->workspace;
+      p.ws_dv = p.ws_dk + part / 8;
+    }
+    p.ksplit = cuts_of(a->dq_splits, packed);
+    if (p.ksplit > 1) p.ws_dq = (float*)((char*)a->workspace + part);
   }
   hipStream_t st = (hipStream_t)stream;
   const bool causal = a->causal != 0;

@@ -772,6 +772,8 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
     return USP_EUNSUPPORTED;
   const bool packed = a->seq_q != nullptr || a->seq_k != nullptr;
   if (packed && !(a->seq_q && a->seq_k)) return USP_EINVAL;
+  if ((a->flags & USP_ATTN_WINDOW) && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)))
+    return USP_EUNSUPPORTED;                      // sliding windows: not in this build's forward
   const int f_all = packed ? 2 : a->Sq;          // packed: final_begin/_end count half sequences (0,1,2)
   int fb = a->final_begin < 0 ? 0 : a->final_begin;
   int fe = a->final_end > f_all ? f_all : a->final_end;

@@ -958,3 +958,51 @@ def test_seq64k_sampled_parity_through_bench(dev):
     err = b.sampled_parity(t["tensors"])["max_abs_err"]
     assert err["out"] < 2e-2 and err["lse"] < 2e-3, err
     assert err["dq"] < 5e-2 and err["dk"] < 5e-2 * 8 ** 0.5 and err["dv"] < 5e-2 * 8 ** 0.5, err       # grad_tol: G = 8
+
+
+@pytest.mark.parametrize("B,Sq,Sk,Hq,Hkv,D,causal,dt", [(1, 1024, 1024, 2, 2, 128, True, "bfloat16"),
+                                                        (2, 300, 712, 4, 2, 64, False, "float16"),
+                                                        (1, 333, 200, 2, 1, 128, True, "bfloat16"),
+                                                        (1, 4096, 4096, 2, 1, 128, True, "bfloat16")])
+def test_backward_cuts_through_the_binding(dev, B, Sq, Sk, Hq, Hkv, D, causal, dt):
+    """usp_bwd_args.dq_splits / dkdv_splits (ABI v5) through _C.flash_bwd (workspace from torch): every cut against the
+    uncut launch (fp32 summation order is all that differs), the uncut launch against the oracle; fp32 outputs with an
+    accumulated dq, and 16-bit final outputs.  The default policy must pick cuts for the few-head long shape."""
+    from yunchang_amd import _C
+    q, k, v, do = (_rand(s, dt, 80 + i) for i, s in enumerate([(B, Sq, Hq, D), (B, Sk, Hkv, D), (B, Sk, Hkv, D), (B, Sq, Hq, D)]))
+    tq, tk, tv, tdo = (_t(x, dt, dev) for x in (q, k, v, do))
+    scale = D ** -0.5
+    out = torch.empty_like(tq)
+    lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=dev)
+    _C.flash_fwd(tq, tk, tv, scale, causal, lse, out)
+    delta = torch.empty_like(lse)
+    _C.bwd_delta(tdo, out, delta)
+    ro, rl = O.attention_ref(q, k, v, causal=causal)
+    refs = O.block_bwd(do, q, k, v, ro, rl, None, causal)
+    tdt = getattr(torch, dt)
+
+    def run(splits, final16):
+        if final16:
+            g = [torch.full(t.shape, float("nan"), dtype=tdt, device=dev) for t in (tq, tk, tv)]
+            _C.flash_bwd(tdo, tq, tk, tv, lse, delta, None, None, None, scale, causal, dq16=g[0], dk16=g[1], dv16=g[2],
+                         splits=splits)
+            return [_f(t) for t in g]
+        dq = torch.ones((B, Sq, Hq, D), dtype=torch.float32, device=dev)            # accumulated onto
+        dk = torch.full((B, Sk, Hkv, D), float("nan"), dtype=torch.float32, device=dev)
+        dv = torch.full_like(dk, float("nan"))
+        _C.flash_bwd(tdo, tq, tk, tv, lse, delta, dq, dk, dv, scale, causal, accum_dq=True, splits=splits)
+        return [_f(dq) - 1.0, _f(dk), _f(dv)]
+
+    atol, rtol = grad_tol(dt, Hq // Hkv)
+    for final16 in (False, True):
+        base = run((0, 0), final16)
+        for got, ref, name in zip(base, refs, ("dq", "dk", "dv")):
+            assert_close(got, ref, atol, rtol, f"uncut {name} final16={final16}")
+        for splits in ((2, 2), (3, 4), (8, 8), (4, 1), (1, 3)):
+            for got, b0, name in zip(run(splits, final16), base, ("dq", "dk", "dv")):
+                assert np.isfinite(got).all(), f"{name} cuts {splits}"
+                assert_close(got, b0, atol, rtol, f"{name} cuts {splits} final16={final16}")
+    if Sq == 4096:
+        assert _C.bwd_splits(B, Sq, Sk, Hq, causal) == (4, 4)        # 32 / 64 items: the policy cuts this launch
+        for got, ref, name in zip(run(None, True), refs, ("dq", "dk", "dv")):
+            assert_close(got, ref, atol, rtol, f"default policy {name}")

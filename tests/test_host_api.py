@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libusp_hip.so does not export {name}"
     assert set(_C.EXPORTS) == declared
     L = _C.load()
-    assert L.usp_abi_version() == _C.ABI_VERSION == 4
+    assert L.usp_abi_version() == _C.ABI_VERSION == 5
     assert b"head_dim" in L.usp_strerror(-2)
 
 
@@ -439,3 +439,33 @@ def test_link_rate_probe_is_inert_without_rccl(monkeypatch):
     monkeypatch.delenv("USP_LINK_GBS")
     monkeypatch.setattr(link, "_measured", 90e9)
     assert link.link_bytes_per_s() == 90e9
+
+
+def test_backward_cut_workspace_and_policy(monkeypatch):
+    """ABI v5's cuts of few-item backward launches: the workspace size the C side asks for (host code, no GPU), the
+    argument checks that need no launch, and the policy of the Python binding."""
+    import ctypes
+    L = _C.load()
+    a = _C.UspBwdArgs()
+    a.B, a.Sq, a.Sk, a.Hq, a.Hkv, a.D = 2, 300, 712, 4, 2, 64
+    kv_slab, q_slab = 2 * 712 * 2 * 64 * 4, 2 * 300 * 4 * 64 * 4
+    need = lambda: L.usp_flash_bwd_workspace_bytes(ctypes.byref(a))
+    assert need() == 2 * 2 * kv_slab                                 # GQA head split alone: G = 2 slabs for dK and for dV
+    a.dkdv_splits = 3
+    assert need() == 2 * 6 * kv_slab
+    a.dq_splits = 4
+    assert need() == 2 * 6 * kv_slab + 4 * q_slab
+    a.dkdv_splits, a.Hq = 1, 2                                       # MHA, no cut of the dK/dV launch: only dQ partials
+    assert need() == 4 * (2 * 300 * 2 * 64 * 4)
+    a.dq_splits = 0
+    assert need() == 0
+    a.dq_splits, a.seq_q = 4, 8                                      # packed batches are not cut
+    assert need() == 0
+    # the policy
+    monkeypatch.setattr(_C, "_BWD_SPLIT_MODE", "auto")
+    assert _C.bwd_splits(1, 16384, 16384, 2, True) == (4, 2) and _C.bwd_splits(1, 16384, 16384, 4, True) == (2, 0)
+    assert _C.bwd_splits(1, 16384, 16384, 8, True) == (0, 0) and _C.bwd_splits(2, 8192, 8192, 16, True) == (0, 0)
+    assert _C.bwd_splits(1, 8192, 16384, 8, False) == (0, 0)        # a ring step of BASELINE's 8-GPU rank: 256 / 1024 items
+    assert _C.bwd_splits(1, 2048, 2048, 2, True) == (0, 0)          # short: nothing to balance
+    assert _C.set_bwd_split(0) == "auto" and _C.bwd_splits(1, 16384, 16384, 2, True) == (0, 0)
+    assert _C.set_bwd_split("auto") == 0
