@@ -337,7 +337,9 @@ def pmc_traffic():
     correction + WRITE_SIZE, separate passes, C2 shape).  Hardware counters cannot be collected from inside
     this process, so the numbers come from profiles/r02_rocprof_summary.txt -- but ONLY if that profile was
     taken from the kernel sources of this tree (the summary carries their hash); otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r02_rocprof_summary.txt")
+    name = next((n for n in ("r03_rocprof_summary.txt", "r02_rocprof_summary.txt")
+                 if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_rocprof_summary.txt")
+    path = os.path.join(ROOT, "profiles", name)
     try:
         rd = wr = sha = isa = None
         for ln in open(path):
@@ -352,7 +354,7 @@ def pmc_traffic():
         if rd is None or wr is None:
             return None
         res = {"read_MB": rd, "write_MB": wr, "algorithmic_MB": 268.4, "kernel_src_sha16": sha,
-               "source": "profiles/r02_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources)"}
+               "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources)"}
         if sha == kernel_source_sha16():
             return res
         # The sources have changed since the profile.  The figures still describe THIS library if the profiled kernel's
@@ -365,14 +367,14 @@ def pmc_traffic():
         except Exception as e:                                   # no llvm-objdump, unreadable library ...
             mine = f"unavailable ({repr(e)[:80]})"
         if isa is not None and mine == isa:
-            res["source"] = ("profiles/r02_rocprof_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE); the sources have "
+            res["source"] = (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE); the sources have "
                              "changed since, the machine code of the profiled kernel has not (tools/kernel_isa.py)")
             res["roofline_kernel_isa_sha16"] = isa
             res["kernel_src_sha16_now"] = kernel_source_sha16()
             return res
         # a stale number is worse than none: report where the last measurement is and what it was taken from
         return {"read_MB": None, "write_MB": None, "algorithmic_MB": 268.4, "kernel_src_sha16": kernel_source_sha16(),
-                "stale": f"profiles/r02_rocprof_summary.txt holds {rd} MB read + {wr} MB written per launch, taken from "
+                "stale": f"profiles/{name} holds {rd} MB read + {wr} MB written per launch, taken from "
                          f"kernel sources {sha} (kernel machine code {isa}); this library's: {mine} -- no figure is claimed"}
     except OSError:
         return None

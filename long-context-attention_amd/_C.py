@@ -245,13 +245,21 @@ def _strides(t):
     return None if t is None else t.stride()
 
 
-def _fwd_args(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end, interleave, n):
+def _window(window):
+    """flash-attn's `window_size` -> (left, right) ints, or None for no window ((-1, -1) / None)."""
+    if window is None:
+        return None
+    wl, wr = int(window[0]), int(window[1])
+    return None if (wl < 0 and wr < 0) else (wl, wr)
+
+
+def _fwd_args(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end, interleave, n, window=None):
     """The filled usp_fwd_args block of a dense launch.  Everything but the seven pointers is a function of
     (dtype, shapes, strides, flags), and a training loop issues the same few launches over and over: the block is
     cached per thread under that signature and only the pointers are patched (filling 27 ctypes fields and five
     usp_tensor structs costs ~35 us of host time per launch, tools/host_step_cpu.py; a hit costs ~8)."""
     key = (q.dtype, q.shape, q.stride(), k.shape, k.stride(), v.stride(), lse.stride(), _strides(out), _strides(acc),
-           softmax_scale, causal, merge_in, final_begin, final_end, interleave, n)
+           softmax_scale, causal, merge_in, final_begin, final_end, interleave, n, window)
     cache = _TLS.__dict__.setdefault("fwd", {})
     a = cache.get(key)
     if a is None:
@@ -267,6 +275,9 @@ def _fwd_args(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_beg
         a.final_begin = final_begin
         a.final_end = Sq if final_end is None else final_end
         a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
+        if window is not None:
+            a.flags |= USP_ATTN_WINDOW
+            a.window_left, a.window_right = window
         a.k_splits = n if n > 1 else 0
         if len(cache) >= _ARGS_CACHE_MAX:
             cache.clear()
@@ -280,15 +291,16 @@ def _fwd_args(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_beg
 
 def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=None,
               merge_in: bool = False, final_begin: int = 0, final_end: Optional[int] = None,
-              interleave: bool = False, k_splits: Optional[int] = None):
+              interleave: bool = False, k_splits: Optional[int] = None, window=None):
     """usp_flash_fwd (include/usp_hip.h).  q (B,Sq,Hq,D); k,v (B,Sk,Hkv,D); lse (B,Hq,Sq) fp32;
     out 16-bit / acc fp32 (B,Sq,Hq,D).  All may be strided views (unit dim stride).  `k_splits`: cut the keys of
-    every query tile into that many work items (None: fwd_k_splits decides; 0 / 1: off)."""
+    every query tile into that many work items (None: fwd_k_splits decides; 0 / 1: off).  `window` = flash-attn's
+    window_size (left, right), None / (-1, -1) = none."""
     _require_cuda(q, k, v, lse, out, acc)
     B, Sq, Hq, D = q.shape
     n = fwd_k_splits(B, Sq, Hq, causal) if k_splits is None else int(k_splits)
     a = _fwd_args(q, k, v, softmax_scale, bool(causal), lse, out, acc, bool(merge_in), final_begin, final_end,
-                  bool(interleave), n)
+                  bool(interleave), n, _window(window))
     L = load()
     if n > 1:
         # scratch for the partial results: one buffer per (device, stream), grown on demand; launches on one stream
@@ -409,10 +421,11 @@ def bwd_delta(dout, out, delta):
 
 def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causal: bool,
               accum_dq=False, accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None,
-              interleave: bool = False, splits=None):
+              interleave: bool = False, splits=None, window=None):
     """usp_flash_bwd.  dq/dk/dv are fp32 (B,S,H,D) views, written or accumulated; a 16-bit
     dq16/dk16/dv16 receives the FINAL rounded result instead (the fp32 tensor may then be None
-    unless it is accumulated from).  `splits` = (dq_splits, dkdv_splits), None: bwd_splits decides."""
+    unless it is accumulated from).  `splits` = (dq_splits, dkdv_splits), None: bwd_splits decides.  `window` =
+    flash-attn's window_size (left, right), None / (-1, -1) = none."""
     _require_cuda(dout, q, k, v, lse, delta, dq, dk, dv, dq16, dk16, dv16)
     B, Sq, Hq, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
@@ -432,6 +445,10 @@ def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causa
     a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
     a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
     a.dq_splits, a.dkdv_splits = bwd_splits(B, Sq, Sk, Hq, bool(causal)) if splits is None else splits
+    win = _window(window)
+    if win is not None:
+        a.flags |= USP_ATTN_WINDOW
+        a.window_left, a.window_right = win
     L = load()
     need = L.usp_flash_bwd_workspace_bytes(ctypes.byref(a))     # GQA head split and / or cuts of few-item launches
     ws = None

@@ -49,6 +49,9 @@ struct BwdParams {
   int ksplit;                         // dQ launch: every (head, query block) item is cut along the key tiles it sees
   int nslab;                          // dK/dV partial slabs the reduce sums: (split ? G : 1) * qsplit
   float* ws_dq;                       // dQ partials [ksplit][B*Sq][Hq][D] fp32 (ksplit > 1)
+  int win_on, win_lo;                 // sliding window, left bound (ABI v5): query row i sees key j only if
+                                      // j >= i + win_lo (= Sk - Sq - window_left); the right bound is the causal limit
+                                      // with a shifted offset (causal_off = Sk - Sq + window_right)
   const int* seq_q; const int* seq_k; // packed variable-length batch: B (first row, rows) pairs, or NULL
   int* sched;                         // packed mode: control block of the dynamic item queue, or NULL
   int sched_lds;                      // byte offset of the queue's two LDS slots
@@ -190,9 +193,14 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
       if (t_begin > t_end) t_begin = t_end;
     }
   }
-  if (MODE == 0 && p.ksplit > 1) {             // this item's cut of the key tiles [0, t_end): equal runs
-    const int per = (t_end + p.ksplit - 1) / p.ksplit;
-    t_begin = cut * per < t_end ? cut * per : t_end;
+  if (MODE == 0 && p.win_on) {                 // key tiles left of the window of the block's first row: not streamed
+    const int first = own0 + p.win_lo;
+    t_begin = first > 0 ? first / kTile : 0;
+    if (t_begin > t_end) t_begin = t_end;
+  }
+  if (MODE == 0 && p.ksplit > 1) {             // this item's cut of the key tiles [t_begin, t_end): equal runs
+    const int per = (t_end - t_begin + p.ksplit - 1) / p.ksplit;
+    t_begin = t_begin + cut * per < t_end ? t_begin + cut * per : t_end;
     t_end = t_begin + per < t_end ? t_begin + per : t_end;
   }
   const int per_head = t_end - t_begin;
@@ -354,8 +362,8 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
         const int wl = (ow + 32 < p.Sq ? ow + 32 : p.Sq) - 1;
         wave_kv_end = wl + off + 1 < p.Sk ? wl + off + 1 : p.Sk;
       }
-      active = ow < p.Sq && s0 < wave_kv_end;
-      need_mask = (s0 + kTile > p.Sk) || (CAUSAL && s0 + kTile - 1 > ow + off);
+      active = ow < p.Sq && s0 < wave_kv_end && (!p.win_on || s0 + kTile - 1 >= ow + p.win_lo);
+      need_mask = (s0 + kTile > p.Sk) || (CAUSAL && s0 + kTile - 1 > ow + off) || (p.win_on && s0 < ow + 31 + p.win_lo);
     } else {
       // streamed = query rows, owned = keys
       active = ow < p.Sk && (!CAUSAL || (s0 + kTile - 1 + off >= ow));
@@ -386,9 +394,12 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
         if (MODE == 0) {
           int klim = p.Sk - 1;
           if (CAUSAL) klim = orow + off < klim ? orow + off : klim;
+          const int klo = p.win_on ? orow + p.win_lo : -0x40000000;
 #pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (sr0 + (r & 3) + 8 * (r >> 2) > klim) sS[h][r] = USP_NEG_INF;
+          for (int r = 0; r < 16; ++r) {
+            const int key = sr0 + (r & 3) + 8 * (r >> 2);
+            if (key > klim || key < klo) sS[h][r] = USP_NEG_INF;
+          }
         } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r)                   // query row i sees key j iff j <= i + off
@@ -658,6 +669,12 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
     t_begin = first_q / kTile;
     if (t_begin > t_end) t_begin = t_end;
   }
+  if (p.win_on) {                                // query rows beyond the window of the block's last key: not streamed
+    const int last = own0 + OWN - 1 - p.win_lo;  // row i sees key j only if i <= j - win_lo
+    const int te = last >= 0 ? last / kTile + 1 : 0;
+    t_end = te < t_end ? te : t_end;
+    if (t_begin > t_end) t_begin = t_end;
+  }
   if (p.qsplit > 1) {                            // this item's cut of the query tiles [t_begin, t_end): equal runs
     const int per = (t_end - t_begin + p.qsplit - 1) / p.qsplit;
     t_begin = t_begin + cut * per < t_end ? t_begin + cut * per : t_end;
@@ -791,8 +808,9 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
       tile_a = (tile_a + 1 == t_end) ? t_begin : tile_a + 1;
       const int s0 = tile * kTile;
       const bool valid = my_it >= 0 && my_it < n_iter;
-      const bool active = valid && ow < p.Sk && (!CAUSAL || (s0 + kTile - 1 + off >= ow));
-      const bool need_mask = CAUSAL && (s0 + off < ow + 31);
+      const bool active = valid && ow < p.Sk && (!CAUSAL || (s0 + kTile - 1 + off >= ow)) &&
+                          (!p.win_on || s0 <= ow + 31 - p.win_lo);
+      const bool need_mask = (CAUSAL && (s0 + off < ow + 31)) || (p.win_on && s0 + kTile - 1 > ow - p.win_lo);
 
       if (active) {
         {
@@ -914,10 +932,18 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
             }
           };
           auto apply_mask = [&](int h) {                         // role A only: query row i sees key j iff j <= i + off
-            const int d = orow - off - s0 - 4 * hi;              // one VGPR; thresholds are inline constants
+            if (CAUSAL) {
+              const int d = orow - off - s0 - 4 * hi;            // one VGPR; thresholds are inline constants
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (d > 32 * h + (r & 3) + 8 * (r >> 2)) sc[h][r] = USP_NEG_INF;
+              for (int r = 0; r < 16; ++r)
+                if (d > 32 * h + (r & 3) + 8 * (r >> 2)) sc[h][r] = USP_NEG_INF;
+            }
+            if (p.win_on) {                                      // ... and only if j >= i + win_lo
+              const int dl = orow - p.win_lo - s0 - 4 * hi;
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if (dl < 32 * h + (r & 3) + 8 * (r >> 2)) sc[h][r] = USP_NEG_INF;
+            }
           };
 
 #ifdef USP_DKDV_CHAIN2
@@ -1210,8 +1236,12 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   if (!ok16(a->dout, 2) || !ok16(a->q, 2) || !ok16(a->k, 2) || !ok16(a->v, 2) || !ok32(a->dq) ||
       !ok32(a->dk) || !ok32(a->dv) || !okh(a->dq16) || !okh(a->dk16) || !okh(a->dv16))
     return USP_EUNSUPPORTED;
-  if ((a->flags & USP_ATTN_WINDOW) && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)))
-    return USP_EUNSUPPORTED;                      // sliding windows: not in this build's backward
+  // sliding window (flash-attn's window_size), as in usp_flash_fwd: causal caps the right bound at 0, a right bound is
+  // the causal limit with a shifted offset, a left bound is a second mask term + a shorter streamed range
+  const bool has_win = (a->flags & USP_ATTN_WINDOW) != 0;
+  const int wl = has_win ? a->window_left : -1;
+  const int wr = a->causal ? 0 : (has_win ? a->window_right : -1);
+  if ((a->seq_q || a->seq_k) && (wl >= 0 || wr > 0)) return USP_EUNSUPPORTED;       // dense launches only
   if (a->dq_splits < 0 || a->dq_splits > 8 || a->dkdv_splits < 0 || a->dkdv_splits > 8) return USP_EINVAL;
   // the dK/dV kernel addresses the Q / dO tiles of a head by a 32-bit byte offset from the head's first row
   if ((int64_t)a->Sq * a->q.stride_s * 2 >= (1LL << 31) || (int64_t)a->Sq * a->dout.stride_s * 2 >= (1LL << 31))
@@ -1232,7 +1262,8 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   p.dv_sb = a->dv.stride_b; p.dv_ss = a->dv.stride_s; p.dv_sh = a->dv.stride_h;
   p.B = a->B; p.Sq = a->Sq; p.Sk = a->Sk; p.Hq = a->Hq; p.Hkv = a->Hkv; p.G = a->Hq / a->Hkv;
   p.nblk = 0;
-  p.causal_off = a->Sk - a->Sq;
+  p.causal_off = a->Sk - a->Sq + (wr > 0 ? wr : 0);
+  p.win_on = wl >= 0 ? 1 : 0; p.win_lo = a->Sk - a->Sq - (wl >= 0 ? wl : 0);
   p.scale = a->softmax_scale;
   p.scale_log2 = a->softmax_scale * kLog2e;
   p.accum_dq = a->accum_dq ? 1 : 0; p.accum_dk = a->accum_dk ? 1 : 0; p.accum_dv = a->accum_dv ? 1 : 0;
@@ -1269,7 +1300,7 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
     if (p.ksplit > 1) p.ws_dq = (float*)((char*)a->workspace + part);
   }
   hipStream_t st = (hipStream_t)stream;
-  const bool causal = a->causal != 0;
+  const bool causal = wr >= 0;                    // (a->causal, or a right window bound)
   switch (a->D * 2 + a->dtype) {
     case 64: return launch_bwd<32, 0>(p, causal, st);
     case 65: return launch_bwd<32, 1>(p, causal, st);

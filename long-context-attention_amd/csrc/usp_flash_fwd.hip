@@ -48,6 +48,11 @@ struct FwdParams {
 struct FwdSplit {
   int ksplit;
   float* ws_o; float* ws_lse;
+  // Sliding window, left bound (ABI v5): query row i sees key j only if j >= i + win_lo (win_lo = Sk - Sq - window_left).
+  // Lives in the split instantiation: tiles left of a query tile's window are skipped by the same rebasing the K split
+  // uses, and every tile of a windowed launch takes the generic (masked) loop.  The RIGHT bound needs nothing new: it
+  // is the causal limit with a shifted offset (host: causal_off = Sk - Sq + window_right, causal instantiation).
+  int win_on, win_lo;
 };
 template <bool KS> struct FwdArgsT : FwdParams {};
 template <> struct FwdArgsT<true> : FwdParams, FwdSplit {};
@@ -137,7 +142,11 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdArgs
   // and the causal offset (the tile loops are untouched, as in packed mode).  Each cut writes its own normalised
   // partial (fp32) and its LSE to the workspace through the ordinary not-final epilogue; split_merge_kernel combines
   // them (and the running result, and the 16-bit emission) afterwards.
+  bool win = false;       // left window bound active (split instantiation only)
+  int win_lo = 0;         // row i sees key j only if j >= i + win_lo (in the rebased key numbering)
   if constexpr (KSPLIT) {
+    win = p_in.win_on != 0;
+    win_lo = p_in.win_lo;
     const int q0s = qt * kBM;
     int e = p.Sk;
     if (CAUSAL) {
@@ -145,18 +154,28 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdArgs
       e = lim < e ? lim : e;
     }
     const int nt_all = e > 0 ? (e + kBN - 1) / kBN : 0;
-    const int kb = (ks * nt_all / p_in.ksplit) * kBN;
-    int ke = (ks == p_in.ksplit - 1) ? p.Sk : ((ks + 1) * nt_all / p_in.ksplit) * kBN;
+    int t0 = 0;           // first tile any row of this query tile sees (its first row has the smallest left bound)
+    if (win) {
+      const int first = q0s + win_lo;
+      t0 = first > 0 ? first / kBN : 0;
+      t0 = t0 < nt_all ? t0 : nt_all;
+    }
+    const int ntw = nt_all - t0;
+    const int kb = (t0 + ks * ntw / p_in.ksplit) * kBN;
+    int ke = (ks == p_in.ksplit - 1) ? p.Sk : (t0 + (ks + 1) * ntw / p_in.ksplit) * kBN;
     ke = ke < p.Sk ? ke : p.Sk;
     p.k += 2 * (int64_t)kb * p.k_ss;
     p.v += 2 * (int64_t)kb * p.v_ss;
     p.Sk = ke > kb ? ke - kb : 0;
     p.causal_off -= kb;
-    p.acc = p_in.ws_o + (int64_t)ks * p.B * p.Sq * p.Hq * D;
-    p.a_sb = (int64_t)p.Sq * p.Hq * D; p.a_ss = (int64_t)p.Hq * D; p.a_sh = D;
-    p.lse = p_in.ws_lse + (int64_t)ks * p.B * p.Hq * p.Sq;
-    p.lse_sb = (int64_t)p.Hq * p.Sq; p.lse_sh = p.Sq;
-    p.merge_in = 0; p.final_begin = 0; p.final_end = 0; p.out_wide = 0;
+    win_lo -= kb;
+    if (p_in.ksplit > 1) {
+      p.acc = p_in.ws_o + (int64_t)ks * p.B * p.Sq * p.Hq * D;
+      p.a_sb = (int64_t)p.Sq * p.Hq * D; p.a_ss = (int64_t)p.Hq * D; p.a_sh = D;
+      p.lse = p_in.ws_lse + (int64_t)ks * p.B * p.Hq * p.Sq;
+      p.lse_sb = (int64_t)p.Hq * p.Sq; p.lse_sh = p.Sq;
+      p.merge_in = 0; p.final_begin = 0; p.final_end = 0; p.out_wide = 0;
+    }
   }
 
   const int q0 = qt * kBM;
@@ -183,6 +202,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdArgs
     n_full = nf < n_full ? nf : n_full;
   }
   if (qw + 32 > p.Sq) n_full = 0;                         // ragged / inactive waves take the generic loop
+  if constexpr (KSPLIT) { if (win) n_full = 0; }          // a left window bound: every tile through the masked loop
   if (n_full > nt) n_full = nt;
 
   // ---- Q fragments (B operand: lane holds Q[row][16t + 8hi .. +7]) ---------------------------
@@ -333,6 +353,17 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdArgs
       const int key = kb0 + (r & 3) + 8 * (r >> 2);
       if (key > klim) s0[r] = USP_NEG_INF;
       if (key + 32 > klim) s1[r] = USP_NEG_INF;
+    }
+    if constexpr (KSPLIT) {
+      if (win) {
+        const int klo = row + win_lo;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kb0 + (r & 3) + 8 * (r >> 2);
+          if (key < klo) s0[r] = USP_NEG_INF;
+          if (key + 32 < klo) s1[r] = USP_NEG_INF;
+        }
+      }
     }
   };
 
@@ -545,7 +576,8 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdArgs
     for (int r = 0; r < 16; ++r) { na[r] = 0.f; nb[r] = 0.f; }
     if (j + 1 < nt && kt0 + kBN < wave_kv_end) qk((j + 1) & 1, na, nb);
     if (kt0 < wave_kv_end) {
-      const bool need_mask = (kt0 + kBN > p.Sk) || (CAUSAL && kt0 + kBN - 1 > qw + off);
+      bool need_mask = (kt0 + kBN > p.Sk) || (CAUSAL && kt0 + kBN - 1 > qw + off);
+      if constexpr (KSPLIT) need_mask = need_mask || (win && kt0 < qw + 31 + win_lo);
       if (need_mask) mask(kt0, sa, sb);
       u32x4 pf[4];
       softmax(sa, sb, pf);
@@ -703,7 +735,7 @@ static int launch_fwd_w(FwdArgsT<true> p, bool causal, hipStream_t st) {
   const int slots = cus * (NWAVES == 8 ? 1 : 2);
   const int grid = (((persist || p.sched) && !p.interleave) && p.n_items > slots) ? slots : p.n_items;
   const size_t lds = 2 * 2 * kBN * D * 2 + (p.sched ? 16 : 0);
-  if (p.ksplit > 1) {
+  if (p.ksplit > 1 || p.win_on) {
     if (causal)
       hipLaunchKernelGGL((flash_fwd_kernel<D, DT, true, NWAVES, true>), dim3(grid), dim3(64 * NWAVES), lds, st, p);
     else
@@ -772,8 +804,12 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
     return USP_EUNSUPPORTED;
   const bool packed = a->seq_q != nullptr || a->seq_k != nullptr;
   if (packed && !(a->seq_q && a->seq_k)) return USP_EINVAL;
-  if ((a->flags & USP_ATTN_WINDOW) && (a->window_left >= 0 || (a->window_right >= 0 && !a->causal)))
-    return USP_EUNSUPPORTED;                      // sliding windows: not in this build's forward
+  // sliding window (flash-attn's window_size): causal caps the right bound at 0; a right bound is the causal limit with
+  // a shifted offset; a left bound runs in the split instantiation (FwdSplit)
+  const bool has_win = (a->flags & USP_ATTN_WINDOW) != 0;
+  const int wl = has_win ? a->window_left : -1;
+  const int wr = a->causal ? 0 : (has_win ? a->window_right : -1);
+  if (packed && (wl >= 0 || wr > 0)) return USP_EUNSUPPORTED;       // dense launches only
   const int f_all = packed ? 2 : a->Sq;          // packed: final_begin/_end count half sequences (0,1,2)
   int fb = a->final_begin < 0 ? 0 : a->final_begin;
   int fe = a->final_end > f_all ? f_all : a->final_end;
@@ -798,7 +834,7 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   p.B = a->B; p.Sq = a->Sq; p.Sk = a->Sk; p.Hq = a->Hq; p.Hkv = a->Hkv;
   p.G = a->Hq / a->Hkv;
   p.nq = 0;   // set per workgroup shape in launch_fwd_w
-  p.causal_off = a->Sk - a->Sq;
+  p.causal_off = a->Sk - a->Sq + (wr > 0 ? wr : 0);
   p.scale = a->softmax_scale;
   p.scale_log2 = a->softmax_scale * kLog2e;
   p.merge_in = a->merge_in ? 1 : 0;
@@ -809,6 +845,7 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   p.sched = packed ? a->sched : nullptr;
   p.interleave = (a->flags & USP_LAUNCH_INTERLEAVE) ? 1 : 0;
   p.ksplit = 1; p.ws_o = nullptr; p.ws_lse = nullptr;
+  p.win_on = wl >= 0 ? 1 : 0; p.win_lo = a->Sk - a->Sq - (wl >= 0 ? wl : 0);
   if (a->k_splits > 1 && a->workspace != nullptr) {
     if (packed) return USP_EUNSUPPORTED;                       // dense launches only
     if (a->k_splits > 8 || !aligned16(a->workspace)) return USP_EINVAL;
@@ -819,7 +856,7 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   }
   if (packed) p.q_sb = p.k_sb = p.v_sb = p.o_sb = p.a_sb = p.lse_sb = 0;
   hipStream_t st = (hipStream_t)stream;
-  const bool causal = a->causal != 0;
+  const bool causal = wr >= 0;                    // (a->causal, or a right window bound)
   switch (a->D * 2 + a->dtype) {
     case 32 * 2 + 0: return launch_fwd<32, 0>(p, causal, st);
     case 32 * 2 + 1: return launch_fwd<32, 1>(p, causal, st);

@@ -17,6 +17,7 @@ from torch import Tensor
 from ..comm.all_to_all import SeqAllToAll4D, SeqAllToAll5D
 from ..globals import PROCESS_GROUP
 from ..kernels import AttnType
+from ..kernels.attention import window_of
 from ..ring.zigzag_ring_flash_attn import _check_hot_path_args
 from .async_attn_layer import _AsyncUSPFunc, _MAX_GROUPS, _RING_FWD_BWD, pipeline_mode
 from .utils import RING_IMPL_DICT, RING_IMPL_QKVPACKED_DICT
@@ -111,6 +112,9 @@ class LongContextAttention(_USPLayer):
         """query (bs, seq_len/N, head_cnt, head_size); key/value (bs, seq_len/N, kv_head_cnt,
         head_size) -> context (bs, seq_len/N, head_cnt, head_size)."""
         ng_cap = self._packed_exchange(query, key)
+        if ng_cap is not None and window_of(window_size) is not None:
+            ng_cap = None         # a sliding window: the reference's structure (three exchanges); the ring function
+                                  # serves it at ring degree 1 and refuses beyond (ring/ring_flash_attn.py)
         if ng_cap is not None:
             assert alibi_slopes is None
             _check_hot_path_args(dropout_p, window_size, softcap)

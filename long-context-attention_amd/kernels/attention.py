@@ -54,17 +54,17 @@ class HipBlockBackend:
         return self._beside
 
     def fwd(self, q, k, v, softmax_scale, causal, lse, out=None, acc=None, merge_in=False,
-            final_begin=0, final_end=None):
+            final_begin=0, final_end=None, window=None):
         _C.flash_fwd(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end,
-                     interleave=self.interleave)
+                     interleave=self.interleave, window=window)
 
     def delta(self, dout, out, delta):
         _C.bwd_delta(dout, out, delta)
 
     def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
-            accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None):
+            accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None, window=None):
         _C.flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq,
-                     accum_dk, accum_dv, dq16, dk16, dv16, interleave=self.interleave)
+                     accum_dk, accum_dv, dq16, dk16, dv16, interleave=self.interleave, window=window)
 
     def fwd_packed(self, q, k, v, seq_q, seq_k, max_q, max_k, softmax_scale, causal, lse, out=None,
                    acc=None, merge_in=False, final_begin=0, final_end=2):
@@ -117,17 +117,21 @@ def _default_scale(q, softmax_scale):
     return q.shape[-1] ** (-0.5) if softmax_scale is None else softmax_scale
 
 
-def _check_plain(dropout_p, window_size, softcap, alibi_slopes):
+def _check_plain(dropout_p, softcap, alibi_slopes):
     # the hot path only ever passes these defaults (zigzag_ring_flash_attn.py:207,
-    # hybrid/attn_layer.py:132-147); anything else is outside this package's scope.
+    # hybrid/attn_layer.py:132-147); anything else is outside this package's scope.  (window_size IS served: the
+    # block kernels take flash-attn's (left, right) window -- include/usp_hip.h, USP_ATTN_WINDOW.)
     if dropout_p not in (0, 0.0):
         raise NotImplementedError("dropout_p != 0 is not supported by the HIP attention kernel")
-    if window_size is not None and tuple(window_size) != (-1, -1):
-        raise NotImplementedError("sliding-window attention is not supported by the HIP attention kernel")
     if softcap not in (None, 0, 0.0):
         raise NotImplementedError("softcap is not supported by the HIP attention kernel")
     if alibi_slopes is not None:
         raise NotImplementedError("alibi_slopes is not supported by the HIP attention kernel")
+
+
+def window_of(window_size):
+    """flash-attn's `window_size` -> (left, right) or None when it selects no window ((-1, -1), None)."""
+    return _C._window(window_size)
 
 
 def hip_attn_forward(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
@@ -136,11 +140,12 @@ def hip_attn_forward(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, w
     zigzag_ring_flash_attn.py:29-43, ring_flash_attn.py:36-48):
         (block_out (B,Sq,Hq,D) q.dtype, block_lse (B,Hq,Sq) fp32)
     Unlike the TORCH_* wrappers (attention.py:135) the LSE is NOT rounded to q.dtype."""
-    _check_plain(dropout_p, window_size, softcap, alibi_slopes)
+    _check_plain(dropout_p, softcap, alibi_slopes)
     B, Sq, Hq, D = q.shape
     out = torch.empty((B, Sq, Hq, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
-    get_block_backend().fwd(q, k, v, _default_scale(q, softmax_scale), bool(causal), lse, out=out)
+    get_block_backend().fwd(q, k, v, _default_scale(q, softmax_scale), bool(causal), lse, out=out,
+                            window=window_of(window_size))
     return out, lse
 
 
@@ -151,7 +156,7 @@ def hip_attn_backward(dout, q, k, v, out, softmax_lse, block_dq_buffer, block_dk
     """`bwd-only` contract (argument order of kernels/attention.py:205-206): writes dq/dk/dv into
     the caller's (possibly sliced, 16-bit) buffers; `out`/`softmax_lse` are the GLOBAL rows' values
     (zigzag_ring_flash_attn.py:115-137)."""
-    _check_plain(dropout_p, window_size, softcap, alibi_slopes)
+    _check_plain(dropout_p, softcap, alibi_slopes)
     be = get_block_backend()
     B, Sq, Hq, D = q.shape
     dev = q.device
@@ -166,7 +171,7 @@ def hip_attn_backward(dout, q, k, v, out, softmax_lse, block_dq_buffer, block_dk
     tgt = [t if direct(t) else torch.empty(t.shape, dtype=t.dtype, device=dev)
            for t in (block_dq_buffer, block_dk_buffer, block_dv_buffer)]
     be.bwd(dout, q, k, v, lse, delta, None, None, None, _default_scale(q, softmax_scale), bool(bwd_causal),
-           dq16=tgt[0], dk16=tgt[1], dv16=tgt[2])
+           dq16=tgt[0], dk16=tgt[1], dv16=tgt[2], window=window_of(window_size))
     for t, dst in zip(tgt, (block_dq_buffer, block_dk_buffer, block_dv_buffer)):
         if t is not dst:
             dst.copy_(t)
@@ -177,12 +182,12 @@ class _HipAttnFunc(torch.autograd.Function):
     yunchang/ulysses/attn_layer.py:48,101-113)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, softmax_scale, causal, return_lse):
+    def forward(ctx, q, k, v, softmax_scale, causal, return_lse, window_size=(-1, -1)):
         scale = _default_scale(q, softmax_scale)
         q, k, v = kernel_operand(q), kernel_operand(k), kernel_operand(v)
-        out, lse = hip_attn_forward(q, k, v, softmax_scale=scale, causal=causal)
+        out, lse = hip_attn_forward(q, k, v, softmax_scale=scale, causal=causal, window_size=window_size)
         ctx.save_for_backward(q, k, v, out, lse)
-        ctx.scale, ctx.causal = scale, bool(causal)
+        ctx.scale, ctx.causal, ctx.window_size = scale, bool(causal), window_size
         if return_lse:
             ctx.mark_non_differentiable(lse)
             return out, lse
@@ -192,8 +197,9 @@ class _HipAttnFunc(torch.autograd.Function):
     def backward(ctx, dout, *_):
         q, k, v, out, lse = ctx.saved_tensors
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        hip_attn_backward(kernel_operand(dout), q, k, v, out, lse, dq, dk, dv, 0.0, ctx.scale, ctx.causal)
-        return dq, dk, dv, None, None, None
+        hip_attn_backward(kernel_operand(dout), q, k, v, out, lse, dq, dk, dv, 0.0, ctx.scale, ctx.causal,
+                          ctx.window_size)
+        return dq, dk, dv, None, None, None, None
 
 
 def hip_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
@@ -201,8 +207,8 @@ def hip_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wind
                   *args, **kwargs):
     """`fwd-bwd` contract (flash_attn_func's signature): `out`, or `(out, softmax_lse, None)` with
     return_attn_probs (the probabilities themselves are never materialised: dropout is 0)."""
-    _check_plain(dropout_p, window_size, softcap, alibi_slopes)
+    _check_plain(dropout_p, softcap, alibi_slopes)
     if return_attn_probs:
-        out, lse = _HipAttnFunc.apply(q, k, v, softmax_scale, causal, True)
+        out, lse = _HipAttnFunc.apply(q, k, v, softmax_scale, causal, True, window_size)
         return out, lse, None
-    return _HipAttnFunc.apply(q, k, v, softmax_scale, causal, False)
+    return _HipAttnFunc.apply(q, k, v, softmax_scale, causal, False, window_size)

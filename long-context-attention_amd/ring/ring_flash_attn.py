@@ -10,10 +10,25 @@ import torch
 import torch.distributed as dist
 
 from ..kernels import AttnType
-from ..kernels.attention import get_block_backend, kernel_operand, needs_grad
+from ..kernels.attention import get_block_backend, kernel_operand, needs_grad, window_of
 from .utils import FULL, KVRelay, group_info, final_grads, travel_dkdv
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
+
+
+def _ring_window(window_size, P):
+    """flash-attn's window_size -> (left, right) | None.  A window is served where the ring has ONE block (ring degree
+    1: the Ulysses-only layouts, the single-GPU path); across ring steps every block would need its own shifted bounds
+    (the reference hands the same `window_size` to every block, kernels/attention.py:165-202 -- correct at ring degree
+    1 only) and this package refuses instead of computing something else."""
+    win = window_of(window_size)
+    if win is not None and P > 1:
+        raise NotImplementedError("sliding-window attention across ring steps (ring degree > 1) is not supported")
+    return win
+
+
+def _window_kw(win):
+    return {} if win is None else {"window": win}
 
 
 def basic_fwd_step(be, r, P, step, causal, q, kk, vv, softmax_scale, lse, out, acc):
@@ -45,6 +60,10 @@ def ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, 
     dev = q.device
     out = torch.empty((B, S, H, D), dtype=q.dtype, device=dev)
     lse = torch.empty((B, H, S), dtype=torch.float32, device=dev)
+    win = _ring_window(window_size, P)
+    if win is not None:              # ring degree 1: one block, the kernels take flash-attn's window (left, right)
+        be.fwd(q, k, v, softmax_scale, bool(causal), lse, out, window=win)
+        return out, lse
     last_compute = r if causal else P - 1
     acc = torch.empty((B, S, H, D), dtype=torch.float32, device=dev) if last_compute > 0 else None
     with KVRelay(process_group, k, v) as relay:
@@ -67,8 +86,9 @@ def ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, sof
     if P == 1:   # one block: the kernels round the gradients to q.dtype in their epilogues
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         be.bwd(dout, q, k, v, softmax_lse, delta, None, None, None, softmax_scale, bool(causal),
-               dq16=dq, dk16=dk, dv16=dv)
+               dq16=dq, dk16=dk, dv16=dv, **_window_kw(_ring_window(window_size, P)))
         return dq, dk, dv
+    _ring_window(window_size, P)
     dq_acc = torch.empty((B, S, H, D), dtype=torch.float32, device=dev)
 
     def block(step, kk, vv, dk_dst, dv_dst):
@@ -93,7 +113,7 @@ class RingFlashAttnFunc(torch.autograd.Function):
             softmax_scale = q.shape[-1] ** (-0.5)
         assert alibi_slopes is None
         q, k, v = kernel_operand(q), kernel_operand(k), kernel_operand(v)     # any view a caller holds (maybe_contiguous)
-        _check_hot_path_args(dropout_p, window_size, softcap)
+        _check_hot_path_args(dropout_p, (-1, -1), softcap)                    # (the window: ring_flash_attn_forward)
         out, softmax_lse = ring_flash_attn_forward(
             group, q, k, v, softmax_scale=softmax_scale, dropout_p=dropout_p, causal=causal,
             window_size=window_size, softcap=softcap, alibi_slopes=alibi_slopes, deterministic=False,
@@ -147,11 +167,11 @@ def ring_flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=Fals
                          attn_processor=None):
     if not needs_grad(q, k, v):      # inference / forward-only benchmarks: no autograd node, no saved tensors (~25 us)
         assert alibi_slopes is None
-        _check_hot_path_args(dropout_p, window_size, softcap)
+        _check_hot_path_args(dropout_p, (-1, -1), softcap)
         out, lse = ring_flash_attn_forward(
             group, kernel_operand(q), kernel_operand(k), kernel_operand(v),
             softmax_scale=q.shape[-1] ** (-0.5) if softmax_scale is None else softmax_scale, causal=causal,
-            attn_type=attn_type, attn_processor=attn_processor)
+            window_size=window_size, attn_type=attn_type, attn_processor=attn_processor)
         return out if not return_attn_probs else (out, lse, None)
     return RingFlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap,
                                    alibi_slopes, deterministic, return_attn_probs, group, attn_type,

@@ -99,33 +99,41 @@ EXTRACT = {"basic": basic_extract_local, "zigzag": zigzag_extract_local, "strip"
 # ----------------------------------------------------------------------------
 # full attention truth  (test/test_utils.py:43-130 attention_ref)
 # ----------------------------------------------------------------------------
-def _scores(q, k, scale, causal):
+def _scores(q, k, scale, causal, window=(-1, -1)):
     """q (B,Sq,Hq,D), k (B,Sk,Hkv,D) -> masked scaled scores (B,Hq,Sq,Sk).
 
     GQA: q head i uses kv head i // g  (test_utils.py:86-87 ``repeat b s h d -> b s (h g) d``).
     Causal mask is bottom-right aligned: key j visible to query i iff j <= i + Sk - Sq
-    (test_utils.py:35-36 with window (-1, 0)).
+    (test_utils.py:35-36 with window (-1, 0)).  `window` = (left, right) as test_utils.py:8-40
+    construct_local_mask (the mask flash-attn's `window_size` stands for, kernels/attention.py:165-202): key j is
+    visible to query i iff  i + Sk - Sq - left <= j <= i + Sk - Sq + right, a negative bound = unbounded on that side;
+    causal sets right = 0 (test_utils.py:80-81).
     """
     B, Sq, Hq, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
     g = Hq // Hkv
     kk = np.repeat(k, g, axis=2)
     s = np.einsum("bthd,bshd->bhts", q * scale, kk)
+    left, right = window
     if causal:
-        row = np.arange(Sq)[:, None]
-        col = np.arange(Sk)[None, :]
-        s = np.where(col > row + Sk - Sq, NEG_INF, s)
+        right = 0
+    row = np.arange(Sq)[:, None]
+    col = np.arange(Sk)[None, :]
+    if right >= 0:
+        s = np.where(col > row + Sk - Sq + right, NEG_INF, s)
+    if left >= 0:
+        s = np.where(col < row + Sk - Sq - left, NEG_INF, s)
     return s
 
 
-def attention_ref(q, k, v, causal=False, softmax_scale=None, dtype=np.float64):
+def attention_ref(q, k, v, causal=False, softmax_scale=None, dtype=np.float64, window=(-1, -1)):
     """Returns (out (B,Sq,Hq,D), lse (B,Hq,Sq)) computed in ``dtype`` (upcast=True path,
     test_utils.py:83-84).  Fully masked rows give out=0, lse=-inf (test_utils.py:115-117)."""
     q, k, v = (np.asarray(t, dtype=dtype) for t in (q, k, v))
     D = q.shape[-1]
     scale = (1.0 / math.sqrt(D)) if softmax_scale is None else softmax_scale
     g = q.shape[2] // k.shape[2]
-    s = _scores(q, k, scale, causal)
+    s = _scores(q, k, scale, causal, window)
     m = s.max(axis=-1, keepdims=True)
     m_safe = np.where(np.isfinite(m), m, 0.0)
     p = np.exp(s - m_safe)
@@ -149,7 +157,7 @@ def block_fwd(q, k, v, softmax_scale=None, causal=False, dtype=np.float64):
     return attention_ref(q, k, v, causal=causal, softmax_scale=softmax_scale, dtype=dtype)
 
 
-def block_bwd(dout, q, k, v, out, lse, softmax_scale=None, causal=False, dtype=np.float64):
+def block_bwd(dout, q, k, v, out, lse, softmax_scale=None, causal=False, dtype=np.float64, window=(-1, -1)):
     """Block backward taking the GLOBAL ``out`` rows and GLOBAL ``lse`` (B,Hq,Sq), as the ring
     schedule passes them (zigzag_ring_flash_attn.py:115-137).  Returns (dq, dk, dv).
 
@@ -163,7 +171,7 @@ def block_bwd(dout, q, k, v, out, lse, softmax_scale=None, causal=False, dtype=n
     Hkv = k.shape[2]
     g = Hq // Hkv
     scale = (1.0 / math.sqrt(D)) if softmax_scale is None else softmax_scale
-    s = _scores(q, k, scale, causal)                       # (B,Hq,Sq,Sk)
+    s = _scores(q, k, scale, causal, window)               # (B,Hq,Sq,Sk)
     lse_safe = np.where(np.isfinite(lse), lse, 0.0)
     p = np.exp(s - lse_safe[..., None])
     p = np.where(np.isfinite(lse)[..., None], p, 0.0)

@@ -32,7 +32,7 @@ def grad_tol(dtype: str, heads_summed: int = 1):
 def golden_files():
     """Dense fixtures (make_golden.py); the packed variable-length ones are varlen_golden_files()."""
     return sorted(f for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz"))
-                  if not os.path.basename(f).startswith("v_"))
+                  if not os.path.basename(f).startswith(("v_", "w_")))      # w_: sliding-window mask vectors
 
 
 def varlen_golden_files():

@@ -36,8 +36,9 @@ class OracleBlockBackend:
         self.calls = []
 
     def fwd(self, q, k, v, softmax_scale, causal, lse, out=None, acc=None, merge_in=False,
-            final_begin=0, final_end=None):
+            final_begin=0, final_end=None, window=None):
         Sq = q.shape[1]
+        window = (-1, -1) if window is None else window
         fe = Sq if final_end is None else final_end
         for t, what in ((q, "q"), (k, "k"), (v, "v"), (acc, "acc")):
             _operand(t, what)
@@ -54,7 +55,7 @@ class OracleBlockBackend:
             and (not merge_in or acc is not None), "final rows need `out`, the others (and a merge) need `acc`"
         self.calls.append(("fwd", tuple(q.shape), tuple(k.shape), bool(causal), bool(merge_in),
                            final_begin, fe))
-        bo, bl = O.block_fwd(_np(q), _np(k), _np(v), softmax_scale, causal)      # (B,Sq,H,D), (B,H,Sq)
+        bo, bl = O.attention_ref(_np(q), _np(k), _np(v), causal, softmax_scale, window=window)      # (B,Sq,H,D), (B,H,Sq)
         if merge_in:
             o_run = _np(acc)
             l_run = np.swapaxes(_np(lse), 1, 2)[..., None]                       # (B,S,H,1)
@@ -75,7 +76,8 @@ class OracleBlockBackend:
         _put(delta, np.einsum("bshd,bshd->bhs", _np(dout), _np(out)))
 
     def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
-            accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None):
+            accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None, window=None):
+        window = (-1, -1) if window is None else window
         for t, what in ((dout, "dout"), (q, "q"), (k, "k"), (v, "v"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
             _operand(t, what)
         for t, what in ((dq16, "dq16"), (dk16, "dk16"), (dv16, "dv16")):
@@ -94,7 +96,7 @@ class OracleBlockBackend:
         B, Sq, Hq, D = qn.shape
         Sk, Hkv = kn.shape[1], kn.shape[2]
         g = Hq // Hkv
-        s = O._scores(qn, kn, softmax_scale, causal)
+        s = O._scores(qn, kn, softmax_scale, causal, window)
         fin = np.isfinite(ln)
         p = np.where(fin[..., None], np.exp(s - np.where(fin, ln, 0.0)[..., None]), 0.0)
         vv, kk = np.repeat(vn, g, axis=2), np.repeat(kn, g, axis=2)

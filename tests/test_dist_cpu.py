@@ -539,3 +539,44 @@ def test_virtual_grid_runs_the_layer_for_every_rank_in_one_process(monkeypatch, 
         for t, name in zip(res[r][0], ("out", "dq", "dk", "dv")):
             tol = TOL[g.dtype]["out"] if name == "out" else grad_tol(g.dtype, g.Hq // g.Hkv if name != "dq" else 1)
             assert_close(t.float().numpy(), getattr(g, name)[r], *tol, f"{g.name} {name} rank {r}")
+
+
+def _window_worker(rank, ws, ud, rd):
+    """window_size through the layers at ulysses degree `ud` (ring degree 1: one block per rank after the exchange) against
+    exact windowed attention on the unsharded tensors; beside a ring it must be refused, not approximated."""
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    from oracle import usp_oracle as O
+    set_block_backend(OracleBlockBackend())
+    Y.set_seq_parallel_pg(ud, rd, rank, ws)
+    torch.manual_seed(0)
+    B, S, Hq, Hkv, D, win = 2, 64 * ws, 4, 2, 32, (40, 0)
+    q, k, v, do = (torch.randn(B, S, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
+    ext = Y.EXTRACT_FUNC_DICT["basic"]
+    lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=rd, ud=ud).detach().clone() for t in (q, k, v, do))
+    for t in (lq, lk, lv):
+        t.requires_grad_(True)
+    attn = Y.LongContextAttention(ring_impl_type="basic")
+    if rd > 1:
+        try:
+            attn(lq, lk, lv, causal=True, window_size=win)
+        except NotImplementedError:
+            return True
+        return False
+    out = attn(lq, lk, lv, causal=True, window_size=win)
+    out.backward(ldo)
+    qn, kn, vn, don = (t.float().numpy().astype(np.float64) for t in (q, k, v, do))
+    ro, rl = O.attention_ref(qn, kn, vn, causal=True, window=win)
+    truth = [ext(torch.from_numpy(np.ascontiguousarray(t)), rank, world_size=ws, rd=rd, ud=ud).float()
+             for t in (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, True, window=win))]
+    got = [t.detach().float() for t in (out, lq.grad, lk.grad, lv.grad)]
+    ok = all(torch.allclose(a, t, atol=tol, rtol=tol) for a, t, tol in zip(got, truth, (2e-2, 5e-2, 5e-2, 5e-2)))
+    u = Y.UlyssesAttention(Y.PROCESS_GROUP.ULYSSES_PG, attn_type=Y.AttnType.HIP)
+    o2 = u(lq.detach(), lk.detach(), lv.detach(), causal=True, window_size=win)
+    return ok and torch.allclose(o2.float(), truth[0], atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("ws,ud,rd", [(2, 2, 1), (1, 1, 1), (2, 1, 2)])
+def test_sliding_window_through_the_layers(ws, ud, rd):
+    assert all(run_distributed(_window_worker, ws, ud, rd))

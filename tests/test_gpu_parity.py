@@ -1006,3 +1006,73 @@ def test_backward_cuts_through_the_binding(dev, B, Sq, Sk, Hq, Hkv, D, causal, d
         assert _C.bwd_splits(B, Sq, Sk, Hq, causal) == (4, 4)        # 32 / 64 items: the policy cuts this launch
         for got, ref, name in zip(run(None, True), refs, ("dq", "dk", "dv")):
             assert_close(got, ref, atol, rtol, f"default policy {name}")
+
+
+WINDOWS = [
+    # B, Sq, Sk, Hq, Hkv, D, causal, (left, right), dtype
+    (1, 512, 512, 2, 2, 128, True, (64, 0), "bfloat16"),        # causal sliding window (the usual local attention)
+    (2, 384, 640, 4, 2, 64, False, (100, 30), "bfloat16"),      # both bounds, Sq != Sk, GQA
+    (1, 300, 300, 2, 1, 128, False, (-1, 17), "float16"),       # right bound only = a shifted causal limit
+    (1, 333, 200, 2, 2, 64, False, (33, -1), "bfloat16"),       # left bound only; rows without any visible key
+    (1, 2048, 2048, 2, 2, 128, True, (256, 0), "bfloat16"),     # long: whole key tiles left of the window are skipped
+    (1, 1024, 2048, 2, 1, 32, True, (0, 0), "bfloat16"),        # the diagonal only
+    (1, 777, 777, 3, 3, 128, False, (5000, 5000), "bfloat16"),  # a window wider than the sequence = full attention
+]
+
+
+@pytest.mark.parametrize("B,Sq,Sk,Hq,Hkv,D,causal,win,dt", WINDOWS)
+def test_sliding_window_forward_backward_vs_oracle(dev, B, Sq, Sk, Hq, Hkv, D, causal, win, dt):
+    """flash-attn's `window_size` (left, right) through the C ABI (USP_ATTN_WINDOW, ABI v5) -- the argument the
+    reference's block contract passes through (kernels/attention.py:165-202) -- forward (out, LSE) and backward against the
+    fp64 oracle, whose window mask is pinned to the reference's (tests/golden/w_window_ref.npz); also with the K split
+    of the forward and the cuts of the backward on top."""
+    from yunchang_amd import _C
+    q, k, v, do = (_rand(s, dt, 90 + i) for i, s in enumerate([(B, Sq, Hq, D), (B, Sk, Hkv, D), (B, Sk, Hkv, D), (B, Sq, Hq, D)]))
+    tq, tk, tv, tdo = (_t(x, dt, dev) for x in (q, k, v, do))
+    scale = D ** -0.5
+    ro, rl = O.attention_ref(q, k, v, causal=causal, window=win)
+    rdq, rdk, rdv = O.block_bwd(do, q, k, v, ro, rl, None, causal, window=win)
+    tdt = getattr(torch, dt)
+    for ks, cuts in ((0, (0, 0)), (3, (2, 3))):
+        out = torch.full((B, Sq, Hq, D), float("nan"), dtype=tdt, device=dev)
+        lse = torch.full((B, Hq, Sq), float("nan"), dtype=torch.float32, device=dev)
+        _C.flash_fwd(tq, tk, tv, scale, causal, lse, out, window=win, k_splits=ks)
+        assert_close(_f(out), ro, *TOL[dt]["out"], f"out k_splits={ks}")
+        lg, seen = _f(lse), np.isfinite(rl)
+        assert (np.isneginf(lg) == ~seen).all(), "rows without a visible key must report lse = -inf"
+        assert_close(lg[seen], rl[seen], 2e-3, 1e-4, f"lse k_splits={ks}")
+        delta = torch.empty_like(lse)
+        _C.bwd_delta(tdo, out, delta)
+        g = [torch.full(t.shape, float("nan"), dtype=tdt, device=dev) for t in (tq, tk, tv)]
+        _C.flash_bwd(tdo, tq, tk, tv, lse, delta, None, None, None, scale, causal, dq16=g[0], dk16=g[1], dv16=g[2],
+                     window=win, splits=cuts)
+        atol, rtol = grad_tol(dt, Hq // Hkv)
+        for got, ref, name in zip(g, (rdq, rdk, rdv), ("dq", "dk", "dv")):
+            assert_close(_f(got), ref, atol, rtol, f"{name} cuts={cuts}")
+
+
+def test_sliding_window_through_the_block_contract_and_the_layer(dev, single_rank_pg):
+    """window_size through the three seams the reference's selector hands out (fwd-only / bwd-only / fwd-bwd callables)
+    and through LongContextAttention on a 1-rank grid (ring degree 1: one block)."""
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import select_flash_attn_impl
+    B, S, H, D, win = 1, 640, 2, 64, (96, 0)
+    q, k, v, do = (_rand((B, S, H, D), "bfloat16", 110 + i) for i in range(4))
+    ro, rl = O.attention_ref(q, k, v, causal=True, window=win)
+    refs = O.block_bwd(do, q, k, v, ro, rl, None, True, window=win)
+    tq, tk, tv, tdo = (_t(x, "bfloat16", dev) for x in (q, k, v, do))
+    fwd = select_flash_attn_impl(Y.AttnType.HIP, stage="fwd-only")
+    out, lse = fwd(tq, tk, tv, 0.0, None, causal=True, window_size=win)
+    assert_close(_f(out), ro, *TOL["bfloat16"]["out"], "fwd-only")
+    bwd = select_flash_attn_impl(Y.AttnType.HIP, stage="bwd-only")
+    g = [torch.empty_like(t) for t in (tq, tk, tv)]
+    bwd(tdo, tq, tk, tv, out, lse, g[0], g[1], g[2], 0.0, None, True, win, 0.0, None, False)
+    for got, ref, name in zip(g, refs, ("dq", "dk", "dv")):
+        assert_close(_f(got), ref, *TOL["bfloat16"]["grad"], f"bwd-only {name}")
+    leaves = [t.clone().requires_grad_(True) for t in (tq, tk, tv)]
+    attn = Y.LongContextAttention(ring_impl_type="basic", attn_type=Y.AttnType.HIP)
+    o2 = attn(*leaves, causal=True, window_size=win)
+    o2.backward(tdo)
+    assert_close(_f(o2), ro, *TOL["bfloat16"]["out"], "layer out")
+    for leaf, ref, name in zip(leaves, refs, ("dq", "dk", "dv")):
+        assert_close(_f(leaf.grad), ref, *TOL["bfloat16"]["grad"], f"layer {name}")

@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/usp_oracle.py) against outputs of the reference itself
 (tests/golden/*.npz, produced by tests/golden/make_golden.py on CPU/gloo)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -98,3 +100,15 @@ def test_cpu_baseline_port_equals_the_reference_single_rank_run(path):
     got = out.float().numpy()
     assert got.shape == g.out[0].shape
     assert np.array_equal(got, g.out[0]), f"{g.name}: max abs diff {np.abs(got - g.out[0]).max():.3e}"
+
+
+def test_oracle_window_mask_equals_the_reference():
+    """oracle.attention_ref(window=...) against the reference's own attention_ref with `window_size`
+    (tests/golden/w_window_ref.npz, made by tests/golden/make_golden_window.py importing the reference)."""
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "w_window_ref.npz"))
+    for i in range(int(z["n"])):
+        Sq, Sk, Hq, Hkv, D, causal, wl, wr = (int(x) for x in z[f"case{i}"])
+        rs = np.random.RandomState(100 + i)
+        q, k, v = (rs.standard_normal((1, S, H, D)).astype(np.float32) for S, H in ((Sq, Hq), (Sk, Hkv), (Sk, Hkv)))
+        out, _ = O.attention_ref(q, k, v, causal=bool(causal), window=(wl, wr))
+        assert_close(out, z[f"out{i}"], 2e-5, 2e-5, f"window case {i}: {(Sq, Sk, causal, wl, wr)}")

@@ -101,16 +101,38 @@ def main():
     # configs[4]: 8 GPUs, ulysses 2 x ring 4, B1 S65536 H32/4, forward + backward.
     fwd, bwd = 16.7 * 0.29, 16.7 * 0.71
     ex = dict(fi=ms(40 * MiB), fo=ms(32 * MiB), bi=ms(32 * MiB), bo=ms(40 * MiB))
-    hop = ms(32 * MiB)
+    hop = ms(32 * MiB)                                                      # fp32 dK + dV of both KV heads, one hop
+    kv = ms(16 * MiB)                                                       # K/V of one peer, both KV heads (mesh fetch: 3 links in parallel)
     print("\nconfigs[4]  8 GPUs  ulysses 2 x ring 4, fwd+bwd  exchanges %.2f + %.2f + %.2f + %.2f ms, dK/dV hop %.2f ms, K/V fetch %.2f ms x 2"
-          % (ex["fi"], ex["fo"], ex["bi"], ex["bo"], hop, ms(16 * MiB)))
-    for ng, eff_f, eff_b in ((1, 1.0, 1.0), (2, 0.95, 0.99)):
+          % (ex["fi"], ex["fo"], ex["bi"], ex["bo"], hop, kv))
+
+    def c5(ng, eff_f, eff_b, defer_tail, hop16):
+        """One iteration of a rank.  Exposed: the first input and the last output exchange of each pass (pipeline()), and
+        the last dK/dV hop of a head group -- round 2: of EVERY group (the compute stream waited for it before the next
+        group's kernels); round 3 (`defer_tail`): only of the last group (the hop is waited for on the exchange lane),
+        at half the bytes when it travels rounded (`hop16`).  t_comm: every transfer once."""
         tf, _ = pipeline(ex["fi"], fwd, ex["fo"], ng, eff_f)
         tb, _ = pipeline(ex["bi"], bwd, ex["bo"], ng, eff_b)
-        tot = tf + tb + ng * (hop / ng)                                     # each group's last dK/dV hop (1/ng of the heads) is exposed
-        comm = sum(ex.values()) + 4 * hop * 1.0 + 2 * ms(16 * MiB)
-        print("   %d head group(s): %.1f ms per iteration = %5.0f TFLOP/s on 8 GPUs; overlap = 1 - (t - t_compute)/t_comm = %.2f"
-              % (ng, tot, 8 * 15.39 / tot * 1e3, 1 - (tot - (fwd / eff_f + bwd / eff_b)) / comm))
+        last = (hop / ng) * (0.5 if hop16 else 1.0)
+        tot = tf + tb + (1 if defer_tail else ng) * last
+        comm = sum(ex.values()) + 3 * hop + ng * last + 2 * kv
+        return tot, 1 - (tot - (fwd / eff_f + bwd / eff_b)) / comm
+    for label, args in (("round 2: 1 head group (USP_PIPELINE_ULYSSES=0 / USP_SAFE_COMM=1)", (1, 1.0, 1.0, False, False)),
+                        ("round 2: 2 head groups pipelined", (2, 0.95, 0.99, False, False)),
+                        ("round 3: 2 groups, last hop pending on the lane + rounded (default)", (2, 0.97, 0.995, True, True)),
+                        ("round 3: 1 head group, last hop rounded (USP_SAFE_COMM=1)", (1, 1.0, 1.0, True, True))):
+        tot, ov = c5(*args)
+        print("   %-72s %.1f ms per iteration = %5.0f TFLOP/s on 8 GPUs; overlap = 1 - (t - t_compute)/t_comm = %.2f"
+              % (label + ":", tot, 8 * 15.39 / tot * 1e3, ov))
+    # What 0.90 would take (costed, not built -- DESIGN.md 5): what stays exposed with two groups is the first input and
+    # the last output exchange of each pass (0.33 + 0.26 + 0.26 + 0.33 ms at 64 GB/s) and the last hop (0.13).
+    e = dict(F1=ex["fi"] / 2, F2=ex["fo"] / 2, B1=ex["bi"] / 2, B2=ex["bo"] / 2, H=hop / 4)
+    print("   exposed with the round-3 default: first-in fwd %.2f, last-out fwd %.2f, first-in bwd %.2f, last-out bwd %.2f, last hop %.2f = %.2f ms"
+          % (e["F1"], e["F2"], e["B1"], e["B2"], e["H"], sum(e.values())))
+    cut = dict(F1=0.10, F2=e["F2"] / 2, B1=0.0, B2=0.20, H=e["H"])   # self-chunk start, row-chunked tails: see DESIGN.md 5
+    comm = sum(ex.values()) + 3 * hop + 2 * hop / 4 + 2 * kv
+    print("   with self-chunk starts + row-chunked tails (3-4 launches instead of 1 at four places, ~0.2 ms of kernel time): %.2f ms exposed -> overlap %.2f"
+          % (sum(cut.values()), 1 - sum(cut.values()) / comm))
 
     # Ring backward: the travelling dK/dV (relay, the reference's order) against USP_DKDV_RETURN=direct (every block
     # straight to its owner over its own link, front-half blocks at half size).  Per ring rank; t_c = kernels of one step.
