@@ -322,7 +322,7 @@ def reference_fwdbwd(cfg, dev, ours_tflops, iters=5):
 
 
 def kernel_source_sha16():
-    """Identity of the kernel sources a profile belongs to (tools/prof_r02.sh writes it into the summary)."""
+    """Identity of the kernel sources a profile belongs to (tools/prof_round.sh writes it into the summary)."""
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "long-context-attention_amd", "csrc")

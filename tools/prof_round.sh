@@ -1,9 +1,9 @@
-# usage (on the GPU box, from the repo root): bash tools/prof_r02.sh [tag]
+# usage (on the GPU box, from the repo root): bash tools/prof_round.sh [tag]
 # rocprofv3 kernel-trace + PMC passes (SQ / FETCH / WRITE+GRBM in separate passes, as the MI355X guide prescribes) of the
 # three flash kernels at the C2 shape, plus the kernel trace of the default bench.py run; summary -> gpurun_out/prof_<tag>/summary.txt
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
