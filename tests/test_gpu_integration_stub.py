@@ -46,3 +46,22 @@ def test_documented_stub_forward_and_backward(B, S, Hq, Hkv, D, causal, dt):
     assert_close(dq.float().cpu().numpy(), rdq, *TOL[dt]["grad"], "stub dq")
     assert_close(dk.float().cpu().numpy(), rdk, *grad_tol(dt, g), "stub dk")
     assert_close(dv.float().cpu().numpy(), rdv, *grad_tol(dt, g), "stub dv")
+
+
+def test_documented_stub_with_a_sliding_window():
+    """The stub forwards `window_size` (ABI v5, USP_ATTN_WINDOW): forward and backward against the windowed oracle."""
+    ns = _stub_namespace()
+    dev = torch.device("cuda:0")
+    B, S, H, D, dt, win = 1, 448, 2, 64, "bfloat16", (96, 0)
+    rs = np.random.RandomState(8)
+    q, k, v, do = (round_to(rs.standard_normal((B, S, H, D)).astype(np.float32), dt) for _ in range(4))
+    tq, tk, tv, tdo = (torch.from_numpy(x).to(torch.bfloat16).to(dev) for x in (q, k, v, do))
+    out, lse = ns["usp_hip_attn_forward"](tq, tk, tv, 0.0, None, causal=True, window_size=win)
+    ro, rl = O.attention_ref(q, k, v, causal=True, window=win)
+    assert_close(out.float().cpu().numpy(), ro, *TOL[dt]["out"], "stub out")
+    dq, dk, dv = torch.empty_like(tq), torch.empty_like(tk), torch.empty_like(tv)
+    ns["usp_hip_attn_backward"](tdo, tq, tk, tv, out, lse, dq, dk, dv, 0.0, None, True, win)
+    torch.cuda.synchronize()
+    for got, ref, name in zip((dq, dk, dv), O.block_bwd(do, q, k, v, out.float().cpu().numpy(), rl, None, True, window=win),
+                              ("dq", "dk", "dv")):
+        assert_close(got.float().cpu().numpy(), ref, *TOL[dt]["grad"], f"stub {name}")
