@@ -689,7 +689,8 @@ def main(argv=None, dev=None):
     roofline = None
     if ws == 1 and rank == 0:
         roofline = kernel_roofline(cfg, dev, traffic)
-    n_heat = heat_steps(cfg, ws) if dev.type == "cuda" else 0      # host tensors: the CPU tests drive main()
+    n_heat = heat_steps(cfg, ws) if (dev.type == "cuda" and not smoke) else 0      # not on host tensors (the CPU tests drive
+                                                                                    # main()), not over gloo (seconds per step)
     flops = fwd_flops(cfg["B"], cfg["Hq"], cfg["S"], cfg["D"]) * (3.5 if cfg["bwd"] else 1.0)
 
     def measure():
