@@ -876,17 +876,19 @@ def test_expanded_gradient_reaches_the_kernels(dev, single_rank_pg):
         assert (w.grad[..., 1::2] == 0).all()
 
 
-def test_c5_rank_block_shapes_against_sampled_fp64(dev):
+@pytest.mark.parametrize("Hq,Hkv", [(16, 2), (16, 16)], ids=["configs4_rank_gqa", "configs3_rank_mha"])
+def test_c5_rank_block_shapes_against_sampled_fp64(dev, Hq, Hkv):
     """The blocks a rank of BASELINE configs[4] (8 GPUs, ulysses 2 x ring 4, S = 65536, H32/Hkv4) actually launches, at
-    their REAL size: c = 8192, local q (1, 16384, 16, 128), K/V (1, 16384, 2, 128).  Forward: step 0 (causal, all rows,
+    their REAL size: c = 8192, local q (1, 16384, 16, 128), K/V (1, 16384, 2, 128) -- and the same with 16 KV heads, the
+    blocks of a configs[3] rank (4 GPUs, ring 4, S = 32768, MHA H16; c = 4096 there, the larger c is the harder case).  Forward: step 0 (causal, all rows,
     nothing final) then a step beyond the rank (q[c:] x another rank's 16384 keys, merge mode, final_end = c) -- rows
     [c, 2c) final in 16 bits, rows [0, c) still fp32 in the running output.  Backward: the block of that step (global
     LSE, delta, dq accumulated onto a running fp32 buffer, fp32 dK/dV through the GQA head-split workspace).  Sampled
     rows / key columns against exact fp64 attention over the keys those rows have seen."""
     from yunchang_amd import _C
     torch.manual_seed(5)
-    c, Hq, Hkv, D = 8192, 16, 2, 128
-    S2, G, scale = 2 * c, 8, 128 ** -0.5
+    c, D = 8192, 128
+    S2, G, scale = 2 * c, Hq // Hkv, 128 ** -0.5
     q, do = (torch.randn(1, S2, Hq, D, device=dev).to(torch.bfloat16) for _ in range(2))
     kl, vl, ko, vo = (torch.randn(1, S2, Hkv, D, device=dev).to(torch.bfloat16) for _ in range(4))
     out = torch.full((1, S2, Hq, D), float("nan"), dtype=torch.bfloat16, device=dev)
@@ -930,7 +932,7 @@ def test_c5_rank_block_shapes_against_sampled_fp64(dev):
             ds = p * (vod @ doi - delta[0, h, i].double())
             assert_close(_f(dq_acc[0, i, h]) - 1.0, ((ds @ kod) * scale).cpu().numpy(), *TOL["bfloat16"]["grad"],
                          f"dq row {i} head {h}")
-    for hk in (0, 1):
+    for hk in (0, Hkv - 1):
         kod, vod = ko[0, :, hk].double(), vo[0, :, hk].double()
         for j in sorted({0, S2 - 1, *rs.randint(0, S2, 3).tolist()}):
             rdk = torch.zeros(D, dtype=torch.float64, device=dev)
