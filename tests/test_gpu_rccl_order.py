@@ -237,3 +237,73 @@ def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch,
             for r in range(ws):
                 for t, t0, name in zip(got[r], first[r], names):
                     assert torch.equal(t, t0), f"iteration {it}: {name} of rank {r} differs from iteration 0"
+
+
+@pytest.mark.timeout(1500)
+def test_configs4_full_size_on_a_virtual_grid_sampled_parity(nccl_single, monkeypatch):
+    """BASELINE configs[4] AT ITS OWN SIZE -- 8 ranks, ulysses 2 x ring 4, zigzag, B1 S65536 H32/Hkv4 D128 bf16 causal,
+    forward + backward -- with the 8 ranks as virtual ranks of one GPU: the layer's default schedule (packed q|k|v exchange
+    pipelined over two head groups beside the ring, zigzag mesh fetch, travelling dK/dV with the rounded, pending last hop),
+    the real kernels at the real per-rank shapes, every transfer a real RCCL call.  The eight shards are put back
+    together and checked against exact fp64 attention over all 65536 tokens on sampled rows (out, dQ) and sampled key
+    columns (dK, dV, summed over the GQA group of 8 and over every later row) -- bench.sampled_parity, the check the
+    single-GPU 64K entry of the bench line carries."""
+    import importlib.util
+    import yunchang_amd as Y
+    from yunchang_amd import _C
+    from virtual_grid import patch_dist, run_grid
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    cfg = b.WORKLOADS[8]
+    dev = torch.device("cuda:0")
+    ud, rd, ws = cfg["ud"], cfg["rd"], 8
+    q, k, v, do = b.make_global(cfg, dev)
+    from oracle import usp_oracle as O
+
+    def ext(t, r):          # the zigzag shard of rank r (comm/extract_local.py needs the real process grid: restated, and
+        ch = t.chunk(2 * rd, dim=1)                     # held against the oracle's layout right below)
+        return torch.cat([ch[r // ud], ch[2 * rd - 1 - r // ud]], dim=1).chunk(ud, dim=1)[r % ud]
+    rows = torch.arange(cfg["S"], device=dev).view(1, -1, 1, 1)
+    owned = [ext(rows, r).reshape(-1) for r in range(ws)]                                        # global row ids per rank
+    small = np.arange(64, dtype=np.float32).reshape(1, 64, 1, 1)
+    for r in range(ws):
+        assert np.array_equal(ext(torch.from_numpy(small), r).numpy(), O.zigzag_extract_local(small, r, ws, rd, ud))
+    loc = [[ext(t, r).contiguous() for t in (q, k, v, do)] for r in range(ws)]
+    grid = _VirtualGrid(ud, rd, nccl_single)
+    AL = patch_dist(monkeypatch, grid)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(ws)]
+    torch.cuda.synchronize()
+
+    def rank_fn(r):
+        torch.cuda.set_device(dev)
+        lq, lk, lv, ldo = loc[r]
+        upg, rpg = grid.groups_of(r)
+        ctx = _Ctx()
+        with torch.cuda.stream(streams[r]):
+            out = AL._AsyncUSPFunc.forward(ctx, lq, lk, lv, None, True, upg, rpg, "zigzag", AL._MAX_GROUPS)
+            grads = AL._AsyncUSPFunc.backward(ctx, ldo)[:3]
+        return (out,) + tuple(grads), ctx.meta[6]
+
+    res = run_grid(grid, ws, rank_fn)
+    torch.cuda.synchronize()
+    assert {n for _, n in res} == {2}                                     # two head groups per rank: the default pipeline
+    assert {kind for kind, _ in grid.calls} == {"ulysses", "ring"}
+    glob = [torch.empty_like(t) for t in (q, q, k, v)]                     # out, dq, dk, dv
+    for r in range(ws):
+        for g, shard in zip(glob, res[r][0]):
+            g[:, owned[r]] = shard
+    # the global LSE (the key columns' softmax normaliser) from ONE single-GPU forward of the same tensors; sampled_parity
+    # checks it against the exact one on its sampled rows, and that single launch's rows against the grid's
+    lse = torch.empty((1, cfg["Hq"], cfg["S"]), dtype=torch.float32, device=dev)
+    one = torch.empty_like(q)
+    _C.flash_fwd(q, k, v, cfg["D"] ** -0.5, True, lse, one)
+    # NOTE delta: the backward of rank r formed delta from ITS out rows = the rows of `glob[0]`
+    err = b.sampled_parity(dict(q=q, k=k, v=v, do=do, out=glob[0], lse=lse, dq=glob[1], dk=glob[2], dv=glob[3]))["max_abs_err"]
+    print("configs[4] at full size on the virtual grid, max abs errors vs fp64 samples:", err)      # (pytest -rP shows it)
+    assert err["out"] < 2e-2 and err["lse"] < 2e-3, err
+    g = cfg["Hq"] // cfg["Hkv"]
+    assert err["dq"] < 5e-2 and err["dk"] < 5e-2 * g ** 0.5 and err["dv"] < 5e-2 * g ** 0.5, err
+    d = (glob[0].float() - one.float()).abs()                              # the distributed result == the one-launch result
+    assert bool((d <= 2e-2 + 2e-2 * one.float().abs()).all()), float(d.max())
