@@ -240,36 +240,40 @@ def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch,
 
 
 @pytest.mark.timeout(1500)
-def test_configs4_full_size_on_a_virtual_grid_sampled_parity(nccl_single, monkeypatch):
-    """BASELINE configs[4] AT ITS OWN SIZE -- 8 ranks, ulysses 2 x ring 4, zigzag, B1 S65536 H32/Hkv4 D128 bf16 causal,
-    forward + backward -- with the 8 ranks as virtual ranks of one GPU: the layer's default schedule (packed q|k|v exchange
-    pipelined over two head groups beside the ring, zigzag mesh fetch, travelling dK/dV with the rounded, pending last hop),
-    the real kernels at the real per-rank shapes, every transfer a real RCCL call.  The eight shards are put back
-    together and checked against exact fp64 attention over all 65536 tokens on sampled rows (out, dQ) and sampled key
-    columns (dK, dV, summed over the GQA group of 8 and over every later row) -- bench.sampled_parity, the check the
-    single-GPU 64K entry of the bench line carries."""
+@pytest.mark.parametrize("n_gpus", [8, 4, 2], ids=["configs4_8gpu_u2r4_gqa_fwd_bwd", "configs3_4gpu_r4_fwd", "configs2_2gpu_u2_fwd"])
+def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatch, n_gpus):
+    """BASELINE's multi-GPU configs AT THEIR OWN SIZE with the ranks as virtual ranks of one GPU -- configs[4]: 8 ranks,
+    ulysses 2 x ring 4, zigzag, B1 S65536 H32/Hkv4 D128 bf16 causal, forward + backward; configs[3]: 4 ranks, ring 4
+    zigzag, S32768 H16, forward; configs[2]: 2 ranks, ulysses 2, S16384 H16, forward -- through the layer's default
+    schedule (packed q|k|v exchange pipelined over head groups, beside the ring where there is one; zigzag mesh fetch in
+    row-range waves; K split of few-head launches; travelling dK/dV with the rounded, pending last hop), the real kernels
+    at the real per-rank shapes, every transfer a real RCCL call.  The shards are put back together and checked against
+    the single-launch result of the same tensors and against exact fp64 attention over the whole sequence on sampled
+    rows (out, dQ) and sampled key columns (dK, dV summed over the GQA group and every later row) -- bench.sampled_parity,
+    the check the single-GPU 64K entry of the bench line carries."""
     import importlib.util
-    import yunchang_amd as Y
+    from oracle import usp_oracle as O
     from yunchang_amd import _C
     from virtual_grid import patch_dist, run_grid
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
-    cfg = b.WORKLOADS[8]
+    cfg = b.WORKLOADS[n_gpus]
     dev = torch.device("cuda:0")
-    ud, rd, ws = cfg["ud"], cfg["rd"], 8
+    ud, rd, ws, impl, bwd = cfg["ud"], cfg["rd"], n_gpus, cfg["impl"], cfg["bwd"]
     q, k, v, do = b.make_global(cfg, dev)
-    from oracle import usp_oracle as O
 
-    def ext(t, r):          # the zigzag shard of rank r (comm/extract_local.py needs the real process grid: restated, and
-        ch = t.chunk(2 * rd, dim=1)                     # held against the oracle's layout right below)
+    def ext(t, r):          # the shard of rank r (comm/extract_local.py needs the real process grid: restated, and held
+        if impl == "basic":                                 # against the oracle's layout right below)
+            return t.chunk(ws, dim=1)[r]
+        ch = t.chunk(2 * rd, dim=1)
         return torch.cat([ch[r // ud], ch[2 * rd - 1 - r // ud]], dim=1).chunk(ud, dim=1)[r % ud]
     rows = torch.arange(cfg["S"], device=dev).view(1, -1, 1, 1)
     owned = [ext(rows, r).reshape(-1) for r in range(ws)]                                        # global row ids per rank
     small = np.arange(64, dtype=np.float32).reshape(1, 64, 1, 1)
     for r in range(ws):
-        assert np.array_equal(ext(torch.from_numpy(small), r).numpy(), O.zigzag_extract_local(small, r, ws, rd, ud))
+        assert np.array_equal(ext(torch.from_numpy(small), r).numpy(), O.EXTRACT[impl](small, r, ws, rd, ud))
     loc = [[ext(t, r).contiguous() for t in (q, k, v, do)] for r in range(ws)]
     grid = _VirtualGrid(ud, rd, nccl_single)
     AL = patch_dist(monkeypatch, grid)
@@ -281,29 +285,37 @@ def test_configs4_full_size_on_a_virtual_grid_sampled_parity(nccl_single, monkey
         lq, lk, lv, ldo = loc[r]
         upg, rpg = grid.groups_of(r)
         ctx = _Ctx()
+        ctx.needs_input_grad = (bwd, bwd, bwd)                # forward-only configs: head groups sized for the K split
         with torch.cuda.stream(streams[r]):
-            out = AL._AsyncUSPFunc.forward(ctx, lq, lk, lv, None, True, upg, rpg, "zigzag", AL._MAX_GROUPS)
-            grads = AL._AsyncUSPFunc.backward(ctx, ldo)[:3]
+            if ud == 1:       # no exchange: the layer hands q, k, v straight to the ring function (hybrid/attn_layer.py)
+                import yunchang_amd.ring.zigzag_ring_flash_attn as Z
+                return (Z.zigzag_ring_flash_attn_forward(rpg, lq, lk, lv, cfg["D"] ** -0.5)[0],), 1
+            out = AL._AsyncUSPFunc.forward(ctx, lq, lk, lv, None, True, upg, rpg, impl, AL._MAX_GROUPS)
+            grads = AL._AsyncUSPFunc.backward(ctx, ldo)[:3] if bwd else ()
         return (out,) + tuple(grads), ctx.meta[6]
 
     res = run_grid(grid, ws, rank_fn)
     torch.cuda.synchronize()
-    assert {n for _, n in res} == {2}                                     # two head groups per rank: the default pipeline
-    assert {kind for kind, _ in grid.calls} == {"ulysses", "ring"}
-    glob = [torch.empty_like(t) for t in (q, q, k, v)]                     # out, dq, dk, dv
+    assert {n for _, n in res} == {{8: 2, 4: 1, 2: 4}[n_gpus]}            # head groups per rank: the default pipeline
+    assert {kind for kind, _ in grid.calls} == {"ulysses", "ring"} - ({"ulysses"} if ud == 1 else set()) - ({"ring"} if rd == 1 else set())
+    glob = [torch.empty_like(t) for t in ((q, q, k, v) if bwd else (q,))]      # out [, dq, dk, dv]
     for r in range(ws):
         for g, shard in zip(glob, res[r][0]):
             g[:, owned[r]] = shard
-    # the global LSE (the key columns' softmax normaliser) from ONE single-GPU forward of the same tensors; sampled_parity
-    # checks it against the exact one on its sampled rows, and that single launch's rows against the grid's
+    # ONE single-GPU forward of the same tensors: its rows against the grid's, and its LSE as the key columns' softmax
+    # normaliser (sampled_parity checks that LSE against the exact one on its sampled rows)
     lse = torch.empty((1, cfg["Hq"], cfg["S"]), dtype=torch.float32, device=dev)
     one = torch.empty_like(q)
     _C.flash_fwd(q, k, v, cfg["D"] ** -0.5, True, lse, one)
-    # NOTE delta: the backward of rank r formed delta from ITS out rows = the rows of `glob[0]`
-    err = b.sampled_parity(dict(q=q, k=k, v=v, do=do, out=glob[0], lse=lse, dq=glob[1], dk=glob[2], dv=glob[3]))["max_abs_err"]
-    print("configs[4] at full size on the virtual grid, max abs errors vs fp64 samples:", err)      # (pytest -rP shows it)
-    assert err["out"] < 2e-2 and err["lse"] < 2e-3, err
-    g = cfg["Hq"] // cfg["Hkv"]
-    assert err["dq"] < 5e-2 and err["dk"] < 5e-2 * g ** 0.5 and err["dv"] < 5e-2 * g ** 0.5, err
-    d = (glob[0].float() - one.float()).abs()                              # the distributed result == the one-launch result
+    d = (glob[0].float() - one.float()).abs()
     assert bool((d <= 2e-2 + 2e-2 * one.float().abs()).all()), float(d.max())
+    if not bwd:
+        glob += [torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)]
+    err = b.sampled_parity(dict(q=q, k=k, v=v, do=do, out=glob[0], lse=lse, dq=glob[1], dk=glob[2], dv=glob[3]))["max_abs_err"]
+    if not bwd:
+        err = {n: err[n] for n in ("out", "lse")}
+    print(f"{cfg['name']}: virtual grid at full size, max abs errors vs fp64 samples:", err)      # (pytest -rP shows it)
+    assert err["out"] < 2e-2 and err["lse"] < 2e-3, err
+    if bwd:
+        g = cfg["Hq"] // cfg["Hkv"]
+        assert err["dq"] < 5e-2 and err["dk"] < 5e-2 * g ** 0.5 and err["dv"] < 5e-2 * g ** 0.5, err
