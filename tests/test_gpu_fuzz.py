@@ -40,25 +40,36 @@ def _dense_case(rs):
     Sq = int(rs.randint(1, 700))
     Sk = Sq if rs.rand() < 0.5 else int(rs.randint(1, 700))
     causal = bool(rs.rand() < 0.6)
-    return B, Sq, Sk, Hq, Hkv, D, causal, dt
+    # (drawn last, so that the shapes of the earlier rounds' seeds stay what they were)  a third of the cases carry a
+    # sliding window, a third the K split of the forward and cuts of the two backward launches (ABI v5)
+    win = None
+    if rs.rand() < 0.33:
+        win = (int(rs.choice([-1, 0, 1, 17, 64, 200, 1000])), int(rs.choice([-1, 0, 3, 40])))
+        if win == (-1, -1):
+            win = (33, 0)
+    ks, cuts = 0, (0, 0)
+    if rs.rand() < 0.33:
+        ks, cuts = int(rs.choice([2, 3, 5, 8])), (int(rs.choice([0, 2, 3, 8])), int(rs.choice([0, 2, 4])))
+    return B, Sq, Sk, Hq, Hkv, D, causal, dt, win, ks, cuts
 
 
 @pytest.mark.parametrize("seed", range(_N_DENSE))
 def test_fuzz_dense(dev, seed):
     from yunchang_amd import _C
     rs = np.random.RandomState(1000 + seed)
-    B, Sq, Sk, Hq, Hkv, D, causal, dt = _dense_case(rs)
-    what = f"B{B} Sq{Sq} Sk{Sk} Hq{Hq} Hkv{Hkv} D{D} causal={causal} {dt}"
+    B, Sq, Sk, Hq, Hkv, D, causal, dt, win, ks, cuts = _dense_case(rs)
+    what = f"B{B} Sq{Sq} Sk{Sk} Hq{Hq} Hkv{Hkv} D{D} causal={causal} {dt} window={win} k_splits={ks} cuts={cuts}"
+    wkw = {} if win is None else {"window": win}
     q, k, v, do = (round_to(rs.standard_normal(s).astype(np.float32), dt)
                    for s in [(B, Sq, Hq, D), (B, Sk, Hkv, D), (B, Sk, Hkv, D), (B, Sq, Hq, D)])
     tq, tk, tv, tdo = (_t(x, dt, dev) for x in (q, k, v, do))
     scale = D ** -0.5
-    ro, rl = O.block_fwd(q, k, v, scale, causal)
+    ro, rl = O.attention_ref(q, k, v, causal, scale, **wkw)
     runs = []
     for _ in range(2):
         out = torch.full((B, Sq, Hq, D), float("nan"), dtype=tq.dtype, device=dev)
         lse = torch.full((B, Hq, Sq), float("nan"), dtype=torch.float32, device=dev)
-        _C.flash_fwd(tq, tk, tv, scale, causal, lse, out=out, interleave=len(runs) == 1)
+        _C.flash_fwd(tq, tk, tv, scale, causal, lse, out=out, interleave=len(runs) == 1, k_splits=ks, **wkw)
         runs.append((_f(out), _f(lse)))
     assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1]), what
     fin = np.isfinite(rl)
@@ -66,7 +77,7 @@ def test_fuzz_dense(dev, seed):
     assert_close(runs[0][0], ro, *TOL[dt]["out"], what + " out")
     assert_close(runs[0][1][fin], rl[fin], 2e-3, 1e-4, what + " lse")
     o16 = round_to(ro.astype(np.float32), dt)
-    rdq, rdk, rdv = O.block_bwd(do, q, k, v, o16, rl, scale, causal)
+    rdq, rdk, rdv = O.block_bwd(do, q, k, v, o16, rl, scale, causal, **wkw)
     lse_t = torch.from_numpy(np.ascontiguousarray(rl, dtype=np.float32)).to(dev)
     delta = torch.empty((B, Hq, Sq), dtype=torch.float32, device=dev)
     _C.bwd_delta(tdo, _t(o16, dt, dev), delta)
@@ -74,7 +85,7 @@ def test_fuzz_dense(dev, seed):
     for _ in range(2):
         dq, dk, dv = (torch.full_like(t, float("nan")) for t in (tq, tk, tv))
         _C.flash_bwd(tdo, tq, tk, tv, lse_t, delta, None, None, None, scale, causal, dq16=dq, dk16=dk, dv16=dv,
-                     interleave=len(grads) == 1)
+                     interleave=len(grads) == 1, splits=cuts, **wkw)
         grads.append([_f(x) for x in (dq, dk, dv)])
     for a_, b_, n_ in zip(grads[0], grads[1], ("dq", "dk", "dv")):
         assert np.array_equal(a_, b_), f"{what}: {n_} differs between two launches"
