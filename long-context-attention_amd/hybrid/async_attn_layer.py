@@ -20,6 +20,7 @@ from torch import Tensor
 
 from ..comm import all_to_all as A
 from ..comm.link import link_bytes_per_s
+from ..kernels.attention import kernel_head_dim, pad_head_dim
 from ..globals import PROCESS_GROUP
 from ..kernels import AttnType
 from ..ring.ring_flash_attn import ring_flash_attn_backward, ring_flash_attn_forward
@@ -347,5 +348,10 @@ class AsyncLongContextAttention(torch.nn.Module):
         """query (bs, seqlen/P, hc, hs); key/value (bs, seqlen/P, hc_kv, hs) -> (bs, seqlen/P, hc, hs)."""
         assert alibi_slopes is None
         _check_hot_path_args(dropout_p, window_size, softcap)
-        return _AsyncUSPFunc.apply(query, key, value, softmax_scale, causal, self.ulysses_pg, self.ring_pg,
-                                   self.ring_impl_type)
+        D = query.shape[-1]
+        if kernel_head_dim(D) != D:      # a head dim the kernels do not instantiate: zero-padded copies
+            query, key, value = pad_head_dim(query, key, value)
+            softmax_scale = D ** -0.5 if softmax_scale is None else softmax_scale
+        out = _AsyncUSPFunc.apply(query, key, value, softmax_scale, causal, self.ulysses_pg, self.ring_pg,
+                                  self.ring_impl_type)
+        return out[..., :D]

@@ -17,7 +17,7 @@ from torch import Tensor
 from ..comm.all_to_all import SeqAllToAll4D, SeqAllToAll5D
 from ..globals import PROCESS_GROUP
 from ..kernels import AttnType
-from ..kernels.attention import window_of
+from ..kernels.attention import kernel_head_dim, pad_head_dim, window_of
 from ..ring.zigzag_ring_flash_attn import _check_hot_path_args
 from .async_attn_layer import _AsyncUSPFunc, _MAX_GROUPS, _RING_FWD_BWD, pipeline_mode
 from .utils import RING_IMPL_DICT, RING_IMPL_QKVPACKED_DICT
@@ -111,6 +111,11 @@ class LongContextAttention(_USPLayer):
                 deterministic=False, return_attn_probs=False, *args: Any) -> Tensor:
         """query (bs, seq_len/N, head_cnt, head_size); key/value (bs, seq_len/N, kv_head_cnt,
         head_size) -> context (bs, seq_len/N, head_cnt, head_size)."""
+        D = query.shape[-1]
+        if kernel_head_dim(D) != D:      # a head dim the kernels do not instantiate (e.g. 96): zero-padded copies
+            out = self.forward(*pad_head_dim(query, key, value), dropout_p, D ** -0.5 if softmax_scale is None else softmax_scale,
+                               causal, window_size, softcap, alibi_slopes, deterministic, return_attn_probs, *args)
+            return out[..., :D]
         ng_cap = self._packed_exchange(query, key)
         if ng_cap is not None and window_of(window_size) is not None:
             ng_cap = None         # a sliding window: the reference's structure (three exchanges); the ring function
@@ -146,6 +151,11 @@ class LongContextAttentionQKVPacked(_USPLayer):
     def forward(self, qkv, dropout_p=0.0, softmax_scale=None, causal=False, window_size=(-1, -1),
                 softcap=0.0, alibi_slopes=None, deterministic=False, return_attn_probs=False,
                 *args: Any) -> Tensor:
+        D = qkv.shape[-1]
+        if kernel_head_dim(D) != D:
+            out = self.forward(pad_head_dim(qkv)[0], dropout_p, D ** -0.5 if softmax_scale is None else softmax_scale, causal,
+                               window_size, softcap, alibi_slopes, deterministic, return_attn_probs, *args)
+            return out[..., :D]
         exchange = self.ulysses_size > 1
         if exchange:         # scatter 3 (heads), gather 1 (sequence)
             qkv = SeqAllToAll5D.apply(self.ulysses_pg, qkv, self.scatter_idx, self.gather_idx, self.use_sync, False)

@@ -28,6 +28,30 @@ def kernel_operand(t: torch.Tensor) -> torch.Tensor:
     return t if ok else t.contiguous()
 
 
+KERNEL_HEAD_DIMS = (32, 64, 128)      # what libusp_hip.so instantiates (include/usp_hip.h: anything else is USP_EUNSUPPORTED)
+
+
+def kernel_head_dim(D: int) -> int:
+    """The head dim the kernels run a `D`-dim problem at: the smallest instantiated one that holds it.  Zero-padding the head
+    dim changes neither the scores (the pad contributes 0 to every dot product; the softmax scale stays D ** -0.5) nor the first D
+    output dims, so head dims such as 40, 72, 80, 96, 112 -- which flash-attn serves (kernels/attention.py:177-202: any
+    multiple of 8 up to 256) -- run through the entry points of this package on padded copies, at the padded dim's cost.
+    Above 128 there is no kernel (a 256-dim tile does not fit the 256-register budget of the 8-wave shape)."""
+    for d in KERNEL_HEAD_DIMS:
+        if D <= d:
+            return d
+    raise NotImplementedError(f"head_dim {D} > {KERNEL_HEAD_DIMS[-1]} is not supported by the HIP attention kernels")
+
+
+def pad_head_dim(*tensors):
+    """Zero-pad the last dim of each tensor to kernel_head_dim (autograd-aware: torch.nn.functional.pad)."""
+    D = tensors[0].shape[-1]
+    Dp = kernel_head_dim(D)
+    if Dp == D:
+        return tensors
+    return tuple(torch.nn.functional.pad(t, (0, Dp - D)) for t in tensors)
+
+
 def needs_grad(*tensors) -> bool:
     """Does autograd have to record this call?  (The ring functions skip their autograd.Function otherwise.)"""
     return torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
@@ -142,10 +166,13 @@ def hip_attn_forward(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, w
     Unlike the TORCH_* wrappers (attention.py:135) the LSE is NOT rounded to q.dtype."""
     _check_plain(dropout_p, softcap, alibi_slopes)
     B, Sq, Hq, D = q.shape
+    scale = _default_scale(q, softmax_scale)
+    if kernel_head_dim(D) != D:                 # e.g. 96: on zero-padded copies (kernel_head_dim)
+        out, lse = hip_attn_forward(*pad_head_dim(q, k, v), softmax_scale=scale, causal=causal, window_size=window_size)
+        return out[..., :D].contiguous(), lse
     out = torch.empty((B, Sq, Hq, D), dtype=q.dtype, device=q.device)
     lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device)
-    get_block_backend().fwd(q, k, v, _default_scale(q, softmax_scale), bool(causal), lse, out=out,
-                            window=window_of(window_size))
+    get_block_backend().fwd(q, k, v, scale, bool(causal), lse, out=out, window=window_of(window_size))
     return out, lse
 
 
@@ -160,6 +187,14 @@ def hip_attn_backward(dout, q, k, v, out, softmax_lse, block_dq_buffer, block_dk
     be = get_block_backend()
     B, Sq, Hq, D = q.shape
     dev = q.device
+    if kernel_head_dim(D) != D:                 # on zero-padded copies; the first D dims of the gradients are the answer
+        pdo, pq, pk, pv, po = pad_head_dim(dout, q, k, v, out)
+        g = [torch.empty_like(t) for t in (pq, pk, pv)]
+        hip_attn_backward(pdo, pq, pk, pv, po, softmax_lse, g[0], g[1], g[2], dropout_p, _default_scale(q, softmax_scale),
+                          bwd_causal, window_size, softcap, alibi_slopes, deterministic, rng_state)
+        for dst, src in zip((block_dq_buffer, block_dk_buffer, block_dv_buffer), g):
+            dst.copy_(src[..., :D])
+        return
     delta = torch.empty((B, Hq, Sq), dtype=torch.float32, device=dev)
     be.delta(dout, out, delta)
     lse = softmax_lse if softmax_lse.dtype == torch.float32 else softmax_lse.float()
@@ -208,6 +243,11 @@ def hip_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=False, wind
     """`fwd-bwd` contract (flash_attn_func's signature): `out`, or `(out, softmax_lse, None)` with
     return_attn_probs (the probabilities themselves are never materialised: dropout is 0)."""
     _check_plain(dropout_p, softcap, alibi_slopes)
+    D = q.shape[-1]
+    if kernel_head_dim(D) != D:                 # on zero-padded copies (autograd differentiates the pad and the slice)
+        res = hip_attn_func(*pad_head_dim(q, k, v), softmax_scale=_default_scale(q, softmax_scale), causal=causal,
+                            window_size=window_size, return_attn_probs=return_attn_probs)
+        return (res[0][..., :D], res[1], None) if return_attn_probs else res[..., :D]
     if return_attn_probs:
         out, lse = _HipAttnFunc.apply(q, k, v, softmax_scale, causal, True, window_size)
         return out, lse, None

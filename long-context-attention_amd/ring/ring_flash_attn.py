@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 
 from ..kernels import AttnType
-from ..kernels.attention import get_block_backend, kernel_operand, needs_grad, window_of
+from ..kernels.attention import get_block_backend, kernel_head_dim, kernel_operand, needs_grad, pad_head_dim, window_of
 from .utils import FULL, KVRelay, group_info, final_grads, travel_dkdv
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
@@ -165,6 +165,11 @@ def ring_flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=Fals
                          window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
                          return_attn_probs=False, group=None, attn_type: AttnType = AttnType.HIP,
                          attn_processor=None):
+    D = q.shape[-1]
+    if kernel_head_dim(D) != D:      # a head dim the kernels do not instantiate (e.g. 96): zero-padded copies
+        res = ring_flash_attn_func(*pad_head_dim(q, k, v), dropout_p, D ** -0.5 if softmax_scale is None else softmax_scale, causal,
+                                   window_size, softcap, alibi_slopes, deterministic, return_attn_probs, group, attn_type, attn_processor)
+        return (res[0][..., :D],) + tuple(res[1:]) if isinstance(res, tuple) else res[..., :D]
     if not needs_grad(q, k, v):      # inference / forward-only benchmarks: no autograd node, no saved tensors (~25 us)
         assert alibi_slopes is None
         _check_hot_path_args(dropout_p, (-1, -1), softcap)

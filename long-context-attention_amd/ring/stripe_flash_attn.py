@@ -13,7 +13,7 @@ import torch
 import torch.distributed as dist
 
 from ..kernels import AttnType
-from ..kernels.attention import get_block_backend, kernel_operand
+from ..kernels.attention import get_block_backend, kernel_head_dim, kernel_operand, pad_head_dim
 from .utils import FULL, KVRelay, group_info, final_grads, travel_dkdv
 from .zigzag_ring_flash_attn import _check_hot_path_args
 
@@ -157,5 +157,10 @@ def stripe_flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, causal=Fa
                            window_size=(-1, -1), softcap=0.0, alibi_slopes=None, deterministic=False,
                            return_attn_probs=False, group=None, attn_type: AttnType = AttnType.HIP,
                            attn_processor=None):
+    D = q.shape[-1]
+    if kernel_head_dim(D) != D:      # a head dim the kernels do not instantiate (e.g. 96): zero-padded copies
+        res = stripe_flash_attn_func(*pad_head_dim(q, k, v), dropout_p, D ** -0.5 if softmax_scale is None else softmax_scale, causal,
+                                     window_size, softcap, alibi_slopes, deterministic, return_attn_probs, group, attn_type, attn_processor)
+        return (res[0][..., :D],) + tuple(res[1:]) if isinstance(res, tuple) else res[..., :D]
     return StripeFlashAttnFunc.apply(q, k, v, dropout_p, softmax_scale, causal, window_size, softcap,
                                      alibi_slopes, deterministic, return_attn_probs, group, attn_type)

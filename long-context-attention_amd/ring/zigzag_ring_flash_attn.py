@@ -22,7 +22,7 @@ import torch
 import torch.distributed as dist
 
 from ..kernels import AttnType
-from ..kernels.attention import get_block_backend, kernel_operand, needs_grad
+from ..kernels.attention import get_block_backend, kernel_head_dim, kernel_operand, needs_grad, pad_head_dim
 from .utils import FULL, KVRelay, group_info, ZigzagKVFetch, final_grads, kv_relay_mode, travel_dkdv, zigzag_fetch_pieces
 
 
@@ -236,6 +236,11 @@ def zigzag_ring_flash_attn_func(q, k, v, dropout_p=0.0, softmax_scale=None, caus
                                 window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
                                 deterministic=False, return_attn_probs=False, group=None,
                                 attn_type: AttnType = AttnType.HIP, attn_processor=None):
+    D = q.shape[-1]
+    if kernel_head_dim(D) != D:      # a head dim the kernels do not instantiate (e.g. 96): zero-padded copies
+        res = zigzag_ring_flash_attn_func(*pad_head_dim(q, k, v), dropout_p, D ** -0.5 if softmax_scale is None else softmax_scale, causal,
+                                          window_size, softcap, alibi_slopes, deterministic, return_attn_probs, group, attn_type, attn_processor)
+        return (res[0][..., :D],) + tuple(res[1:]) if isinstance(res, tuple) else res[..., :D]
     if not needs_grad(q, k, v):      # inference / forward-only benchmarks: no autograd node, no saved tensors
         assert alibi_slopes is None
         _check_hot_path_args(dropout_p, window_size, softcap)

@@ -580,3 +580,39 @@ def _window_worker(rank, ws, ud, rd):
 @pytest.mark.parametrize("ws,ud,rd", [(2, 2, 1), (1, 1, 1), (2, 1, 2)])
 def test_sliding_window_through_the_layers(ws, ud, rd):
     assert all(run_distributed(_window_worker, ws, ud, rd))
+
+
+def _head_dim_worker(rank, ws, ud, rd, impl, D):
+    """A head dim the kernels do not instantiate (96, 80, 40): the layers run it on zero-padded copies -- out and gradients
+    against exact attention at the ORIGINAL head dim (softmax scale D ** -0.5)."""
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    from oracle import usp_oracle as O
+    set_block_backend(OracleBlockBackend())
+    Y.set_seq_parallel_pg(ud, rd, rank, ws)
+    torch.manual_seed(0)
+    B, S, Hq, Hkv = 1, 64 * ws, 4, 2
+    q, k, v, do = (torch.randn(B, S, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
+    ext = Y.EXTRACT_FUNC_DICT[impl]
+    qn, kn, vn, don = (t.float().numpy().astype(np.float64) for t in (q, k, v, do))
+    ro, rl = O.attention_ref(qn, kn, vn, causal=True)
+    truth = [ext(torch.from_numpy(np.ascontiguousarray(t)), rank, world_size=ws, rd=rd, ud=ud).float()
+             for t in (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, True))]
+    ok = True
+    for cls in (Y.LongContextAttention, Y.AsyncLongContextAttention):
+        lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=rd, ud=ud).detach().clone() for t in (q, k, v, do))
+        for t in (lq, lk, lv):
+            t.requires_grad_(True)
+        out = cls(ring_impl_type=impl)(lq, lk, lv, causal=True)
+        assert out.shape[-1] == D
+        out.backward(ldo)
+        got = [t.detach().float() for t in (out, lq.grad, lk.grad, lv.grad)]
+        ok = ok and all(g.shape == t.shape and torch.allclose(g, t, atol=tol, rtol=tol)
+                        for g, t, tol in zip(got, truth, (2e-2, 5e-2, 5e-2, 5e-2)))
+    return ok
+
+
+@pytest.mark.parametrize("ws,ud,rd,impl,D", [(2, 2, 1, "basic", 96), (4, 2, 2, "zigzag", 80), (1, 1, 1, "basic", 40)])
+def test_head_dims_between_the_instantiated_ones_run_padded(ws, ud, rd, impl, D):
+    assert all(run_distributed(_head_dim_worker, ws, ud, rd, impl, D))

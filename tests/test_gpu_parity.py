@@ -1078,3 +1078,37 @@ def test_sliding_window_through_the_block_contract_and_the_layer(dev, single_ran
     assert_close(_f(o2), ro, *TOL["bfloat16"]["out"], "layer out")
     for leaf, ref, name in zip(leaves, refs, ("dq", "dk", "dv")):
         assert_close(_f(leaf.grad), ref, *TOL["bfloat16"]["grad"], f"layer {name}")
+
+
+@pytest.mark.parametrize("D", [96, 80, 40, 120])
+def test_head_dims_between_the_instantiated_ones(dev, single_rank_pg, D):
+    """Head dims flash-attn serves and this library does not instantiate (multiples of 8 below 128): the block contract
+    (fwd-only / bwd-only / fwd-bwd) and the layer run them on zero-padded copies, against the oracle at the ORIGINAL head
+    dim; above 128 the refusal is a NotImplementedError, not a wrong answer."""
+    import yunchang_amd as Y
+    from yunchang_amd.kernels import hip_attn_backward, hip_attn_forward, hip_attn_func
+    B, S, Hq, Hkv = 1, 320, 4, 2
+    q, k, v, do = (_rand(s, "bfloat16", 120 + i) for i, s in enumerate([(B, S, Hq, D), (B, S, Hkv, D), (B, S, Hkv, D), (B, S, Hq, D)]))
+    ro, rl = O.attention_ref(q, k, v, causal=True)
+    refs = O.block_bwd(do, q, k, v, ro, rl, None, True)
+    tq, tk, tv, tdo = (_t(x, "bfloat16", dev) for x in (q, k, v, do))
+    out, lse = hip_attn_forward(tq, tk, tv, causal=True)
+    assert out.shape == tq.shape
+    assert_close(_f(out), ro, *TOL["bfloat16"]["out"], "fwd-only")
+    assert_close(_f(lse), rl, 2e-3, 1e-4, "lse")
+    g = [torch.empty_like(t) for t in (tq, tk, tv)]
+    hip_attn_backward(tdo, tq, tk, tv, out, lse, g[0], g[1], g[2], 0.0, None, True)
+    atol, rtol = grad_tol("bfloat16", Hq // Hkv)
+    for got, ref, name in zip(g, refs, ("dq", "dk", "dv")):
+        assert_close(_f(got), ref, atol, rtol, f"bwd-only {name}")
+    for fn in (lambda a, b, c: hip_attn_func(a, b, c, causal=True),
+               lambda a, b, c: Y.LongContextAttention(ring_impl_type="zigzag", attn_type=Y.AttnType.HIP)(a, b, c, causal=True)):
+        leaves = [t.clone().requires_grad_(True) for t in (tq, tk, tv)]
+        o2 = fn(*leaves)
+        o2.backward(tdo)
+        assert_close(_f(o2), ro, *TOL["bfloat16"]["out"], "fwd-bwd out")
+        for leaf, ref, name in zip(leaves, refs, ("dq", "dk", "dv")):
+            assert_close(_f(leaf.grad), ref, atol, rtol, f"fwd-bwd {name}")
+    big = torch.zeros((1, 64, 2, 256), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(NotImplementedError):
+        hip_attn_forward(big, big, big, causal=True)
