@@ -1,4 +1,4 @@
-# usage: bash tools/r03_ab.sh variant [variant ...]   -- native suite (bwd) + rocprof kernel times at C2 for each variant under abl/
+# usage: bash tools/r03/r03_ab.sh variant [variant ...]   -- native suite (bwd) + rocprof kernel times at C2 for each variant under abl/
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/r03; mkdir -p $OUT; cd $R
 K=./long-context-attention_amd/kbench
 for v in "$@"; do

@@ -1,4 +1,4 @@
-# usage (on the GPU box, from the repo root): bash tools/r03_call1.sh
+# usage (on the GPU box, from the repo root): bash tools/r03/r03_call1.sh
 # Round 3, first GPU contact: (1) the whole GPU suite with everything round 2 left staged now ON (K split through the
 # binding = default policy, direct dK/dV return, operand normalisation) plus the new RCCL virtual-grid test; (2) the
 # driver's bench command three times on this box (the N=1 step must land within 3 % of the kernel); (3) the dK/dV
