@@ -792,6 +792,7 @@ def main(argv=None, dev=None):
             line["cpu_baseline"] = cpu_baseline(cfg)
     emit()
     barrier(ws)
+    AL._COMM_OVERRIDE.clear()            # (the staged measurement set the communicator mode in-process)
     if own_pg:
         dist.destroy_process_group()
 

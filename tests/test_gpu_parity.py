@@ -185,10 +185,16 @@ def test_merge_copy_cast_add_kernels(dev):
 
 
 def test_unsupported_arguments_raise(dev):
+    from yunchang_amd import _C
     from yunchang_amd.kernels import hip_attn_forward
     q = torch.randn(1, 64, 2, 96, device=dev, dtype=torch.bfloat16)
-    with pytest.raises(RuntimeError, match="unsupported"):
-        hip_attn_forward(q, q, q)
+    lse = torch.empty((1, 2, 64), dtype=torch.float32, device=dev)
+    with pytest.raises(RuntimeError, match="unsupported"):      # the C ABI instantiates head dims 32 / 64 / 128 ...
+        _C.flash_fwd(q, q, q, 0.1, False, lse, torch.empty_like(q))
+    assert hip_attn_forward(q, q, q)[0].shape == q.shape        # ... the entry points serve the ones below 128 padded
+    big = torch.randn(1, 64, 2, 256, device=dev, dtype=torch.bfloat16)
+    with pytest.raises(NotImplementedError):
+        hip_attn_forward(big, big, big)
     q32 = torch.randn(1, 64, 2, 64, device=dev)
     with pytest.raises(TypeError):
         hip_attn_forward(q32, q32, q32)
