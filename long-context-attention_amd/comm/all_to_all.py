@@ -18,6 +18,7 @@ import torch.distributed as dist
 from torch import Tensor
 
 from ..kernels.attention import get_block_backend
+from . import relay_exchange
 
 
 def seq_major_empty(B, S, H, D, dtype, device):
@@ -52,6 +53,11 @@ def _copy_rows(dst: Tensor, src: Tensor, row_elems: int, sizes, dst_strides, src
 
 
 def _exchange(send: Tensor, group, use_sync: bool) -> Tensor:
+    if relay_exchange.applicable(send, group):       # a pair's exchange striped over the idle mesh links (opt-in)
+        recv = relay_exchange.exchange_relayed(send, group)
+        if use_sync and send.is_cuda:
+            torch.cuda.synchronize()
+        return recv
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send, group=group)
     if use_sync and send.is_cuda:

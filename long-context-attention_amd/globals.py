@@ -61,6 +61,8 @@ def set_seq_parallel_pg(sp_ulysses_degree, sp_ring_degree, rank, world_size, use
 
     PROCESS_GROUP.ULYSSES_PG = ulysses_pg
     PROCESS_GROUP.RING_PG = ring_pg
+    from .comm import relay_exchange
+    relay_exchange.GRID = (sp_ulysses_degree, sp_ring_degree, world_size, bool(use_ulysses_low))      # who is whose peer
     # every rank is here by contract: the one collective moment to measure what the schedules size themselves by
     from .comm.link import probe_link_rate
     probe_link_rate(rank, world_size)

@@ -163,7 +163,7 @@ def _main_worker(rank, ws):
     else:
         assert set(line["overlap"]) >= {"value", "ms_iter", "ms_compute_only", "ms_comm_only"}
     if ws == 8:       # ulysses 2 x ring 4: two communicators -> the safe mode is measured first, then the overlapped one
-        assert set(line["comm_modes_ms_per_step"]) == {"safe", "overlapped"}
+        assert set(line["comm_modes_ms_per_step"]) == {"safe", "overlapped", "relayed"}
         assert line["config"]["comm_mode"].startswith(("safe", "overlapped"))
         assert line["ms_per_step"] == min(line["comm_modes_ms_per_step"].values())
     else:

@@ -500,7 +500,7 @@ def test_zigzag_fetch_ungrouped_switch_gives_the_same_result(monkeypatch):
 GRID = [f for f in golden_files() if Golden(f).ud > 1 and Golden(f).rd > 1 and Golden(f).layer == "hybrid"]
 
 
-@pytest.mark.parametrize("mode", ["pipelined", "safe"])
+@pytest.mark.parametrize("mode", ["pipelined", "safe", "relay"])
 @pytest.mark.parametrize("path", GRID, ids=lambda p: p.split("/")[-1][:-4])
 def test_virtual_grid_runs_the_layer_for_every_rank_in_one_process(monkeypatch, path, mode):
     """tests/virtual_grid.py on host tensors (the harness the RCCL ordering test uses on the GPU): all ranks of a
@@ -516,6 +516,8 @@ def test_virtual_grid_runs_the_layer_for_every_rank_in_one_process(monkeypatch, 
     AL = patch_dist(monkeypatch, grid)
     monkeypatch.setattr(AL, "_FILL_ITEMS", 1)
     monkeypatch.setitem(AL._COMM_OVERRIDE, "safe", mode == "safe")
+    import yunchang_amd.comm.relay_exchange as RX
+    monkeypatch.setitem(RX._OVERRIDE, "relay", mode == "relay")      # the pair exchange striped over the other ranks
     dtype = getattr(torch, g.dtype)
     loc = [[torch.from_numpy(np.ascontiguousarray(g.shard(x, r))).to(dtype) for x in (g.q, g.k, g.v, g.dout)]
            for r in range(g.ws)]
@@ -525,7 +527,7 @@ def test_virtual_grid_runs_the_layer_for_every_rank_in_one_process(monkeypatch, 
             q, k, v, do = loc[r]
             upg, rpg = grid.groups_of(r)
             ctx = Ctx()
-            cap = AL._MAX_GROUPS if AL.pipeline_mode(g.rd) or mode == "pipelined" and not AL.safe_comm() else 1
+            cap = AL._MAX_GROUPS if AL.pipeline_mode(g.rd) else 1
             out = AL._AsyncUSPFunc.forward(ctx, q, k, v, None, g.causal, upg, rpg, g.impl, cap)
             grads = AL._AsyncUSPFunc.backward(ctx, do)[:3] if g.bwd else ()
             return (out,) + tuple(grads), ctx.meta[6]
@@ -534,7 +536,7 @@ def test_virtual_grid_runs_the_layer_for_every_rank_in_one_process(monkeypatch, 
         set_block_backend(prev)
     ng = {n for _, n in res}
     assert ng == ({1} if mode == "safe" else {min(AL._MAX_GROUPS, g.Hkv // g.ud)}), ng
-    assert {k for k, _ in grid.calls} == {"ulysses", "ring"}
+    assert {k for k, _ in grid.calls} == ({"world", "ring"} if mode == "relay" and g.ud == 2 else {"ulysses", "ring"})
     for r in range(g.ws):
         for t, name in zip(res[r][0], ("out", "dq", "dk", "dv")):
             tol = TOL[g.dtype]["out"] if name == "out" else grad_tol(g.dtype, g.Hq // g.Hkv if name != "dq" else 1)
@@ -616,3 +618,51 @@ def _head_dim_worker(rank, ws, ud, rd, impl, D):
 @pytest.mark.parametrize("ws,ud,rd,impl,D", [(2, 2, 1, "basic", 96), (4, 2, 2, "zigzag", 80), (1, 1, 1, "basic", 40)])
 def test_head_dims_between_the_instantiated_ones_run_padded(ws, ud, rd, impl, D):
     assert all(run_distributed(_head_dim_worker, ws, ud, rd, impl, D))
+
+
+def _relay_worker(rank, ws, ud, rd, low):
+    """comm/relay_exchange.py: a pair's exchange striped over the other ranks (two grouped send/recv phases on the world
+    group) must land the same bytes in the same places as all_to_all_single -- raw buffers with odd row counts, then the
+    whole layer (forward + backward) with the relay on against the relay off, bit for bit."""
+    import yunchang_amd as Y
+    import yunchang_amd.comm.all_to_all as A
+    import yunchang_amd.comm.relay_exchange as RX
+    import yunchang_amd.hybrid.async_attn_layer as AL
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    set_block_backend(OracleBlockBackend())
+    Y.set_seq_parallel_pg(ud, rd, rank, ws, use_ulysses_low=low)
+    upg = Y.PROCESS_GROUP.ULYSSES_PG
+    ok = RX.GRID == (ud, rd, ws, low)
+    for rows in (37, 64, ws + 1, 5):                       # 5 rows over 6 helpers + 2: stripes of 0 rows -> not applicable
+        torch.manual_seed(rank * 100 + rows)
+        send = torch.randn(2, rows, 3, 8)
+        want = A._exchange(send, upg, False)
+        RX._OVERRIDE["relay"] = True
+        try:
+            used = RX.applicable(send, upg)
+            got = A._exchange(send, upg, False)
+        finally:
+            RX._OVERRIDE.clear()
+        ok = ok and torch.equal(got, want) and used == (rows // (ws - 2 + 2) > 0)
+    AL._FILL_ITEMS = 1
+    torch.manual_seed(0)
+    B, S, Hq, Hkv, D = 2, 32 * ws, 8, 4, 32
+    q, k, v, do = (torch.randn(B, S, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
+    ext = Y.EXTRACT_FUNC_DICT["zigzag"]
+    res = []
+    for relay in (False, True):
+        RX._OVERRIDE["relay"] = relay
+        lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=rd, ud=ud).detach().clone() for t in (q, k, v, do))
+        for t in (lq, lk, lv):
+            t.requires_grad_(True)
+        out = Y.LongContextAttention(ring_impl_type="zigzag")(lq, lk, lv, causal=True)
+        out.backward(ldo)
+        res.append([t.detach().clone() for t in (out, lq.grad, lk.grad, lv.grad)])
+    RX._OVERRIDE.clear()
+    return ok and all(torch.equal(a, b) for a, b in zip(*res))
+
+
+@pytest.mark.parametrize("ws,ud,rd,low", [(4, 2, 2, True), (8, 2, 4, True), (8, 2, 4, False)])
+def test_relayed_pair_exchange_is_bit_identical(ws, ud, rd, low):
+    assert all(run_distributed(_relay_worker, ws, ud, rd, low))

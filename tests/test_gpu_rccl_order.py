@@ -184,12 +184,16 @@ GRID = [f for f in golden_files() if Golden(f).ud > 1 and Golden(f).rd > 1 and G
 
 
 # (fixture, row ranges per K/V half of the zigzag mesh fetch): the row-range waves exist at ring degree > 2 only
-GRID_CASES = [(f, w) for f in GRID for w in ((1, 2) if Golden(f).impl == "zigzag" and Golden(f).rd > 2 else (1,))]
+# the third item: the pair exchange striped over the other ranks (comm/relay_exchange.py), a THIRD kind of traffic
+# (world-group send/recv) beside the two communicators' -- where it applies (ulysses 2, at least two helpers)
+GRID_CASES = [(f, w, False) for f in GRID for w in ((1, 2) if Golden(f).impl == "zigzag" and Golden(f).rd > 2 else (1,))] + \
+             [(f, 1, True) for f in GRID if Golden(f).ud == 2]
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("path,pieces", GRID_CASES, ids=lambda v: v.split("/")[-1][:-4] if isinstance(v, str) else f"pieces{v}")
-def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch, path, pieces):
+@pytest.mark.parametrize("path,pieces,relay", GRID_CASES,
+                         ids=lambda v: v.split("/")[-1][:-4] if isinstance(v, str) else ("relay" if v is True else "direct" if v is False else f"pieces{v}"))
+def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch, path, pieces, relay):
     """The two-communicator schedule (USP_PIPELINE_ULYSSES=1 beside a ring: BASELINE's 8-GPU grid ulysses 2 x ring 4,
     GQA, zigzag, forward + backward; and the 2 x 2 grids) with every exchange and every ring transfer going through real
     RCCL, stream-ordered only: head group i's ring attention starts behind ITS exchange, its output exchange runs
@@ -203,6 +207,8 @@ def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch,
     AL = patch_dist(monkeypatch, grid)
     monkeypatch.setattr(AL, "_FILL_ITEMS", 1)                # tiny fixture: let the head groups form
     monkeypatch.setenv("USP_ZZ_PIECES", str(pieces))
+    import yunchang_amd.comm.relay_exchange as RX
+    monkeypatch.setitem(RX._OVERRIDE, "relay", relay)
     dtype = getattr(torch, g.dtype)
     ws = g.ws
     loc = [[torch.from_numpy(np.ascontiguousarray(g.shard(x, r))).to(dtype).to(dev) for x in (g.q, g.k, g.v, g.dout)]
@@ -228,7 +234,8 @@ def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch,
         got = [[t.clone() for t in res[r]] for r in range(ws)]
         if first is None:
             first = got
-            assert {k for k, _ in grid.calls} == {"ulysses", "ring"}          # both communicators carried traffic
+            # both communicators carried traffic (relayed: the pair exchanges ride world-group send/recv instead)
+            assert {k for k, _ in grid.calls} == ({"world", "ring"} if relay else {"ulysses", "ring"})
             for r in range(ws):
                 for t, name in zip(got[r], names):
                     tol = TOL[g.dtype]["out"] if name == "out" else grad_tol(g.dtype, g.Hq // g.Hkv if name != "dq" else 1)
@@ -240,8 +247,10 @@ def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch,
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("n_gpus", [8, 4, 2], ids=["configs4_8gpu_u2r4_gqa_fwd_bwd", "configs3_4gpu_r4_fwd", "configs2_2gpu_u2_fwd"])
-def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatch, n_gpus):
+@pytest.mark.parametrize("n_gpus,relay", [(8, False), (4, False), (2, False), (8, True)],
+                         ids=["configs4_8gpu_u2r4_gqa_fwd_bwd", "configs3_4gpu_r4_fwd", "configs2_2gpu_u2_fwd",
+                              "configs4_8gpu_relayed_pair_exchange"])
+def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatch, n_gpus, relay):
     """BASELINE's multi-GPU configs AT THEIR OWN SIZE with the ranks as virtual ranks of one GPU -- configs[4]: 8 ranks,
     ulysses 2 x ring 4, zigzag, B1 S65536 H32/Hkv4 D128 bf16 causal, forward + backward; configs[3]: 4 ranks, ring 4
     zigzag, S32768 H16, forward; configs[2]: 2 ranks, ulysses 2, S16384 H16, forward -- through the layer's default
@@ -277,6 +286,8 @@ def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatc
     loc = [[ext(t, r).contiguous() for t in (q, k, v, do)] for r in range(ws)]
     grid = _VirtualGrid(ud, rd, nccl_single)
     AL = patch_dist(monkeypatch, grid)
+    import yunchang_amd.comm.relay_exchange as RX
+    monkeypatch.setitem(RX._OVERRIDE, "relay", relay)         # (8 ranks: every pair exchange striped over the 6 other ranks)
     streams = [torch.cuda.Stream(device=dev) for _ in range(ws)]
     torch.cuda.synchronize()
 
@@ -297,7 +308,8 @@ def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatc
     res = run_grid(grid, ws, rank_fn)
     torch.cuda.synchronize()
     assert {n for _, n in res} == {{8: 2, 4: 1, 2: 4}[n_gpus]}            # head groups per rank: the default pipeline
-    assert {kind for kind, _ in grid.calls} == {"ulysses", "ring"} - ({"ulysses"} if ud == 1 else set()) - ({"ring"} if rd == 1 else set())
+    kinds = {"ulysses", "ring"} - ({"ulysses"} if ud == 1 else set()) - ({"ring"} if rd == 1 else set())
+    assert {kind for kind, _ in grid.calls} == ((kinds - {"ulysses"}) | {"world"} if relay else kinds)
     glob = [torch.empty_like(t) for t in ((q, q, k, v) if bwd else (q,))]      # out [, dq, dk, dv]
     for r in range(ws):
         for g, shard in zip(glob, res[r][0]):

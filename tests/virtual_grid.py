@@ -55,6 +55,7 @@ class VirtualGrid:
         self.tls = threading.local()
         self.ulysses = [Group("ulysses", [r * ud + u for u in range(ud)]) for r in range(rd)]
         self.ring = [Group("ring", [r * ud + u for r in range(rd)]) for u in range(ud)]
+        self.world = Group("world", range(ud * rd))             # group=None in a P2POp: the relayed pair exchange
         self.calls = []                                         # (kind, first member) in issue order
         self.issue = threading.Lock()                           # torch's coalescing manager keeps per-group global state:
                                                                 # one real grouped call at a time
@@ -63,21 +64,23 @@ class VirtualGrid:
         return self.ulysses[rank // self.ud], self.ring[rank % self.ud]
 
     def abort(self):
-        for g in self.ulysses + self.ring:
+        for g in self.ulysses + self.ring + [self.world]:
             g.barrier.abort()
 
     # --- queries ---------------------------------------------------------------------------------------------
     def get_world_size(self, group=None):
+        group = self.world if group is None else group
         return len(group.members) if isinstance(group, Group) else self.d.get_world_size(group)
 
     def get_rank(self, group=None):
+        group = self.world if group is None else group
         return group.members.index(self.tls.rank) if isinstance(group, Group) else self.d.get_rank(group)
 
     def get_global_rank(self, group, r):
         return group.members[r] if isinstance(group, Group) else self.d.get_global_rank(group, r)
 
     def P2POp(self, op, tensor, peer, group=None):
-        return (op, tensor, peer, group)
+        return (op, tensor, peer, self.world if group is None else group)
 
     # --- the two kinds of traffic ----------------------------------------------------------------------------
     def _joint(self, group, payload, pairs_of):
@@ -119,7 +122,7 @@ class VirtualGrid:
 
     def batch_isend_irecv(self, ops):
         group = ops[0][3]
-        assert isinstance(group, Group) and group.kind == "ring" and all(o[3] is group for o in ops)
+        assert isinstance(group, Group) and group.kind in ("ring", "world") and all(o[3] is group for o in ops)
 
         def pairs_of(per_rank):
             pairs = []
@@ -151,13 +154,15 @@ class VirtualGrid:
 def patch_dist(monkeypatch, grid):
     """Point every module of the package that talks to torch.distributed at the virtual grid."""
     import yunchang_amd.comm.all_to_all as A
+    import yunchang_amd.comm.relay_exchange as RX
     import yunchang_amd.hybrid.async_attn_layer as AL
     import yunchang_amd.ring.ring_flash_attn as R
     import yunchang_amd.ring.stripe_flash_attn as S
     import yunchang_amd.ring.utils as U
     import yunchang_amd.ring.zigzag_ring_flash_attn as Z
-    for mod in (U, Z, R, S, AL, A):
+    for mod in (U, Z, R, S, AL, A, RX):
         monkeypatch.setattr(mod, "dist", grid)
+    monkeypatch.setattr(RX, "GRID", (grid.ud, grid.rd, grid.ud * grid.rd, True))
     return AL
 
 

@@ -106,21 +106,23 @@ def main():
     print("\nconfigs[4]  8 GPUs  ulysses 2 x ring 4, fwd+bwd  exchanges %.2f + %.2f + %.2f + %.2f ms, dK/dV hop %.2f ms, K/V fetch %.2f ms x 2"
           % (ex["fi"], ex["fo"], ex["bi"], ex["bo"], hop, kv))
 
-    def c5(ng, eff_f, eff_b, defer_tail, hop16):
+    def c5(ng, eff_f, eff_b, defer_tail, hop16, relay=1.0):
         """One iteration of a rank.  Exposed: the first input and the last output exchange of each pass (pipeline()), and
         the last dK/dV hop of a head group -- round 2: of EVERY group (the compute stream waited for it before the next
         group's kernels); round 3 (`defer_tail`): only of the last group (the hop is waited for on the exchange lane),
         at half the bytes when it travels rounded (`hop16`).  t_comm: every transfer once."""
-        tf, _ = pipeline(ex["fi"], fwd, ex["fo"], ng, eff_f)
-        tb, _ = pipeline(ex["bi"], bwd, ex["bo"], ng, eff_b)
+        e = {n: t * relay for n, t in ex.items()}     # relay: the pair exchange striped over k helpers takes 3 / (k + 2)
+        tf, _ = pipeline(e["fi"], fwd, e["fo"], ng, eff_f)
+        tb, _ = pipeline(e["bi"], bwd, e["bo"], ng, eff_b)
         last = (hop / ng) * (0.5 if hop16 else 1.0)
         tot = tf + tb + (1 if defer_tail else ng) * last
-        comm = sum(ex.values()) + 3 * hop + ng * last + 2 * kv
+        comm = sum(e.values()) + 3 * hop + ng * last + 2 * kv
         return tot, 1 - (tot - (fwd / eff_f + bwd / eff_b)) / comm
     for label, args in (("round 2: 1 head group (USP_PIPELINE_ULYSSES=0 / USP_SAFE_COMM=1)", (1, 1.0, 1.0, False, False)),
                         ("round 2: 2 head groups pipelined", (2, 0.95, 0.99, False, False)),
                         ("round 3: 2 groups, last hop pending on the lane + rounded (default)", (2, 0.97, 0.995, True, True)),
-                        ("round 3: 1 head group, last hop rounded (USP_SAFE_COMM=1)", (1, 1.0, 1.0, True, True))):
+                        ("round 3: 1 head group, last hop rounded (USP_SAFE_COMM=1)", (1, 1.0, 1.0, True, True)),
+                        ("round 3: default + pair exchanges striped over 6 helpers (USP_EXCHANGE_RELAY=1)", (2, 0.97, 0.995, True, True, 3 / 8))):
         tot, ov = c5(*args)
         print("   %-72s %.1f ms per iteration = %5.0f TFLOP/s on 8 GPUs; overlap = 1 - (t - t_compute)/t_comm = %.2f"
               % (label + ":", tot, 8 * 15.39 / tot * 1e3, ov))
