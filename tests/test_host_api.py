@@ -469,3 +469,27 @@ def test_backward_cut_workspace_and_policy(monkeypatch):
     assert _C.bwd_splits(1, 2048, 2048, 2, True) == (0, 0)          # short: nothing to balance
     assert _C.set_bwd_split(0) == "auto" and _C.bwd_splits(1, 16384, 16384, 2, True) == (0, 0)
     assert _C.set_bwd_split("auto") == 0
+
+
+def test_relay_plan_is_a_partition_and_an_involution():
+    """comm/relay_exchange.py as pure functions: on every grid it applies to, a rank's peer's peer is the rank itself, the
+    helpers are the rest of its sequence-parallel block, the stripes a sender cuts its chunk into cover every row exactly
+    once, and sender and receiver agree on where each stripe lies."""
+    from yunchang_amd.comm import relay_exchange as R
+    for ud, rd, ws, low in [(2, 2, 4, True), (2, 4, 8, True), (2, 4, 8, False), (2, 3, 6, True), (2, 2, 8, True), (2, 8, 16, False)]:
+        grid = (ud, rd, ws, low)
+        sp = ud * rd
+        for rank in range(ws):
+            peer, helpers = R.pair_and_helpers(rank, grid)
+            assert R.pair_and_helpers(peer, grid)[0] == rank and peer != rank
+            base = (rank // sp) * sp
+            assert sorted(helpers + [rank, peer]) == list(range(base, base + sp))
+            assert R.pair_and_helpers(peer, grid)[1] == helpers             # a pair shares its helpers
+            for rows in (8, 37, 1024, 8192):
+                d, r = R.stripe_rows(rows, len(helpers))
+                assert d + len(helpers) * r == rows and d >= r >= 0
+                off = R._offsets(rank, peer, helpers, d, r)
+                spans = sorted((off[w], off[w] + (d if w == peer else r)) for w in helpers + [peer])
+                assert spans[0][0] == 0 and spans[-1][1] == rows and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert R.pair_and_helpers(0, (4, 2, 8, True)) is None and R.pair_and_helpers(0, (2, 1, 2, True)) is None
+    assert R.pair_and_helpers(0, None) is None or R.GRID is not None
