@@ -500,7 +500,7 @@ def test_zigzag_fetch_ungrouped_switch_gives_the_same_result(monkeypatch):
 GRID = [f for f in golden_files() if Golden(f).ud > 1 and Golden(f).rd > 1 and Golden(f).layer == "hybrid"]
 
 
-@pytest.mark.parametrize("mode", ["pipelined", "safe", "relay"])
+@pytest.mark.parametrize("mode", ["pipelined", "safe", "relay", "pipelined-pairwise", "relay-pairwise"])
 @pytest.mark.parametrize("path", GRID, ids=lambda p: p.split("/")[-1][:-4])
 def test_virtual_grid_runs_the_layer_for_every_rank_in_one_process(monkeypatch, path, mode):
     """tests/virtual_grid.py on host tensors (the harness the RCCL ordering test uses on the GPU): all ranks of a
@@ -509,10 +509,13 @@ def test_virtual_grid_runs_the_layer_for_every_rank_in_one_process(monkeypatch, 
     form, against the reference's goldens -- and the same sequence of collectives on every member of a group."""
     from golden_util import grad_tol
     from oracle_backend import OracleBlockBackend
-    from virtual_grid import Ctx, VirtualGrid, patch_dist, run_grid
+    from virtual_grid import Ctx, VirtualGrid, VirtualGridPairwise, patch_dist, run_grid
     from yunchang_amd.kernels import set_block_backend
     g = Golden(path)
-    grid = VirtualGrid(g.ud, g.rd)
+    # "-pairwise": no group-wide host rendezvous -- messages matched per rank pair, random host delays: the ranks drift
+    pairwise = mode.endswith("-pairwise")
+    mode = mode.split("-")[0]
+    grid = VirtualGridPairwise(g.ud, g.rd, jitter=(7, 0.003)) if pairwise else VirtualGrid(g.ud, g.rd)
     AL = patch_dist(monkeypatch, grid)
     monkeypatch.setattr(AL, "_FILL_ITEMS", 1)
     monkeypatch.setitem(AL._COMM_OVERRIDE, "safe", mode == "safe")
@@ -537,6 +540,10 @@ def test_virtual_grid_runs_the_layer_for_every_rank_in_one_process(monkeypatch, 
     ng = {n for _, n in res}
     assert ng == ({1} if mode == "safe" else {min(AL._MAX_GROUPS, g.Hkv // g.ud)}), ng
     assert {k for k, _ in grid.calls} == ({"world", "ring"} if mode == "relay" and g.ud == 2 else {"ulysses", "ring"})
+    if pairwise:          # every member of a group posted the same number of calls of each kind
+        per_rank = {r: tuple(sum(1 for kk, rr in grid.calls if kk == k and rr == r) for k in ("ulysses", "world", "ring"))
+                    for r in range(g.ws)}
+        assert len(set(per_rank.values())) == 1, per_rank
     for r in range(g.ws):
         for t, name in zip(res[r][0], ("out", "dq", "dk", "dv")):
             tol = TOL[g.dtype]["out"] if name == "out" else grad_tol(g.dtype, g.Hq // g.Hkv if name != "dq" else 1)

@@ -186,14 +186,19 @@ GRID = [f for f in golden_files() if Golden(f).ud > 1 and Golden(f).rd > 1 and G
 # (fixture, row ranges per K/V half of the zigzag mesh fetch): the row-range waves exist at ring degree > 2 only
 # the third item: the pair exchange striped over the other ranks (comm/relay_exchange.py), a THIRD kind of traffic
 # (world-group send/recv) beside the two communicators' -- where it applies (ulysses 2, at least two helpers)
-GRID_CASES = [(f, w, False) for f in GRID for w in ((1, 2) if Golden(f).impl == "zigzag" and Golden(f).rd > 2 else (1,))] + \
-             [(f, 1, True) for f in GRID if Golden(f).ud == 2]
+# the fourth item: "barrier" = every collective is a host rendezvous of its whole group (one grouped RCCL call for all
+# members); "pairwise" = no rendezvous: every message is matched between its two ranks only and the ranks drift apart on
+# the host (random delays) the way real ranks do -- a schedule whose ranks post in different orders times out there
+GRID_CASES = [(f, w, False, "barrier") for f in GRID for w in ((1, 2) if Golden(f).impl == "zigzag" and Golden(f).rd > 2 else (1,))] + \
+             [(f, 1, True, "barrier") for f in GRID if Golden(f).ud == 2] + \
+             [(f, 2 if Golden(f).rd > 2 else 1, relay, "pairwise") for f in GRID for relay in (False, True) if Golden(f).ud == 2]
 
 
 @pytest.mark.timeout(1200)
-@pytest.mark.parametrize("path,pieces,relay", GRID_CASES,
-                         ids=lambda v: v.split("/")[-1][:-4] if isinstance(v, str) else ("relay" if v is True else "direct" if v is False else f"pieces{v}"))
-def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch, path, pieces, relay):
+@pytest.mark.parametrize("path,pieces,relay,harness", GRID_CASES,
+                         ids=lambda v: v.split("/")[-1][:-4] if isinstance(v, str) and "/" in v else
+                         (v if isinstance(v, str) else "relay" if v is True else "direct" if v is False else f"pieces{v}"))
+def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch, path, pieces, relay, harness):
     """The two-communicator schedule (USP_PIPELINE_ULYSSES=1 beside a ring: BASELINE's 8-GPU grid ulysses 2 x ring 4,
     GQA, zigzag, forward + backward; and the 2 x 2 grids) with every exchange and every ring transfer going through real
     RCCL, stream-ordered only: head group i's ring attention starts behind ITS exchange, its output exchange runs
@@ -203,7 +208,8 @@ def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch,
     from virtual_grid import patch_dist, run_grid
     dev = torch.device("cuda:0")
     g = Golden(path)
-    grid = _VirtualGrid(g.ud, g.rd, nccl_single)
+    from virtual_grid import VirtualGridPairwise
+    grid = _VirtualGrid(g.ud, g.rd, nccl_single) if harness == "barrier" else VirtualGridPairwise(g.ud, g.rd, nccl_single, jitter=(11, 0.002))
     AL = patch_dist(monkeypatch, grid)
     monkeypatch.setattr(AL, "_FILL_ITEMS", 1)                # tiny fixture: let the head groups form
     monkeypatch.setenv("USP_ZZ_PIECES", str(pieces))
@@ -247,10 +253,11 @@ def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch,
 
 
 @pytest.mark.timeout(1500)
-@pytest.mark.parametrize("n_gpus,relay", [(8, False), (4, False), (2, False), (8, True)],
+@pytest.mark.parametrize("n_gpus,relay,harness", [(8, False, "barrier"), (4, False, "barrier"), (2, False, "barrier"),
+                                                  (8, True, "barrier"), (8, False, "pairwise"), (4, False, "pairwise")],
                          ids=["configs4_8gpu_u2r4_gqa_fwd_bwd", "configs3_4gpu_r4_fwd", "configs2_2gpu_u2_fwd",
-                              "configs4_8gpu_relayed_pair_exchange"])
-def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatch, n_gpus, relay):
+                              "configs4_8gpu_relayed_pair_exchange", "configs4_8gpu_drifting_ranks", "configs3_4gpu_drifting_ranks"])
+def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatch, n_gpus, relay, harness):
     """BASELINE's multi-GPU configs AT THEIR OWN SIZE with the ranks as virtual ranks of one GPU -- configs[4]: 8 ranks,
     ulysses 2 x ring 4, zigzag, B1 S65536 H32/Hkv4 D128 bf16 causal, forward + backward; configs[3]: 4 ranks, ring 4
     zigzag, S32768 H16, forward; configs[2]: 2 ranks, ulysses 2, S16384 H16, forward -- through the layer's default
@@ -284,7 +291,9 @@ def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatc
     for r in range(ws):
         assert np.array_equal(ext(torch.from_numpy(small), r).numpy(), O.EXTRACT[impl](small, r, ws, rd, ud))
     loc = [[ext(t, r).contiguous() for t in (q, k, v, do)] for r in range(ws)]
-    grid = _VirtualGrid(ud, rd, nccl_single)
+    from virtual_grid import VirtualGridPairwise
+    # "pairwise": no host rendezvous of a group at its collectives, random host delays -- the ranks drift apart (virtual_grid.py)
+    grid = _VirtualGrid(ud, rd, nccl_single) if harness == "barrier" else VirtualGridPairwise(ud, rd, nccl_single, jitter=(5, 0.004))
     AL = patch_dist(monkeypatch, grid)
     import yunchang_amd.comm.relay_exchange as RX
     monkeypatch.setitem(RX._OVERRIDE, "relay", relay)         # (8 ranks: every pair exchange striped over the 6 other ranks)

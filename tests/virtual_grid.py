@@ -186,3 +186,100 @@ def run_grid(grid, ws, rank_fn):
         t.join(300)
     assert not errs, errs[0]
     return res
+
+
+class VirtualGridPairwise(VirtualGrid):
+    """The same grid WITHOUT a host rendezvous of the whole group at every collective: every message is matched between
+    its two ranks only (a mailbox per ordered rank pair), so the virtual ranks drift apart on the host the way real ranks
+    do -- a rank may be a whole ring step ahead of its neighbour -- and a schedule whose ranks post their transfers in
+    different orders deadlocks here (a timeout) instead of being straightened out by a group barrier.  The receiver issues
+    each transfer (one grouped RCCL self send/recv, behind the sender's and its own stream) and hands the completion event
+    back; a sender's wait() blocks on the host only until its receiver has issued.  `jitter` = (seed, max seconds): random
+    host delays in front of every posting, to shake the interleavings."""
+
+    def __init__(self, ud, rd, real_dist=None, jitter=None):
+        super().__init__(ud, rd, real_dist)
+        import collections
+        import queue
+        self.box = collections.defaultdict(queue.Queue)          # (src, dst) -> messages in posting order
+        self.jitter = jitter
+        self.aborted = threading.Event()
+
+    def abort(self):
+        self.aborted.set()
+        super().abort()
+
+    def _nap(self):
+        if self.jitter:
+            import random
+            import time
+            rnd = self.tls.__dict__.setdefault("rnd", random.Random(self.jitter[0] * 1000 + self.tls.rank))
+            time.sleep(rnd.random() * self.jitter[1])
+
+    def _post(self, tensor, dst):
+        ready = None
+        if self.d is not None:
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream())
+        msg = {"t": tensor, "ready": ready, "done": threading.Event(), "ev": None}
+        self.box[(self.tls.rank, dst)].put(msg)
+        return msg
+
+    def _take(self, tensor, src):
+        import queue
+        while True:                                              # the sender has not posted yet: wait (bounded)
+            try:
+                msg = self.box[(src, self.tls.rank)].get(timeout=1.0)
+                break
+            except queue.Empty:
+                if self.aborted.is_set():
+                    raise RuntimeError("virtual grid aborted")
+                self._waited = getattr(self, "_waited", 0) + 1
+                if self._waited > 300:
+                    raise TimeoutError(f"rank {self.tls.rank}: no message from rank {src} -- the ranks' posting orders differ")
+        assert msg["t"].shape == tensor.shape and msg["t"].dtype == tensor.dtype, (src, self.tls.rank, msg["t"].shape, tensor.shape)
+        if self.d is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(msg["ready"])
+            with self.issue:
+                reqs = self.d.batch_isend_irecv([self.d.P2POp(self.d.isend, msg["t"], 0), self.d.P2POp(self.d.irecv, tensor, 0)])
+            for req in reqs:
+                req.wait()
+            msg["ev"] = torch.cuda.Event()
+            msg["ev"].record(cur)
+        else:
+            tensor.copy_(msg["t"])
+        msg["done"].set()
+        return msg
+
+    class _PairReq:
+        def __init__(self, grid, sent, got):
+            self.grid, self.sent, self.got = grid, sent, got
+
+        def wait(self):
+            for msg in self.sent:                                # (host) until the receiver has issued the transfer ...
+                while not msg["done"].wait(timeout=1.0):
+                    if self.grid.aborted.is_set():
+                        raise RuntimeError("virtual grid aborted")
+            if self.grid.d is not None:                          # ... then stream-wise, like ProcessGroupNCCL's work.wait()
+                cur = torch.cuda.current_stream()
+                for msg in self.sent + self.got:
+                    cur.wait_event(msg["ev"])
+
+    def batch_isend_irecv(self, ops):
+        self._nap()
+        kind = ops[0][3].kind
+        self.calls.append((kind, self.tls.rank))
+        sent = [self._post(t, dst) for op, t, dst, _ in ops if op == "send"]      # every send first, then the receives
+        got = [self._take(t, src) for op, t, src, _ in ops if op == "recv"]
+        return [self._PairReq(self, sent, got)]
+
+    def all_to_all_single(self, recv, send, group=None):
+        assert isinstance(group, Group) and group.kind == "ulysses"
+        self._nap()
+        self.calls.append(("ulysses", self.tls.rank))
+        P, me = len(group.members), group.members.index(self.tls.rank)
+        recv.chunk(P)[me].copy_(send.chunk(P)[me])
+        sent = [self._post(send.chunk(P)[di], d) for di, d in enumerate(group.members) if di != me]
+        got = [self._take(recv.chunk(P)[si], s) for si, s in enumerate(group.members) if si != me]
+        self._PairReq(self, sent, got).wait()
