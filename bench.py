@@ -84,6 +84,13 @@ def local_row_ranges(cfg, rank, ws):
     return out
 
 
+def nanmax(a, b):
+    """max(a, b) that PROPAGATES NaN.  Python's max(0.0, nan) returns 0.0 (every comparison with NaN is False), which
+    would silently drop a NaN in a compared row from every parity figure this file prints; a NaN anywhere makes the
+    figure NaN, and the tests that read the figure fail on it."""
+    return float("nan") if (a != a or b != b) else max(a, b)
+
+
 def parity_check(cfg, rank, ws, out_local, q, k, v, n_rows=6):
     """The USP shard of this rank against (a) the third-party op behind the reference's AttnType.TORCH_EFFICIENT
     (aten::_scaled_dot_product_efficient_attention, yunchang/kernels/attention.py:76-86; equal heads only, so K/V
@@ -104,7 +111,7 @@ def parity_check(cfg, rank, ws, out_local, q, k, v, n_rows=6):
         worst_op, pos = 0.0, 0
         for a, b in ranges:
             got = out_local[:, pos:pos + (b - a)]
-            worst_op = max(worst_op, float((got.float() - ref[:, a:b].float()).abs().max()))
+            worst_op = nanmax(worst_op, float((got.float() - ref[:, a:b].float()).abs().max()))
             pos += b - a
         del ref, kk, vv
     except Exception as e:                                   # the op may be missing from a torch build
@@ -118,7 +125,7 @@ def parity_check(cfg, rank, ws, out_local, q, k, v, n_rows=6):
             p = torch.softmax(torch.einsum("bhd,bshd->bhs", qd, kd) * scale, dim=-1)
             ref_row = torch.einsum("bhs,bshd->bhd", p, vd)
             got = out_local[:, pos + row - a].double()
-            worst_rows = max(worst_rows, float((got - ref_row).abs().max()))
+            worst_rows = nanmax(worst_rows, float((got - ref_row).abs().max()))
         pos += b - a
     return worst_op, worst_rows
 
@@ -187,7 +194,7 @@ def sampled_parity(t, n_rows=8, n_keys=8, seed=0):
     rows = sorted(r for r in {0, 255, 256, S // 2 - 1, S // 2, S - 1, *rs.randint(0, S, size=n_rows).tolist()} if 0 <= r < S)
     keys = sorted(j for j in {0, 127, 128, S - 1, *rs.randint(0, S, size=n_keys).tolist()} if 0 <= j < S)
     err = dict(out=0.0, lse=0.0, dq=0.0, dk=0.0, dv=0.0)
-    up = lambda name, a, b: err.__setitem__(name, max(err[name], float((a.double() - b).abs().max())))
+    up = lambda name, a, b: err.__setitem__(name, nanmax(err[name], float((a.double() - b).abs().max())))
     for h in sorted({0, Hq - 1}):
         kd, vd = k[0, :, h // G].double(), v[0, :, h // G].double()
         for i in rows:

@@ -12,6 +12,7 @@ import sys
 import numpy as np
 import torch
 
+sys.dont_write_bytecode = True          # /root/reference is read-only: importing from it must not leave a __pycache__ there
 sys.path.insert(0, "/root/reference/test")
 from test_utils import attention_ref  # noqa: E402
 

@@ -20,13 +20,12 @@ TOL = {
 
 
 def grad_tol(dtype: str, heads_summed: int = 1):
-    """(atol, rtol) for a gradient.  TOL[...]["grad"] is the envelope of ONE attention head's gradient on
-    N(0,1) inputs.  dK / dV of a GQA group are sums over the group's G query heads; each head's contribution
-    carries its own independent 16-bit rounding noise (P, dS and dO are rounded per head before the MFMAs), so
-    the absolute error of the sum grows like sqrt(G) -- as does the magnitude of the gradient itself, which is
-    why rtol stays.  G = 1 returns the stated MHA tolerance unchanged."""
-    atol, rtol = TOL[dtype]["grad"]
-    return atol * float(np.sqrt(heads_summed)), rtol
+    """(atol, rtol) for a gradient: the stated tolerance, whatever the GQA group size.  (Rounds 1-3 widened atol by
+    sqrt(G) for dK / dV sums over G query heads; the measured errors never needed it -- at G = 8, S = 65536 the sampled
+    dK / dV errors are 2.1e-2 / 3.2e-2 against the un-widened 5e-2 -- so the gate is now what is measured.  The
+    argument stays so that call sites keep saying which sums they check.)"""
+    del heads_summed
+    return TOL[dtype]["grad"]
 
 
 def golden_files():
@@ -131,12 +130,32 @@ class VarlenGolden:
         return f(lq, lk, lv, self.cu_local, douts)
 
 
-def assert_close(got, want, atol, rtol, what=""):
+def close_mask(got, want, atol, rtol):
+    """Element-wise verdict of the parity check, written so that it CAN FAIL on NaN: an element passes only if
+    `|got - want| <= atol + rtol*|want|` evaluates to True (False for NaN on either side), or if both sides are the SAME
+    infinity (an LSE of -inf for a row without visible keys: `-inf - -inf` is NaN, but the values agree exactly).
+    A NaN in `want` never passes -- the fixtures and the oracle hold none."""
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
-    err = np.abs(got - want)
-    lim = atol + rtol * np.abs(want)
-    bad = err > lim
-    assert not bad.any(), (f"{what}: {bad.sum()} / {bad.size} elements out of tolerance "
-                           f"(atol={atol}, rtol={rtol}); max abs err {err.max():.3e} "
-                           f"at {np.unravel_index(err.argmax(), err.shape)}")
+    assert got.shape == want.shape, f"shape mismatch: got {got.shape}, want {want.shape}"
+    same_inf = np.isinf(want) & (got == want)
+    with np.errstate(invalid="ignore"):          # inf - inf: handled by same_inf, everything else must compare True
+        err = np.abs(got - want)
+        # an infinite `want` passes only for the identical infinity (rtol * inf = inf would otherwise admit anything)
+        ok = np.where(np.isinf(want), same_inf, err <= atol + rtol * np.abs(want))
+    return ok, np.where(same_inf, 0.0, err)
+
+
+def assert_close(got, want, atol, rtol, what=""):
+    """The one comparator of the parity tests (same semantics as the reference's only assertion,
+    torch.testing.assert_close, test/test_hybrid_attn.py:386: NaN never equals anything)."""
+    ok, err = close_mask(got, want, atol, rtol)
+    if ok.all():
+        return
+    got = np.asarray(got, dtype=np.float64)
+    n_nan = int(np.isnan(got).sum())
+    finite = np.where(np.isnan(err), -1.0, err)
+    raise AssertionError(f"{what}: {int((~ok).sum())} / {ok.size} elements out of tolerance (atol={atol}, rtol={rtol}); "
+                         f"{n_nan} NaN in the result; max finite abs err {finite.max():.3e} "
+                         f"at {np.unravel_index(finite.argmax(), finite.shape)}; first bad element at "
+                         f"{np.unravel_index(int(np.argmax(~ok)), ok.shape)}")

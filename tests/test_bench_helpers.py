@@ -224,3 +224,31 @@ def test_sampled_parity_reference_equals_autograd():
     t["dk"] = t["dk"].clone()
     t["dk"][0, 0, 0, 3] += 0.25                      # key 0 of kv head 0 is always sampled
     assert abs(b.sampled_parity(t)["max_abs_err"]["dk"] - 0.25) < 1e-6
+
+
+def test_sampled_parity_and_parity_check_propagate_nan():
+    """A NaN in a compared row must reach the printed figure (Python's max(0.0, nan) is 0.0: bench.nanmax), so that
+    every `err < tol` gate on the figure fails."""
+    b = _bench()
+    assert b.nanmax(0.0, float("nan")) != b.nanmax(0.0, float("nan"))          # NaN
+    assert b.nanmax(float("nan"), 1.0) != b.nanmax(float("nan"), 1.0)
+    assert b.nanmax(0.5, 0.25) == 0.5
+    torch.manual_seed(0)
+    B, S, Hq, Hkv, D = 1, 300, 2, 1, 32
+    q, k, v, do = (torch.randn(B, S, h, D, dtype=torch.float64) for h in (Hq, Hkv, Hkv, Hq))
+    z = lambda t: torch.zeros_like(t)
+    base = dict(q=q, k=k, v=v, do=do, out=z(q), lse=torch.zeros(B, Hq, S, dtype=torch.float64), dq=z(q), dk=z(k), dv=z(v))
+    for name, idx in (("out", (0, S - 1, 0, 0)), ("dq", (0, 0, Hq - 1, 5)), ("dk", (0, S - 1, 0, 1)), ("dv", (0, 0, 0, 0)),
+                      ("lse", (0, 0, S - 1))):
+        t = dict(base)
+        t[name] = base[name].clone()
+        t[name][idx] = float("nan")
+        e = b.sampled_parity(t)["max_abs_err"][name]
+        assert e != e and not (e < 1e9), (name, e)
+    # parity_check (the per-rank check of the layer benchmark): a NaN row of the local output
+    cfg = dict(S=64, ud=1, rd=1, impl="basic")
+    q16, k16, v16 = (torch.randn(1, 64, 2, 16) for _ in range(3))
+    out = torch.zeros(1, 64, 2, 16)
+    out[0, 63] = float("nan")                                                  # the last row of a range is always sampled
+    _, worst_rows = b.parity_check(cfg, 0, 1, out, q16, k16, v16)
+    assert worst_rows != worst_rows

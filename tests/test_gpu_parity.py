@@ -953,19 +953,25 @@ def test_c5_rank_block_shapes_against_sampled_fp64(dev, Hq, Hkv):
             assert_close(_f(dv[0, j, hk]), rdv.cpu().numpy(), atol, rtol, f"dv key {j} kv head {hk}")
 
 
-def test_seq64k_sampled_parity_through_bench(dev):
-    """The metric's own size on one GPU (B1 S65536 H32/Hkv4 D128 causal, forward + backward kernels) against exact fp64
-    attention on sampled rows and key columns -- the check bench.py attaches to `roofline.seq64k_single_gpu`."""
+def _load_bench():
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
+    return b
+
+
+def test_seq64k_sampled_parity_through_bench(dev):
+    """The metric's own size on one GPU (B1 S65536 H32/Hkv4 D128 causal, forward + backward kernels) against exact fp64
+    attention on sampled rows and key columns -- the check bench.py attaches to `roofline.seq64k_single_gpu`."""
+    b = _load_bench()
     c5 = b.WORKLOADS[8]
     t = b._fwd_bwd_kernels(c5["B"], c5["S"], c5["Hq"], c5["Hkv"], c5["D"], dev, 1, keep=True)
     err = b.sampled_parity(t["tensors"])["max_abs_err"]
+    # every gate is `err < tol`: False for NaN (bench.nanmax propagates a NaN of any sampled row into the figure)
     assert err["out"] < 2e-2 and err["lse"] < 2e-3, err
-    assert err["dq"] < 5e-2 and err["dk"] < 5e-2 * 8 ** 0.5 and err["dv"] < 5e-2 * 8 ** 0.5, err       # grad_tol: G = 8
+    assert err["dq"] < 5e-2 and err["dk"] < 5e-2 and err["dv"] < 5e-2, err          # the stated bf16 gradient bound, G = 8
 
 
 @pytest.mark.parametrize("B,Sq,Sk,Hq,Hkv,D,causal,dt", [(1, 1024, 1024, 2, 2, 128, True, "bfloat16"),

@@ -112,3 +112,30 @@ def test_oracle_window_mask_equals_the_reference():
         q, k, v = (rs.standard_normal((1, S, H, D)).astype(np.float32) for S, H in ((Sq, Hq), (Sk, Hkv), (Sk, Hkv)))
         out, _ = O.attention_ref(q, k, v, causal=bool(causal), window=(wl, wr))
         assert_close(out, z[f"out{i}"], 2e-5, 2e-5, f"window case {i}: {(Sq, Sk, causal, wl, wr)}")
+
+
+def test_the_comparator_can_fail():
+    """golden_util.assert_close is the one comparator of every parity test: NaN on the result side fails, an
+    unwritten (NaN-prefilled) row fails, the SAME infinity on both sides passes (an LSE of -inf), opposite
+    infinities and inf-vs-finite fail, and no RuntimeWarning escapes (`-inf - -inf`)."""
+    import warnings
+    from golden_util import close_mask
+    want = np.array([[1.0, -np.inf, 2.0], [0.0, 0.5, -3.0]])
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert_close(want.copy(), want, 1e-6, 0.0, "identical")
+        for i, bad in (((0, 0), np.nan), ((0, 1), np.inf), ((0, 1), 0.0), ((0, 1), np.nan), ((1, 2), -3.1), ((1, 0), np.inf)):
+            got = want.copy()
+            got[i] = bad
+            ok, _ = close_mask(got, want, 1e-3, 1e-3)
+            assert not ok[i] and ok.sum() == ok.size - 1
+            with pytest.raises(AssertionError):
+                assert_close(got, want, 1e-3, 1e-3, "mutated")
+        row = want.copy()
+        row[1] = np.nan                                           # a row the kernel never wrote
+        with pytest.raises(AssertionError, match="3 NaN"):
+            assert_close(row, want, 1e-3, 1e-3, "unwritten row")
+        with pytest.raises(AssertionError):
+            assert_close(np.full_like(want, np.nan), want, 1e-3, 1e-3, "all NaN")
+        with pytest.raises(AssertionError):
+            assert_close(want[:1], want, 1e-3, 1e-3, "shape")
