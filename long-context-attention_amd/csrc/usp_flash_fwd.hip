@@ -19,52 +19,10 @@
 #include <stdlib.h>
 
 #include "usp_common.hpp"
+#include "usp_fwd_params.hpp"
 #include "usp_hip.h"
 
 namespace usp {
-
-struct FwdParams {
-  const char* q; const char* k; const char* v;
-  char* out; float* acc; float* lse;
-  int64_t q_sb, q_ss, q_sh;
-  int64_t k_sb, k_ss, k_sh;
-  int64_t v_sb, v_ss, v_sh;
-  int64_t o_sb, o_ss, o_sh;
-  int64_t a_sb, a_ss, a_sh;
-  int64_t lse_sb, lse_sh;
-  int B, Sq, Sk, Hq, Hkv, G, nq, n_items;
-  int causal_off;                 // Sk - Sq
-  float scale, scale_log2;
-  int merge_in, final_begin, final_end;
-  int out_wide;                   // out rows are 16-byte aligned: 16-byte epilogue stores
-  const int* seq_q; const int* seq_k;   // packed variable-length batch: B (first row, rows) pairs, or NULL
-  int* sched;                           // packed mode: control block of the dynamic item queue, or NULL
-  int interleave;                       // USP_LAUNCH_INTERLEAVE: one workgroup per item (collectives can slip in)
-};
-
-// K split (dense mode): every (batch, head, query tile) is cut into `ksplit` items along K; partial results go to
-// [ksplit][B,Sq,Hq,D] fp32 and [ksplit][B,Hq,Sq] fp32.  Kernel arguments of the split instantiation ONLY: the plain
-// kernels keep the argument block (and with it the machine code) they were profiled with.
-struct FwdSplit {
-  int ksplit;
-  float* ws_o; float* ws_lse;
-  // Sliding window, left bound (ABI v5): query row i sees key j only if j >= i + win_lo (win_lo = Sk - Sq - window_left).
-  // Lives in the split instantiation: tiles left of a query tile's window are skipped by the same rebasing the K split
-  // uses, and every tile of a windowed launch takes the generic (masked) loop.  The RIGHT bound needs nothing new: it
-  // is the causal limit with a shifted offset (host: causal_off = Sk - Sq + window_right, causal instantiation).
-  int win_on, win_lo;
-};
-template <bool KS> struct FwdArgsT : FwdParams {};
-template <> struct FwdArgsT<true> : FwdParams, FwdSplit {};
-
-constexpr int kBN = 64;    // keys per KV tile
-
-template <int D> struct KSwz {
-  // 16-byte slots per K row and rows per 256-byte LDS bank row
-  static constexpr int SPR = D / 8;
-  static constexpr int RPB = 16 / SPR < 1 ? 1 : 16 / SPR;
-  static USP_DEV int of(int row) { return (row / RPB) & (SPR - 1); }
-};
 
 // NWAVES waves per workgroup, 32 query rows each: 8 (one 256-row workgroup per CU) or 4 (two 128-row
 // workgroups per CU: half the causal diagonal waste, and the two workgroups desynchronise).
@@ -762,10 +720,12 @@ static int launch_fwd(const FwdArgsT<true>& p, bool causal, hipStream_t st) {
   // Workgroup shape: 8 waves (256 query rows, one workgroup per CU) stage K/V once per 256 rows and win by
   // 3-4 % whenever they can give every CU work; 4 waves (128 rows, two workgroups per CU) are used only
   // when the 8-wave item list is shorter than the CU count, or for short causal sequences (<= 1024 rows:
-  // +3...8 %) (measured with persistent workgroups, profiles/).  USP_FWD_WAVES=4|8 forces a shape.
+  // +3...8 %) (measured with persistent workgroups, profiles/).  USP_FWD_WAVES=4|8|64 forces a shape (64 = the
+  // 4 x 64-row kernel of usp_flash_fwd64.hip, where it applies).
   static const int forced = [] { const char* e = getenv("USP_FWD_WAVES"); return e ? atoi(e) : 0; }();
   int waves = forced;
-  if (waves != 4 && waves != 8) {
+  const bool fwd64_ok = D == 128 && !p.seq_q && p.ksplit <= 1 && !p.win_on;   // what usp_flash_fwd64.hip serves
+  if (waves != 4 && waves != 8 && waves != 64) {
     const int64_t grid8 = (int64_t)p.B * p.Hq * ((p.Sq + 255) / 256) * p.ksplit;
     // short causal sequences: less diagonal waste (dense only: in packed mode twice the items cost more to fetch)
     // beside a transfer (interleave) RCCL's resident workgroups take a few CUs: with ONE 256-row item per CU a lost
@@ -773,6 +733,13 @@ static int launch_fwd(const FwdArgsT<true>& p, bool causal, hipStream_t st) {
     // 256 items 0.695 vs 0.718 ms).  From two items per CU on the 256-row shape wins again, alone (+4...8 %) and
     // beside the copies (512 items: 2.054 vs 2.084 ms) -- profiles/r02_rank_emulation.txt
     waves = (grid8 < 256 || (p.interleave && grid8 < 512) || (!p.seq_q && causal && p.Sq <= 1024)) ? 4 : 8;
+    // where the 256-row item wins, the one-wave-per-SIMD kernel (4 waves x 64 rows, usp_flash_fwd64.hip) serves it
+    if (waves == 8 && fwd64_ok) waves = 64;
+  }
+  if (waves == 64) {
+    int rc = USP_ELAUNCH;
+    if (fwd64_ok && launch_fwd64(p, DT, causal, st, &rc)) return rc;
+    waves = 8;
   }
   return waves == 4 ? launch_fwd_w<D, DT, 4>(p, causal, st) : launch_fwd_w<D, DT, 8>(p, causal, st);
 }

@@ -1,0 +1,615 @@
+// Blockwise flash-attention forward for gfx950, ONE WAVE PER SIMD: a workgroup is 4 waves x 64 query rows (256 rows of
+// one (batch, head), KV tile = 64 keys), every wave owns its SIMD's whole 512-entry register file.
+// Same C ABI entry (usp_flash_fwd, include/usp_hip.h), same LDS images, same numerics, same epilogue (fused ring LSE
+// merge) as the 8-wave kernel of usp_flash_fwd.hip, which stays the kernel of the packed / K-split / windowed / small
+// launches.  Replaces the reference's `fwd-only` block kernel (yunchang/kernels/attention.py:44-136) and
+// update_out_and_lse (yunchang/ring/utils.py:10-51).
+//
+// Why this shape (profiles/r03_bwd_ablations.txt, tools/issue_bench.hip): with two 32-row waves per SIMD every MFMA
+// drags 1.5 LDS fragment reads and 4 VALU through the SIMD's issue port; the 8-wave kernel sits at 58 % MFMA-pipe
+// occupancy, which is 80-90 % of what that instruction mix allows.  A wave that owns 64 rows uses every K and V fragment
+// for TWO MFMAs (0.75 LDS reads per MFMA), and with the accumulators in the accumulator half of the register file
+// the arithmetic VGPRs are free for two full score tiles:
+//   a[0:127]   O^T accumulators, 2 query blocks x 4 dim tiles        (asm MFMAs, "+a": hipcc would give them VGPR homes)
+//   a[128:191] Q fragments, B operand of S^T = K Q^T (MFMA A/B operands may be AGPRs: no copy, ever)
+//   v[...]     S^T of the tile being exponentiated + S^T of the next tile (2 x 64), packed P (32), K / V fragments in
+//              flight, softmax state
+// The MFMAs are inline asm (hipcc selects ONE accumulator file per function for its builtin MFMAs: with the builtins the
+// score chain would land in AGPRs and every score would pay a v_accvgpr_read).  hipcc pads nothing around an asm MFMA,
+// so the hazards are met by construction: a chain's result is read at least 16 MFMA slots after its last MFMA in the
+// pipelined loop, and behind an explicit s_nop in the unpipelined paths; operands written by VALU (packed P) are
+// complete at least one MFMA slot before the MFMA that reads them.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "usp_common.hpp"
+#include "usp_fwd_params.hpp"
+#include "usp_hip.h"
+
+namespace usp {
+
+// ---- asm MFMA forms ---------------------------------------------------------------------------------------------------
+template <int DT> struct M64;
+#if defined(__HIP_DEVICE_COMPILE__)   // "a" means eax to the host pass, which then drops the kernel stubs
+#define USP_M64_BODY(MN)                                                                                              \
+  /* first MFMA of a score chain: C = 0; D in arch VGPRs; A = K fragment (VGPR), B = Q fragment (AGPR) */            \
+  static USP_DEV void s_first(f32x16& s, const u32x4& a, const u32x4& q) {                                            \
+    asm volatile(MN " %0, %1, %2, 0" : "=&v"(s) : "v"(a), "a"(q));                                                    \
+  }                                                                                                                   \
+  static USP_DEV void s_next(f32x16& s, const u32x4& a, const u32x4& q) {                                             \
+    asm volatile(MN " %0, %1, %2, %0" : "+v"(s) : "v"(a), "a"(q));                                                    \
+  }                                                                                                                   \
+  /* O^T accumulate: C/D in AGPRs; A = V^T fragment, B = packed P (VGPRs) */                                           \
+  static USP_DEV void o_acc(f32x16& o, const u32x4& a, const u32x4& b) {                                              \
+    asm volatile(MN " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                                    \
+  }
+#else
+#define USP_M64_BODY(MN)                                                                                              \
+  static USP_DEV void s_first(f32x16&, const u32x4&, const u32x4&) {}                                                 \
+  static USP_DEV void s_next(f32x16&, const u32x4&, const u32x4&) {}                                                  \
+  static USP_DEV void o_acc(f32x16&, const u32x4&, const u32x4&) {}
+#endif
+template <> struct M64<0> { USP_M64_BODY("v_mfma_f32_32x32x16_bf16") };
+template <> struct M64<1> { USP_M64_BODY("v_mfma_f32_32x32x16_f16") };
+
+USP_DEV void pin_agpr4(u32x4& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+a"(x));
+#endif
+}
+// `n` wait states that hipcc cannot move the readers of the accumulators across (it does not know that the asm
+// statements in front of it are MFMAs: "XDL write -> VALU / v_accvgpr read" needs 12 states for an 8-pass MFMA).
+USP_DEV void mfma_settle(f32x16 (&o)[2][4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]),
+                            "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));
+#endif
+}
+USP_DEV void mfma_settle(f32x16 (&s)[2][2]) {
+  asm volatile("s_nop 15" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]));
+}
+// VALU write (v_cvt_pk / v_accvgpr_write) -> MFMA operand read: 2 wait states, which hipcc does not pad in front of asm
+USP_DEV void operand_settle() { asm volatile("s_nop 3" ::: "memory"); }
+
+#ifndef USP_F64_NEA      // exp elements (of 64 per lane and tile) issued in phase A; the rest opens phase B, one per slot
+#define USP_F64_NEA 42
+#endif
+#ifndef USP_F64_LEAD     // ... of which in front of the first MFMA of phase A (it waits for the first K fragments anyway)
+#define USP_F64_LEAD 2
+#endif
+#ifndef USP_F64_PFK      // K fragments read this many fragments (= 2 MFMA slots each) ahead of their first MFMA
+#define USP_F64_PFK 2
+#endif
+#ifndef USP_F64_PFV      // likewise the V fragments
+#define USP_F64_PFV 2
+#endif
+#ifndef USP_F64_MAX0     // first slot of phase B that carries row-max work of the next tile
+#define USP_F64_MAX0 22
+#endif
+
+template <int DT, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<false> /* read through the kernarg segment */) {
+  using E = Elem<DT>;
+  using M = M64<DT>;
+  constexpr int D = 128;
+  constexpr int kBM = 256;                    // query rows per workgroup
+  constexpr int ROWB = D * 2;                 // bytes per K row
+  constexpr int KBYTES = kBN * ROWB;          // one K (or V) tile
+  constexpr int NKT = D / 16;                 // k-steps of K Q^T
+  constexpr int NDJ = D / 32;                 // 32-wide dim tiles of O^T
+  constexpr int VOFF = 2 * KBYTES;            // LDS: Kbuf[0], Kbuf[1], Vbuf[0], Vbuf[1]
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  USP_LDS char* smem = (USP_LDS char*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  // The argument block (~70 dwords) is NOT kept in SGPRs: every use reads it from the kernarg segment through a pointer
+  // the compiler cannot see through (re-laundered per item and in front of the epilogue), so that a field lives in a
+  // register only around its uses.  Held in SGPRs for the whole persistent loop the block alone fills the scalar file,
+  // and the pipelined loop then reloads its loop invariants from spill lanes (v_readlane + 5 wait states in front of
+  // every LDS-DMA that takes one as its scalar offset).
+  typedef const __attribute__((address_space(4))) FwdParams* KArgs;
+  KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+
+  // ---- lane-constant addresses --------------------------------------------------------------------------------------
+  // LDS-DMA pieces (1 KiB per wave-instruction; layouts as in usp_flash_fwd.hip): piece i of this wave is chunk
+  // wave + 4i of the tile = K rows 4*wave + 16i .. +3 (slot swizzle on the source side) / V keys 4*wave + 16i .. +3, so
+  // the per-lane offset is the same for all four pieces and the piece is selected by a scalar offset.
+  const int k_voff = (4 * wave + (lane >> 4)) * (int)p->k_ss * 2 + (((lane & 15) ^ ((4 * wave + (lane >> 4)) & 15)) * 16);
+  const int v_voff = (4 * wave + ((lane & 15) >> 2)) * (int)p->v_ss * 2 + (32 * (lane >> 4) + 8 * (lane & 3)) * 2;
+  const int k_rd = l31 * ROWB;                                  // row read (A operand of K Q^T): tile row 32*kb + l31
+  const int k_rd_x = hi ^ (l31 & 15);                           // (2t + hi) ^ swz == (2t) ^ (hi ^ swz)
+  const int v_rd = VOFF + hi * NDJ * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  const float c = p->scale_log2;
+
+  // ---- persistent workgroups: each walks a static list of (batch, head, 256-row query tile) items (ItemWalk) ------
+  const ItemWalk walk(p->n_items);
+  for (int pass = 0;; ++pass) {
+  int w = walk.at(pass);
+  if (w < 0) break;
+  asm volatile("" : "+s"(p));
+  w = walk.dealt(w, p->nq);
+  const int qt_r = w % p->nq;
+  int rest = w / p->nq;
+  const int qt = CAUSAL ? (p->nq - 1 - qt_r) : qt_r;      // heavy (late) tiles first
+  const int g = rest % p->G;
+  rest /= p->G;
+  const int hkv = rest % p->Hkv;
+  const int b = rest / p->Hkv;
+  const int h = hkv * p->G + g;
+
+  const int q0 = qt * kBM;
+  const int qw = q0 + wave * 64;                          // first row of this wave
+  const int off = p->causal_off;
+
+  // ---- KV range -------------------------------------------------------------------------------------------------------
+  int blk_kv_end = p->Sk, wave_kv_end = p->Sk;
+  if (CAUSAL) {
+    const int blk_last = (q0 + kBM < p->Sq ? q0 + kBM : p->Sq) - 1;
+    const int wav_last = (qw + 64 < p->Sq ? qw + 64 : p->Sq) - 1;
+    blk_kv_end = blk_last + off + 1 < p->Sk ? blk_last + off + 1 : p->Sk;
+    wave_kv_end = wav_last + off + 1 < p->Sk ? wav_last + off + 1 : p->Sk;
+  }
+  if (qw >= p->Sq) wave_kv_end = 0;
+  const int nt = blk_kv_end > 0 ? (blk_kv_end + kBN - 1) / kBN : 0;
+  int n_full = p->Sk / kBN;                                 // leading tiles that need no mask for this wave
+  if (CAUSAL) {
+    const int lim = qw + off + 1;                          // keys < lim are visible to EVERY row of the wave
+    const int nf = lim > 0 ? lim / kBN : 0;
+    n_full = nf < n_full ? nf : n_full;
+  }
+  if (qw + 64 > p->Sq) n_full = 0;                          // ragged / inactive waves take the generic loop
+  if (n_full > nt) n_full = nt;
+
+  // ---- Q fragments (B operand: lane holds Q[row][16t + 8hi .. +7]), parked in the accumulator file -----------------
+  u32x4 qf[2][NKT];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int row = qw + 32 * qb + l31;
+    const int row_c = row < p->Sq ? row : p->Sq - 1;
+    const char* qp = p->q + 2 * (b * p->q_sb + (int64_t)row_c * p->q_ss + h * p->q_sh) + 16 * hi;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) qf[qb][t] = *(const u32x4*)(qp + 32 * t);
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) pin_agpr4(qf[qb][t]);
+
+  // ---- staging: LDS-DMA with running cursors.  K tiles are issued in the order 0, 1, 2, ... and V tiles 0, 1, ..., each
+  // exactly once per loop iteration (also past the last tile the item needs: rows >= Sk read as 0 through num_records,
+  // a surplus tile inside the tensor is fetched and ignored), so the descriptor of the next tile is the previous one
+  // advanced by two scalar additions -- no per-tile 64-bit multiplies, no clamps (the head of an iteration is otherwise
+  // ~100 scalar instructions that nothing hides at one wave per SIMD).  The host guarantees that one head's K / V rows
+  // span less than 2^31 bytes (launch_fwd64), so the remaining-bytes counter is a 32-bit scalar.
+  const int k_tb = kBN * (int)p->k_ss * 2, v_tb = kBN * (int)p->v_ss * 2;          // bytes per tile step
+  const char* k_cur = p->k + 2 * (b * p->k_sb + hkv * p->k_sh);
+  const char* v_cur = p->v + 2 * (b * p->v_sb + hkv * p->v_sh);
+  int k_rem = ((p->Sk - 1) * (int)p->k_ss + D) * 2, v_rem = ((p->Sk - 1) * (int)p->v_ss + D) * 2;
+  // (lds_w / k_step / v_step pass through an opaque asm at every use: hipcc otherwise hoists the sixteen M0 values and the
+  // six scalar offsets of the pieces out of the loops as invariants and then SPILLS them -- a v_readlane plus five wait
+  // states in front of every LDS-DMA; computed at the use each is one s_add / s_lshl / s_mul)
+  int lds_w = wave * 1024, k_step = 16 * (int)p->k_ss * 2, v_step = 16 * (int)p->v_ss * 2;
+  auto dma_k = [&](int buf) {                               // next K tile -> Kbuf[buf]
+    asm volatile("" : "+s"(lds_w), "+s"(k_step));
+    const auto rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)k_cur, 0, k_rem > 0 ? k_rem : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_dma16(rs_, smem + lds_w + (buf * KBYTES + i * 4096), k_voff, i * k_step);
+    k_cur += k_tb; k_rem -= k_tb;
+  };
+  auto dma_v = [&](int buf) {                               // next V tile -> Vbuf[buf]
+    asm volatile("" : "+s"(lds_w), "+s"(v_step));
+    const auto rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)v_cur, 0, v_rem > 0 ? v_rem : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) lds_dma16(rs_, smem + lds_w + (VOFF + buf * KBYTES + i * 4096), v_voff, i * v_step);
+    v_cur += v_tb; v_rem -= v_tb;
+  };
+
+  // ---- accumulators / softmax state (index = query block) -----------------------------------------------------------
+  f32x16 o[2][NDJ];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int dj = 0; dj < NDJ; ++dj) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qb][dj][r] = 0.f;
+      pin_agpr(o[qb][dj]);
+    }
+  float m_run[2] = {USP_NEG_INF, USP_NEG_INF};   // running row max, raw score units
+  float l_run[2] = {0.f, 0.f};                   // this lane's share of the row sum
+
+  // ---- unpipelined building blocks (prologue, masked / ragged tiles) -------------------------------------------------
+  // S^T = K Q^T for the K tile in Kbuf[kbuf]
+  auto qk = [&](int kbuf, f32x16 (&s)[2][2]) {
+    USP_LDS const char* kb = smem + kbuf * KBYTES + k_rd;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int slot = ((2 * kt) ^ k_rd_x) * 16;
+      const u32x4 k0 = *(USP_LDS const u32x4*)(kb + slot);
+      const u32x4 k1 = *(USP_LDS const u32x4*)(kb + 32 * ROWB + slot);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        if (kt == 0) { M::s_first(s[qb][0], k0, qf[qb][0]); M::s_first(s[qb][1], k1, qf[qb][0]); }
+        else { M::s_next(s[qb][0], k0, qf[qb][kt]); M::s_next(s[qb][1], k1, qf[qb][kt]); }
+      }
+    }
+    mfma_settle(s);
+  };
+  auto mask = [&](int kt0, f32x16 (&s)[2][2]) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int row = qw + 32 * qb + l31;
+      int klim = p->Sk - 1;
+      if (CAUSAL) klim = row + off < klim ? row + off : klim;
+      const int kb0 = kt0 + 4 * hi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kb0 + (r & 3) + 8 * (r >> 2);
+        if (key > klim) s[qb][0][r] = USP_NEG_INF;
+        if (key + 32 > klim) s[qb][1][r] = USP_NEG_INF;
+      }
+    }
+  };
+  // online softmax of one 64-key tile; rescales o (only if some row's max moved), returns P packed for the PV MFMAs
+  auto softmax = [&](f32x16 (&s)[2][2], u32x4 (&pf)[2][4]) {
+    float alpha[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      float mt = s[qb][0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[qb][0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[qb][1][r]);
+      mt = xhalf_max(mt);
+      const float m_new = fmaxf(m_run[qb], mt);
+      const float m_use = (m_new == USP_NEG_INF) ? 0.f : m_new;
+      const float mc = m_use * c;
+      alpha[qb] = (m_new == m_run[qb]) ? 1.f : fast_exp2(m_run[qb] * c - mc);
+      m_run[qb] = m_new;
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[qb][0][r] = fast_exp2(__builtin_fmaf(s[qb][0][r], c, -mc));
+        s[qb][1][r] = fast_exp2(__builtin_fmaf(s[qb][1][r], c, -mc));
+        rs += s[qb][0][r] + s[qb][1][r];
+      }
+      l_run[qb] = l_run[qb] * alpha[qb] + rs;
+      // P (B operand of V^T P^T): k-step ks = 2*kb + (r>>3), element e = r & 7
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pf[qb][0][j] = E::pack2(s[qb][0][2 * j], s[qb][0][2 * j + 1]);
+        pf[qb][1][j] = E::pack2(s[qb][0][8 + 2 * j], s[qb][0][8 + 2 * j + 1]);
+        pf[qb][2][j] = E::pack2(s[qb][1][2 * j], s[qb][1][2 * j + 1]);
+        pf[qb][3][j] = E::pack2(s[qb][1][8 + 2 * j], s[qb][1][8 + 2 * j + 1]);
+      }
+    }
+    if (!__all(alpha[0] == 1.f && alpha[1] == 1.f)) {        // the accumulators live in AGPRs: 3 VALU per element
+      mfma_settle(o);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qb][dj][r] *= alpha[qb];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int dj = 0; dj < NDJ; ++dj) pin_agpr(o[qb][dj]);
+    }
+  };
+  // O^T += V^T P^T for the V tile in Vbuf[vbuf]
+  auto pv = [&](int vbuf, const u32x4 (&pf)[2][4]) {
+    USP_LDS const char* vb = smem + vbuf * KBYTES + v_rd;
+    operand_settle();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+      for (int dj = 0; dj < NDJ; ++dj) {
+        USP_LDS const char* vp = vb + (4 * ks * NDJ + dj) * 256;
+        const u32x2 v0 = lds_read_tr16(vp);
+        const u32x2 v1 = lds_read_tr16(vp + 2 * NDJ * 256);
+        const u32x4 va = {v0[0], v0[1], v1[0], v1[1]};
+        M::o_acc(o[0][dj], va, pf[0][ks]);
+        M::o_acc(o[1][dj], va, pf[1][ks]);
+      }
+    }
+  };
+
+  // ---- prologue: K(0), V(0), K(1) resident; S(0) computed -------------------------------------------------------------
+  f32x16 sa[2][2], sb[2][2];      // S^T [query block][key block] of the current / the next tile (ping-pong)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { sa[qb][kb][r] = 0.f; sb[qb][kb][r] = 0.f; }
+  dma_k(0); dma_v(0); dma_k(1);                  // K(0), V(0), K(1)
+  dma_drain();
+  __syncthreads();
+  if (nt > 0 && wave_kv_end > 0) qk(0, sa);
+  // K(0) must have been read by EVERY wave before the first loop iteration refills Kbuf[0] with K(2)
+  __syncthreads();
+
+  // ---- main loop over unmasked tiles: hand-pinned software pipeline, 64 MFMA slots per tile -------------------------
+  //   phase A (32 slots): S(j+1) = K(j+1) Q^T, k-step major, 4 accumulators in turn (no dependent neighbours); every
+  //            K fragment serves two MFMAs; beside them NEA of the 64 exp2 / row-sum / pack elements of tile j;
+  //   phase B (32 slots): O^T += V(j)^T P(j)^T, 8 accumulators in turn, every V fragment serves two MFMAs; the first
+  //            64 - NEA slots finish tile j's elements (k-step 3 of P is first needed by slot 24), slots from MAX0 on
+  //            carry the row-max chain of S(j+1) (v_max3), the last one the defer-max decision.
+  //   Defer-max: O and l are rescaled only when some row's max grew by more than 2^kThr (wave-uniform, rare);
+  //   otherwise the old reference max is kept (P <= 2^kThr).
+  // sched_barrier(0) pins the slots; the asm MFMAs keep their program order among themselves.
+  constexpr float kThr = 8.f;
+  constexpr int NA = 32, NB = 32;
+  constexpr int NEA = USP_F64_NEA, LEAD = USP_F64_LEAD, PFK = USP_F64_PFK, PFV = USP_F64_PFV, MAX0 = USP_F64_MAX0;
+  static_assert(NEA >= 42 - 0 || true, "");
+  static_assert(64 - NEA <= 22, "k-step 3 of P must be complete two slots before slot 24 of phase B");
+  static_assert(MAX0 >= 1 && MAX0 < NB, "");
+  int j = 0;
+  const int n_main = n_full < nt - 1 ? n_full : nt - 1;    // j + 1 < nt holds inside: no branches
+  const float thr_raw = kThr / c;
+  float m_thr[2] = {USP_NEG_INF, USP_NEG_INF};   // m_run + kThr / c: a tile whose scores stay below keeps the reference
+  float nmc[2] = {0.f, 0.f};                     // -(reference max * c), 0 while the reference is still -inf
+  auto rescale = [&](const float (&mt_lane)[2]) {
+    asm volatile("; rescale (rare)" ::: "memory");          // keeps hipcc from if-converting the branch
+    mfma_settle(o);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const float m_new = fmaxf(m_run[qb], xhalf_max(mt_lane[qb]));
+      const float m_use = (m_new == USP_NEG_INF) ? 0.f : m_new;
+      const float alpha = fast_exp2(m_run[qb] * c - m_use * c);
+      m_run[qb] = m_new;
+      m_thr[qb] = m_new + thr_raw;
+      nmc[qb] = -(m_use * c);
+      l_run[qb] *= alpha;
+#pragma unroll
+      for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[qb][dj][r] *= alpha;
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int dj = 0; dj < NDJ; ++dj) pin_agpr(o[qb][dj]);
+    operand_settle();                                       // v_accvgpr_write -> MFMA SrcC
+  };
+  // one pipelined iteration: softmax + PV of tile jj (scores in cs), scores of tile jj+1 into ns
+  // (PAR = jj & 1 as a compile-time constant: every LDS offset of the iteration is an immediate)
+  auto iter = [&](auto par_c, f32x16 (&cs)[2][2], f32x16 (&ns)[2][2]) {
+    constexpr int PAR = decltype(par_c)::value;
+    dma_k(PAR);                   // K(jj+2) -> Kbuf[jj&1], which held K(jj): last read in the previous iteration
+    dma_v(PAR ^ 1);               // V(jj+1) -> Vbuf[(jj+1)&1], which held V(jj-1): last read in the previous iteration
+    USP_LDS const char* kb = smem + (PAR ^ 1) * KBYTES + k_rd;
+    USP_LDS const char* vb = smem + PAR * KBYTES + v_rd;
+    u32x4 ka[2 * NKT];                                      // fragment f = 2*kt + key block
+    auto rd_k = [&](int f) {
+      ka[f] = *(USP_LDS const u32x4*)(kb + (f & 1) * 32 * ROWB + (((2 * (f >> 1)) ^ k_rd_x) * 16));
+    };
+    u32x4 va[4 * NDJ];                                      // fragment f = NDJ*ks + dj
+    auto rd_v = [&](int f) {
+      USP_LDS const char* vp = vb + (4 * (f / NDJ) * NDJ + (f % NDJ)) * 256;
+      const u32x2 v0 = lds_read_tr16(vp);
+      const u32x2 v1 = lds_read_tr16(vp + 2 * NDJ * 256);
+      va[f] = u32x4{v0[0], v0[1], v1[0], v1[1]};
+    };
+    float rs[2] = {0.f, 0.f};
+    u32x4 pf[2][4];
+    // element e of the tile's 64 scores per lane, in the order the PV k-steps need them:
+    //   e = 16*ks + 8*qb + r8  ->  cs[qb][ks >> 1][8*(ks & 1) + r8]
+    // The consumers of an exp2 result run ONE ELEMENT LATE (row-sum add of e-1, pack of the pair (e-2, e-1)).
+    auto get = [&](int e) -> float { return cs[(e >> 3) & 1][e >> 5][8 * ((e >> 4) & 1) + (e & 7)]; };
+    auto consume = [&](int e) {                              // row sum (+ pack when e closes a pair)
+      rs[(e >> 3) & 1] += get(e);
+      if (e & 1) pf[(e >> 3) & 1][e >> 4][(e & 7) >> 1] = E::pack2(get(e - 1), get(e));
+    };
+    auto exp_elem = [&](int e) {
+      cs[(e >> 3) & 1][e >> 5][8 * ((e >> 4) & 1) + (e & 7)] = fast_exp2(__builtin_fmaf(get(e), c, nmc[(e >> 3) & 1]));
+      if (e > 0) consume(e - 1);
+      if (e == 63) consume(63);
+    };
+#pragma unroll
+    for (int f = 0; f < PFK; ++f) rd_k(f);
+#pragma unroll
+    for (int e = 0; e < LEAD; ++e) exp_elem(e);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---------------- phase A ----------------
+#pragma unroll
+    for (int sl = 0; sl < NA; ++sl) {
+      const int f = sl >> 1, kt = f >> 1, kbk = f & 1, qb = sl & 1;
+      if (qb == 0 && f + PFK < 2 * NKT) rd_k(f + PFK);
+      if (kt == 0) M::s_first(ns[qb][kbk], ka[f], qf[qb][0]);
+      else M::s_next(ns[qb][kbk], ka[f], qf[qb][kt]);
+#pragma unroll
+      for (int e = LEAD + sl * (NEA - LEAD) / NA; e < LEAD + (sl + 1) * (NEA - LEAD) / NA; ++e) exp_elem(e);
+      // the V fragments of phase B's first MFMAs are read behind phase A's last ones (V(jj) has been resident since
+      // the previous barrier)
+      if (sl >= NA - 2 * PFV && ((sl - (NA - 2 * PFV)) & 1) == 0) rd_v((sl - (NA - 2 * PFV)) >> 1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---------------- phase B ----------------
+    float mt[2] = {USP_NEG_INF, USP_NEG_INF};
+    bool keep = true;
+    constexpr int NMAX = NB - MAX0;                           // slots that carry row-max work (64 values)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int f = i >> 1, qb = i & 1;
+      if (qb == 0 && f + PFV < 4 * NDJ) rd_v(f + PFV);
+      M::o_acc(o[qb][f % NDJ], va[f], pf[qb][f / NDJ]);
+      if (NEA + i < 64) exp_elem(NEA + i);
+      if (i == 64 - NEA - 1 || (NEA == 64 && i == 0)) { l_run[0] += rs[0]; l_run[1] += rs[1]; }
+      if (i >= MAX0) {
+#pragma unroll
+        for (int x = (i - MAX0) * 64 / NMAX; x < (i - MAX0 + 1) * 64 / NMAX; ++x)      // value x: qb = x >> 5
+          mt[x >> 5] = fmaxf(mt[x >> 5], ns[x >> 5][(x >> 4) & 1][x & 15]);
+        if (i == NB - 1) keep = __all(mt[0] <= m_thr[0] && mt[1] <= m_thr[1]);       // behind the last MFMA, not after it
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!keep) rescale(mt);
+    dma_drain();                 // this wave's pieces of K(jj+2), V(jj+1) have landed ...
+    __syncthreads();             // ... and so have everybody else's
+  };
+
+  if (n_main > 0) {
+    float mt[2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      mt[qb] = sa[qb][0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt[qb] = fmaxf(mt[qb], sa[qb][0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt[qb] = fmaxf(mt[qb], sa[qb][1][r]);
+    }
+    if (!__all(mt[0] <= m_thr[0] && mt[1] <= m_thr[1])) rescale(mt);
+    const std::integral_constant<int, 0> even;
+    const std::integral_constant<int, 1> odd;
+    for (; j + 1 < n_main; j += 2) {
+      iter(even, sa, sb);
+      iter(odd, sb, sa);
+    }
+    if (j < n_main) {
+      iter(even, sa, sb);
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sa[qb][kb] = sb[qb][kb];
+      ++j;
+    }
+    mfma_settle(sa);             // the chain of the last iteration may end less than 12 states before its first reader
+  }
+  // ---- generic tail: masked and/or inactive tiles ------------------------------------------------------------------
+  for (; j < nt; ++j) {
+    const int kt0 = j * kBN;
+    dma_k(j & 1);                 // K(j+2), V(j+1): unconditionally, the cursors count tiles
+    dma_v((j + 1) & 1);
+    const bool next_active = j + 1 < nt && kt0 + kBN < wave_kv_end;
+    if (next_active) qk((j + 1) & 1, sb);
+    if (kt0 < wave_kv_end) {
+      const bool need_mask = (kt0 + kBN > p->Sk) || (CAUSAL && kt0 + kBN - 1 > qw + off);
+      if (need_mask) mask(kt0, sa);
+      u32x4 pf[2][4];
+      softmax(sa, pf);
+      pv(j & 1, pf);
+    }
+    if (next_active) {
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) sa[qb][kb] = sb[qb][kb];
+    }
+    dma_drain();
+    __syncthreads();
+  }
+
+  // ---- epilogue: normalise, merge with the running result, store (per query block, as in usp_flash_fwd.hip) -------
+  mfma_settle(o);
+  asm volatile("" : "+s"(p));
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int row = qw + 32 * qb + l31;
+    const float l_tot = xhalf_sum(l_run[qb]);
+    const bool empty = !(l_tot > 0.f);
+    const float inv = empty ? 0.f : 1.f / l_tot;
+    const float blk_lse = empty ? USP_NEG_INF : (m_run[qb] * c + log2f(l_tot)) * kLn2;
+    float w_blk = inv, w_old = 0.f, new_lse = blk_lse;
+    float* lse_p = p->lse + b * p->lse_sb + h * p->lse_sh + row;
+    const bool valid = row < p->Sq;
+    const bool fin = row >= p->final_begin && row < p->final_end;
+    // single-pass call whose 32 rows are all final and 16-byte aligned: straight-line widened stores
+    const bool wide = !p->merge_in && p->out_wide && __all(!valid || fin);
+    if (valid) {
+      if (p->merge_in) {
+        const float old = *lse_p;
+        const float mx = fmaxf(old, blk_lse);
+        if (mx == USP_NEG_INF) {
+          new_lse = USP_NEG_INF; w_old = 0.f; w_blk = 0.f;
+        } else {
+          const float e_old = exp2f((old - mx) * kLog2e);
+          const float e_blk = exp2f((blk_lse - mx) * kLog2e);
+          const float sum = e_old + e_blk;
+          new_lse = mx + log2f(sum) * kLn2;
+          w_old = e_old / sum;
+          w_blk = e_blk / sum * inv;
+        }
+      }
+      if (hi == 0) *lse_p = new_lse;
+      const int64_t arow = b * p->a_sb + (int64_t)row * p->a_ss + h * p->a_sh;
+      const int64_t orow = b * p->o_sb + (int64_t)row * p->o_ss + h * p->o_sh;
+      if (wide) {
+        // each row is split across the two half-waves in 8-byte pieces; one v_permlane32_swap per dword regroups two
+        // adjacent pieces into 16 contiguous bytes per lane (the store tail is issue-bound)
+        char* op = p->out + 2 * orow;
+#pragma unroll
+        for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+          for (int g2 = 0; g2 < 2; ++g2) {
+            const int r0 = 8 * g2;
+            uint32_t ax = E::pack2(o[qb][dj][r0] * w_blk, o[qb][dj][r0 + 1] * w_blk);
+            uint32_t ay = E::pack2(o[qb][dj][r0 + 2] * w_blk, o[qb][dj][r0 + 3] * w_blk);
+            uint32_t bx = E::pack2(o[qb][dj][r0 + 4] * w_blk, o[qb][dj][r0 + 5] * w_blk);
+            uint32_t by = E::pack2(o[qb][dj][r0 + 6] * w_blk, o[qb][dj][r0 + 7] * w_blk);
+            const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            *(u32x4*)(op + 2 * (32 * dj + 16 * g2 + 8 * hi)) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+          }
+      } else {
+#pragma unroll
+        for (int dj = 0; dj < NDJ; ++dj) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int d0 = 32 * dj + 8 * g4 + 4 * hi;
+            f32x4 val = {o[qb][dj][4 * g4] * w_blk, o[qb][dj][4 * g4 + 1] * w_blk, o[qb][dj][4 * g4 + 2] * w_blk,
+                         o[qb][dj][4 * g4 + 3] * w_blk};
+            if (p->merge_in) {
+              const f32x4 a = *(const f32x4*)(p->acc + arow + d0);
+              val += a * w_old;
+            }
+            if (fin) {
+              u32x2 pk = {E::pack2(val[0], val[1]), E::pack2(val[2], val[3])};
+              *(u32x2*)(p->out + 2 * (orow + d0)) = pk;
+            } else {
+              *(f32x4*)(p->acc + arow + d0) = val;
+            }
+          }
+        }
+      }
+    }
+  }
+  }  // next item
+}
+
+bool launch_fwd64(const FwdParams& p_in, int dtype, bool causal, hipStream_t st, int* rc) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  // the kernel's K / V cursors count remaining bytes in 32 bits
+  if (((int64_t)(p_in.Sk - 1) * p_in.k_ss + 128) * 2 >= (1LL << 31) || ((int64_t)(p_in.Sk - 1) * p_in.v_ss + 128) * 2 >= (1LL << 31))
+    return false;
+  FwdArgsT<false> p;
+  static_cast<FwdParams&>(p) = p_in;
+  p.nq = (p.Sq + 255) / 256;
+  p.n_items = p.B * p.Hq * p.nq;
+  const int grid = (!p.interleave && p.n_items > cus) ? cus : p.n_items;      // persistent: one workgroup per CU
+  const size_t lds = 2 * 2 * kBN * 128 * 2;
+  if (dtype == USP_BF16) {
+    if (causal) hipLaunchKernelGGL((flash_fwd64_kernel<0, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((flash_fwd64_kernel<0, false>), dim3(grid), dim3(256), lds, st, p);
+  } else {
+    if (causal) hipLaunchKernelGGL((flash_fwd64_kernel<1, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((flash_fwd64_kernel<1, false>), dim3(grid), dim3(256), lds, st, p);
+  }
+  *rc = hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
+  return true;
+}
+
+}  // namespace usp
