@@ -72,6 +72,28 @@ USP_DEV void mfma_settle(f32x16 (&s)[2][2]) {
 // VALU write (v_cvt_pk / v_accvgpr_write) -> MFMA operand read: 2 wait states, which hipcc does not pad in front of asm
 USP_DEV void operand_settle() { asm volatile("s_nop 3" ::: "memory"); }
 
+// LDS-DMA from inline asm (buffer_load_dwordx4 ... lds: 64 x 16 bytes at rsrc.base + soffset + voffset land linearly at
+// the wave-uniform LDS address M0).  hipcc does not see these loads: it puts no s_waitcnt vmcnt(0) in front of the first
+// ds_read_b64_tr_b16 behind a DMA (it cannot tell the double buffers apart), so the pieces can be issued anywhere in an
+// iteration; the kernel drains them itself (dma_drain) in front of the barrier that publishes the tile.  M0 is written
+// by piece 0 of a tile and read by pieces 1-3 (hipcc itself never touches M0 in this kernel: tools/mfma_hazards.py checks
+// the .s); the s_nop covers "SALU write M0 -> LDS-DMA".  Descriptor and offsets are SALU results (no VALU -> SGPR hazard).
+template <int UNUSED>
+USP_DEV void lds_dma16_asm(const u32x4& rsrc, int lds_dst, int voffset, int soffset, int piece) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (piece == 0)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 : : "s"(lds_dst), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+  if (piece == 1) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds" : : "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+  if (piece == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:2048 lds" : : "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+  if (piece == 3) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds" : : "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+#endif
+}
+USP_DEV u32x4 make_rsrc(const char* base, int bytes) {
+  const uint64_t a = (uint64_t)base;
+  return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)(bytes > 0 ? bytes : 0), 0x00020000u};
+}
+
 #ifndef USP_F64_NEA      // exp elements (of 64 per lane and tile) issued in phase A; the rest opens phase B, one per slot
 #define USP_F64_NEA 42
 #endif
@@ -86,6 +108,15 @@ USP_DEV void operand_settle() { asm volatile("s_nop 3" ::: "memory"); }
 #endif
 #ifndef USP_F64_MAX0     // first slot of phase B that carries row-max work of the next tile
 #define USP_F64_MAX0 22
+#endif
+#ifndef USP_F64_DMA0     // slot (0..63 over both phases) behind whose MFMA the first of the iteration's 8 LDS-DMA pieces goes
+#define USP_F64_DMA0 2   // out, and the distance to the next one; step 0 = all eight in front of the first MFMA
+#endif
+#ifndef USP_F64_DMAS
+#define USP_F64_DMAS 6
+#endif
+#ifndef USP_F64_DMAW     // stagger between the waves of a workgroup: wave w issues piece n behind slot DMA0 + DMAS*n + DMAW*w
+#define USP_F64_DMAW 0   // (the four waves run in lockstep -- one barrier per tile -- and a CU has ONE texture addresser)
 #endif
 
 template <int DT, bool CAUSAL>
@@ -118,11 +149,15 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   asm volatile("" : "+s"(p));
 
   // ---- lane-constant addresses --------------------------------------------------------------------------------------
-  // LDS-DMA pieces (1 KiB per wave-instruction; layouts as in usp_flash_fwd.hip): piece i of this wave is chunk
-  // wave + 4i of the tile = K rows 4*wave + 16i .. +3 (slot swizzle on the source side) / V keys 4*wave + 16i .. +3, so
-  // the per-lane offset is the same for all four pieces and the piece is selected by a scalar offset.
-  const int k_voff = (4 * wave + (lane >> 4)) * (int)p->k_ss * 2 + (((lane & 15) ^ ((4 * wave + (lane >> 4)) & 15)) * 16);
-  const int v_voff = (4 * wave + ((lane & 15) >> 2)) * (int)p->v_ss * 2 + (32 * (lane >> 4) + 8 * (lane & 3)) * 2;
+  // LDS-DMA pieces (1 KiB per wave-instruction; tile layouts as in usp_flash_fwd.hip).  This wave fills the CONTIGUOUS chunks
+  // 4*wave .. 4*wave + 3 of every tile = K rows / V keys 16*wave + 4i .. +3 for piece i: the LDS address of a piece is
+  // M0 + the instruction's immediate offset, so ONE M0 write serves the four pieces of a tile (offset 0 / 1024 / 2048 /
+  // 3072; the same immediate also moves the memory address and is taken out of the scalar offset again).  Writing M0 per
+  // piece costs ~65 cycles each -- the s_mov waits for the previous piece to leave the memory pipeline -- which one wave
+  // per SIMD cannot hide (profiles/r04_dma_probes.txt).  K: the slot swizzle key of row 16w + 4i + l/16 is 4i | l/16, so
+  // piece i's per-lane offset is piece 0's with 64*i XORed in (the row part is a multiple of 256 bytes: launch_fwd64).
+  const int k_voff = (16 * wave + (lane >> 4)) * (int)p->k_ss * 2 + (((lane & 15) ^ (lane >> 4)) * 16);
+  const int v_voff = (16 * wave + ((lane & 15) >> 2)) * (int)p->v_ss * 2 + (32 * (lane >> 4) + 8 * (lane & 3)) * 2;
   const int k_rd = l31 * ROWB;                                  // row read (A operand of K Q^T): tile row 32*kb + l31
   const int k_rd_x = hi ^ (l31 & 15);                           // (2t + hi) ^ swz == (2t) ^ (hi ^ swz)
   const int v_rd = VOFF + hi * NDJ * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
@@ -195,20 +230,91 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   // (lds_w / k_step / v_step pass through an opaque asm at every use: hipcc otherwise hoists the sixteen M0 values and the
   // six scalar offsets of the pieces out of the loops as invariants and then SPILLS them -- a v_readlane plus five wait
   // states in front of every LDS-DMA; computed at the use each is one s_add / s_lshl / s_mul)
-  int lds_w = wave * 1024, k_step = 16 * (int)p->k_ss * 2, v_step = 16 * (int)p->v_ss * 2;
-  auto dma_k = [&](int buf) {                               // next K tile -> Kbuf[buf]
-    asm volatile("" : "+s"(lds_w), "+s"(k_step));
-    const auto rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)k_cur, 0, k_rem > 0 ? k_rem : 0, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lds_dma16(rs_, smem + lds_w + (buf * KBYTES + i * 4096), k_voff, i * k_step);
+  int lds_w = wave * 4096, k_step = 4 * (int)p->k_ss * 2 - 1024, v_step = 4 * (int)p->v_ss * 2 - 1024;
+  u32x4 k_rs, v_rs;                                         // descriptors of the tiles being fetched
+  int dma_kbuf = 0, dma_vbuf = 0;
+  // open the next K / V tile (descriptor for the cursor's tile, then advance the cursor); its four pieces follow
+  auto dma_open = [&](int kbuf, int vbuf) {
+    k_rs = make_rsrc(k_cur, k_rem);
+    v_rs = make_rsrc(v_cur, v_rem);
     k_cur += k_tb; k_rem -= k_tb;
-  };
-  auto dma_v = [&](int buf) {                               // next V tile -> Vbuf[buf]
-    asm volatile("" : "+s"(lds_w), "+s"(v_step));
-    const auto rs_ = __builtin_amdgcn_make_buffer_rsrc((void*)v_cur, 0, v_rem > 0 ? v_rem : 0, 0x00020000);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) lds_dma16(rs_, smem + lds_w + (VOFF + buf * KBYTES + i * 4096), v_voff, i * v_step);
     v_cur += v_tb; v_rem -= v_tb;
+    dma_kbuf = kbuf; dma_vbuf = vbuf;
+  };
+  auto dma_open_k = [&](int kbuf) {
+    k_rs = make_rsrc(k_cur, k_rem);
+    k_cur += k_tb; k_rem -= k_tb;
+    dma_kbuf = kbuf;
+  };
+  // piece n of the opened tiles: n < 4 -> K piece n, else V piece n - 4
+#ifdef USP_F64_PROBE      // dev A/B builds: what does a piece cost, and why?  (1: plain load into an AGPR quad, nothing written;
+  u32x4 stg[8];           //  2: ... and written to LDS in front of the barrier -- register staging, functional; 3: every other
+  const int stg_lane = lane * 16 + wave * 4096;   // piece only; 5: 4-byte pieces)
+#endif
+  bool dma_skip = false;           // dev A/B builds (USP_F64_ABL_NODMA): the pipelined loop skips its pieces; LDS keeps REAL tiles
+  auto dma_piece = [&](int n) {
+#ifdef USP_F64_ABL_NODMA
+    if (dma_skip) return;
+#endif
+    {
+    asm volatile("" : "+s"(lds_w), "+s"(k_step), "+s"(v_step));
+    const u32x4& rs_ = n < 4 ? k_rs : v_rs;
+    const int dst = n < 4 ? lds_w + dma_kbuf * KBYTES : lds_w + VOFF + dma_vbuf * KBYTES;     // of the tile's piece 0
+    const int vo = n < 4 ? (k_voff ^ (64 * n)) : v_voff, so = n < 4 ? n * k_step : (n - 4) * v_step;
+#if !defined(USP_F64_PROBE)
+    lds_dma16_asm<(0)>(rs_, dst, vo, so, n & 3);
+#elif USP_F64_PROBE == 1 || USP_F64_PROBE == 2
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(stg[n]) : "v"(vo), "s"(rs_), "s"(so) : "memory"); (void)dst;
+#elif USP_F64_PROBE == 3
+    if ((n & 1) == 0) lds_dma16_asm(rs_, dst, vo, so);
+#elif USP_F64_PROBE == 5
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(dst), "v"(vo), "s"(rs_), "s"(so) : "memory");
+#elif USP_F64_PROBE == 6      // M0 written once per tile (every piece lands on the same KiB: garbage; is the M0 write the cost?)
+    if (n == 0 || n == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(dst) : "memory");
+    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(vo), "s"(rs_), "s"(so) : "memory");
+#elif USP_F64_PROBE == 7      // ... and with the instruction offset walking the KiBs (is the LDS address M0 + offset?)
+    if (n == 0 || n == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(dst) : "memory");
+    if ((n & 3) == 0) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(vo), "s"(rs_), "s"(so) : "memory");
+    if ((n & 3) == 1) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds" : : "v"(vo), "s"(rs_), "s"(so) : "memory");
+    if ((n & 3) == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:2048 lds" : : "v"(vo), "s"(rs_), "s"(so) : "memory");
+    if ((n & 3) == 3) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds" : : "v"(vo), "s"(rs_), "s"(so) : "memory");
+#endif
+    }
+  };
+  // register staging (probe 2): the staged pieces go to LDS behind the wave's vmcnt(0), in front of the barrier
+#ifndef USP_F64_STG_WS
+#define USP_F64_STG_WS 0
+#endif
+#ifndef USP_F64_STG_W0
+#define USP_F64_STG_W0 34
+#endif
+  // register staging, piece n to LDS: behind a COUNTED wait (the pieces were loaded in order, nothing else is in flight)
+  auto stage_write = [&](int n) {
+#if defined(USP_F64_PROBE) && USP_F64_PROBE == 2
+    const int dst = n < 4 ? dma_kbuf * KBYTES + n * 1024 : VOFF + dma_vbuf * KBYTES + (n - 4) * 1024;
+    if (n == 0) asm volatile("s_waitcnt vmcnt(7)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
+    if (n == 1) asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
+    if (n == 2) asm volatile("s_waitcnt vmcnt(5)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
+    if (n == 3) asm volatile("s_waitcnt vmcnt(4)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
+    if (n == 4) asm volatile("s_waitcnt vmcnt(3)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
+    if (n == 5) asm volatile("s_waitcnt vmcnt(2)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
+    if (n == 6) asm volatile("s_waitcnt vmcnt(1)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
+    if (n == 7) asm volatile("s_waitcnt vmcnt(0)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
+#endif
+  };
+  auto stage_flush = [&]() {
+#if defined(USP_F64_PROBE) && USP_F64_PROBE == 2
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {
+      const int dst = n < 4 ? dma_kbuf * KBYTES + n * 1024 : VOFF + dma_vbuf * KBYTES + (n - 4) * 1024;
+      asm volatile("ds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
+    }
+#endif
+  };
+  auto dma_all = [&](int kbuf, int vbuf) {                  // next K tile -> Kbuf[kbuf], next V tile -> Vbuf[vbuf]
+    dma_open(kbuf, vbuf);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) dma_piece(n);
   };
 
   // ---- accumulators / softmax state (index = query block) -----------------------------------------------------------
@@ -329,8 +435,15 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sa[qb][kb][r] = 0.f; sb[qb][kb][r] = 0.f; }
-  dma_k(0); dma_v(0); dma_k(1);                  // K(0), V(0), K(1)
+  dma_all(0, 0);                                 // K(0), V(0)
+#if defined(USP_F64_PROBE) && USP_F64_PROBE == 2
+  dma_drain(); stage_flush();
+#endif
+  dma_open_k(1);                                 // K(1)
+#pragma unroll
+  for (int n = 0; n < 4; ++n) dma_piece(n);
   dma_drain();
+  stage_flush();
   __syncthreads();
   if (nt > 0 && wave_kv_end > 0) qk(0, sa);
   // K(0) must have been read by EVERY wave before the first loop iteration refills Kbuf[0] with K(2)
@@ -383,23 +496,52 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   // (PAR = jj & 1 as a compile-time constant: every LDS offset of the iteration is an immediate)
   auto iter = [&](auto par_c, f32x16 (&cs)[2][2], f32x16 (&ns)[2][2]) {
     constexpr int PAR = decltype(par_c)::value;
-    dma_k(PAR);                   // K(jj+2) -> Kbuf[jj&1], which held K(jj): last read in the previous iteration
-    dma_v(PAR ^ 1);               // V(jj+1) -> Vbuf[(jj+1)&1], which held V(jj-1): last read in the previous iteration
+    // K(jj+2) -> Kbuf[jj&1], which held K(jj), and V(jj+1) -> Vbuf[(jj+1)&1], which held V(jj-1): both last read in the
+    // previous iteration.  The eight pieces go out in front of the first MFMA (DMAS == 0) or one behind every DMAS-th MFMA.
+    constexpr int DMA0 = USP_F64_DMA0, DMAS = USP_F64_DMAS;
+#ifdef USP_F64_ABL_NODMA
+    dma_skip = true;
+#endif
+    dma_open(PAR, PAR ^ 1);
+    if (DMAS == 0) {
+#pragma unroll
+      for (int n = 0; n < 8; ++n) dma_piece(n);
+    }
+    auto dma_slot = [&](int g) {                              // g = slot index over both phases
+      constexpr int DS = DMAS > 0 ? DMAS : 1, DMAW = USP_F64_DMAW;
+      if (DMAS > 0 && DMAW == 0) {
+        if (g >= DMA0 && (g - DMA0) % DS == 0 && (g - DMA0) / DS < 8) dma_piece((g - DMA0) / DS);
+      } else if (DMAS > 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const int t = g - DMA0 - DMAW * w;
+          if (t >= 0 && t % DS == 0 && t / DS < 8) { if (wave == w) dma_piece(t / DS); }
+        }
+      }
+    };
     USP_LDS const char* kb = smem + (PAR ^ 1) * KBYTES + k_rd;
     USP_LDS const char* vb = smem + PAR * KBYTES + v_rd;
     u32x4 ka[2 * NKT];                                      // fragment f = 2*kt + key block
     auto rd_k = [&](int f) {
+#ifdef USP_F64_ABL_NOLDS      // dev A/B build: fragments from registers
+      ka[f] = u32x4{(uint32_t)lane, (uint32_t)f, (uint32_t)hi, 0x3f803f80u}; (void)kb;
+#else
       ka[f] = *(USP_LDS const u32x4*)(kb + (f & 1) * 32 * ROWB + (((2 * (f >> 1)) ^ k_rd_x) * 16));
+#endif
     };
     u32x4 va[4 * NDJ];                                      // fragment f = NDJ*ks + dj
+    float rs[2] = {0.f, 0.f};
+    u32x4 pf[2][4];
     auto rd_v = [&](int f) {
+#ifdef USP_F64_ABL_NOLDS
+      va[f] = u32x4{(uint32_t)lane, (uint32_t)f, (uint32_t)hi, 0x3f803f80u}; (void)vb;
+#else
       USP_LDS const char* vp = vb + (4 * (f / NDJ) * NDJ + (f % NDJ)) * 256;
       const u32x2 v0 = lds_read_tr16(vp);
       const u32x2 v1 = lds_read_tr16(vp + 2 * NDJ * 256);
       va[f] = u32x4{v0[0], v0[1], v1[0], v1[1]};
+#endif
     };
-    float rs[2] = {0.f, 0.f};
-    u32x4 pf[2][4];
     // element e of the tile's 64 scores per lane, in the order the PV k-steps need them:
     //   e = 16*ks + 8*qb + r8  ->  cs[qb][ks >> 1][8*(ks & 1) + r8]
     // The consumers of an exp2 result run ONE ELEMENT LATE (row-sum add of e-1, pack of the pair (e-2, e-1)).
@@ -409,6 +551,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
       if (e & 1) pf[(e >> 3) & 1][e >> 4][(e & 7) >> 1] = E::pack2(get(e - 1), get(e));
     };
     auto exp_elem = [&](int e) {
+#ifdef USP_F64_ABL_NOEXP      // dev A/B build: no element work at all (P = raw bits of every other score)
+      if (e & 1) pf[(e >> 3) & 1][e >> 4][(e & 7) >> 1] = __builtin_bit_cast(uint32_t, get(e));
+      return;
+#endif
       cs[(e >> 3) & 1][e >> 5][8 * ((e >> 4) & 1) + (e & 7)] = fast_exp2(__builtin_fmaf(get(e), c, nmc[(e >> 3) & 1]));
       if (e > 0) consume(e - 1);
       if (e == 63) consume(63);
@@ -430,6 +576,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
       // the V fragments of phase B's first MFMAs are read behind phase A's last ones (V(jj) has been resident since
       // the previous barrier)
       if (sl >= NA - 2 * PFV && ((sl - (NA - 2 * PFV)) & 1) == 0) rd_v((sl - (NA - 2 * PFV)) >> 1);
+      dma_slot(sl);
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---------------- phase B ----------------
@@ -449,11 +596,21 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
           mt[x >> 5] = fmaxf(mt[x >> 5], ns[x >> 5][(x >> 4) & 1][x & 15]);
         if (i == NB - 1) keep = __all(mt[0] <= m_thr[0] && mt[1] <= m_thr[1]);       // behind the last MFMA, not after it
       }
+      dma_slot(NA + i);
+      if (USP_F64_STG_WS > 0 && NA + i >= USP_F64_STG_W0 && (NA + i - USP_F64_STG_W0) % (USP_F64_STG_WS > 0 ? USP_F64_STG_WS : 1) == 0 &&
+          (NA + i - USP_F64_STG_W0) / (USP_F64_STG_WS > 0 ? USP_F64_STG_WS : 1) < 8)
+        stage_write((NA + i - USP_F64_STG_W0) / (USP_F64_STG_WS > 0 ? USP_F64_STG_WS : 1));
       __builtin_amdgcn_sched_barrier(0);
     }
     if (!keep) rescale(mt);
+#ifndef USP_F64_ABL_NOBAR
     dma_drain();                 // this wave's pieces of K(jj+2), V(jj+1) have landed ...
+    if (USP_F64_STG_WS == 0) stage_flush();
+#if defined(USP_F64_PROBE) && USP_F64_PROBE == 2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (staged ds_writes issued from asm are invisible to hipcc's barrier wait)
+#endif
     __syncthreads();             // ... and so have everybody else's
+#endif
   };
 
   if (n_main > 0) {
@@ -484,10 +641,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
     mfma_settle(sa);             // the chain of the last iteration may end less than 12 states before its first reader
   }
   // ---- generic tail: masked and/or inactive tiles ------------------------------------------------------------------
+  dma_skip = false;
   for (; j < nt; ++j) {
     const int kt0 = j * kBN;
-    dma_k(j & 1);                 // K(j+2), V(j+1): unconditionally, the cursors count tiles
-    dma_v((j + 1) & 1);
+    dma_all(j & 1, (j + 1) & 1);  // K(j+2), V(j+1): unconditionally, the cursors count tiles
     const bool next_active = j + 1 < nt && kt0 + kBN < wave_kv_end;
     if (next_active) qk((j + 1) & 1, sb);
     if (kt0 < wave_kv_end) {
@@ -504,6 +661,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
         for (int kb = 0; kb < 2; ++kb) sa[qb][kb] = sb[qb][kb];
     }
     dma_drain();
+    stage_flush();
     __syncthreads();
   }
 
@@ -595,6 +753,7 @@ bool launch_fwd64(const FwdParams& p_in, int dtype, bool causal, hipStream_t st,
   // the kernel's K / V cursors count remaining bytes in 32 bits
   if (((int64_t)(p_in.Sk - 1) * p_in.k_ss + 128) * 2 >= (1LL << 31) || ((int64_t)(p_in.Sk - 1) * p_in.v_ss + 128) * 2 >= (1LL << 31))
     return false;
+  if ((p_in.k_ss * 2) % 256 != 0) return false;        // the K pieces' swizzle is XORed into the per-lane byte offset
   FwdArgsT<false> p;
   static_cast<FwdParams&>(p) = p_in;
   p.nq = (p.Sq + 255) / 256;
