@@ -34,21 +34,26 @@ template <int DT> struct M64;
 #if defined(__HIP_DEVICE_COMPILE__)   // "a" means eax to the host pass, which then drops the kernel stubs
 #define USP_M64_BODY(MN)                                                                                              \
   /* first MFMA of a score chain: C = 0; D in arch VGPRs; A = K fragment (VGPR), B = Q fragment (AGPR) */            \
-  static USP_DEV void s_first(f32x16& s, const u32x4& a, const u32x4& q) {                                            \
-    asm volatile(MN " %0, %1, %2, 0" : "=&v"(s) : "v"(a), "a"(q));                                                    \
+  /* SAFE: two wait states in front ("VALU / v_accvgpr_write -> MFMA operand") for the code outside the steady state, */ \
+  /* where hipcc may re-materialise an operand right in front of the statement                                     */ \
+  template <bool SAFE = false> static USP_DEV void s_first(f32x16& s, const u32x4& a, const u32x4& q) {               \
+    if (SAFE) asm volatile("s_nop 1\n\t" MN " %0, %1, %2, 0" : "=&v"(s) : "v"(a), "a"(q));                          \
+    else asm volatile(MN " %0, %1, %2, 0" : "=&v"(s) : "v"(a), "a"(q));                                               \
   }                                                                                                                   \
-  static USP_DEV void s_next(f32x16& s, const u32x4& a, const u32x4& q) {                                             \
-    asm volatile(MN " %0, %1, %2, %0" : "+v"(s) : "v"(a), "a"(q));                                                    \
+  template <bool SAFE = false> static USP_DEV void s_next(f32x16& s, const u32x4& a, const u32x4& q) {                \
+    if (SAFE) asm volatile("s_nop 1\n\t" MN " %0, %1, %2, %0" : "+v"(s) : "v"(a), "a"(q));                          \
+    else asm volatile(MN " %0, %1, %2, %0" : "+v"(s) : "v"(a), "a"(q));                                               \
   }                                                                                                                   \
   /* O^T accumulate: C/D in AGPRs; A = V^T fragment, B = packed P (VGPRs) */                                           \
-  static USP_DEV void o_acc(f32x16& o, const u32x4& a, const u32x4& b) {                                              \
-    asm volatile(MN " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                                    \
+  template <bool SAFE = false> static USP_DEV void o_acc(f32x16& o, const u32x4& a, const u32x4& b) {                 \
+    if (SAFE) asm volatile("s_nop 1\n\t" MN " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                          \
+    else asm volatile(MN " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                               \
   }
 #else
 #define USP_M64_BODY(MN)                                                                                              \
-  static USP_DEV void s_first(f32x16&, const u32x4&, const u32x4&) {}                                                 \
-  static USP_DEV void s_next(f32x16&, const u32x4&, const u32x4&) {}                                                  \
-  static USP_DEV void o_acc(f32x16&, const u32x4&, const u32x4&) {}
+  template <bool SAFE = false> static USP_DEV void s_first(f32x16&, const u32x4&, const u32x4&) {}                    \
+  template <bool SAFE = false> static USP_DEV void s_next(f32x16&, const u32x4&, const u32x4&) {}                     \
+  template <bool SAFE = false> static USP_DEV void o_acc(f32x16&, const u32x4&, const u32x4&) {}
 #endif
 template <> struct M64<0> { USP_M64_BODY("v_mfma_f32_32x32x16_bf16") };
 template <> struct M64<1> { USP_M64_BODY("v_mfma_f32_32x32x16_f16") };
@@ -78,7 +83,6 @@ USP_DEV void operand_settle() { asm volatile("s_nop 3" ::: "memory"); }
 // iteration; the kernel drains them itself (dma_drain) in front of the barrier that publishes the tile.  M0 is written
 // by piece 0 of a tile and read by pieces 1-3 (hipcc itself never touches M0 in this kernel: tools/mfma_hazards.py checks
 // the .s); the s_nop covers "SALU write M0 -> LDS-DMA".  Descriptor and offsets are SALU results (no VALU -> SGPR hazard).
-template <int UNUSED>
 USP_DEV void lds_dma16_asm(const u32x4& rsrc, int lds_dst, int voffset, int soffset, int piece) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if (piece == 0)
@@ -115,10 +119,6 @@ USP_DEV u32x4 make_rsrc(const char* base, int bytes) {
 #ifndef USP_F64_DMAS
 #define USP_F64_DMAS 6
 #endif
-#ifndef USP_F64_DMAW     // stagger between the waves of a workgroup: wave w issues piece n behind slot DMA0 + DMAS*n + DMAW*w
-#define USP_F64_DMAW 0   // (the four waves run in lockstep -- one barrier per tile -- and a CU has ONE texture addresser)
-#endif
-
 template <int DT, bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<false> /* read through the kernarg segment */) {
   using E = Elem<DT>;
@@ -158,8 +158,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   // piece i's per-lane offset is piece 0's with 64*i XORed in (the row part is a multiple of 256 bytes: launch_fwd64).
   const int k_voff = (16 * wave + (lane >> 4)) * (int)p->k_ss * 2 + (((lane & 15) ^ (lane >> 4)) * 16);
   const int v_voff = (16 * wave + ((lane & 15) >> 2)) * (int)p->v_ss * 2 + (32 * (lane >> 4) + 8 * (lane & 3)) * 2;
-  const int k_rd = l31 * ROWB;                                  // row read (A operand of K Q^T): tile row 32*kb + l31
-  const int k_rd_x = hi ^ (l31 & 15);                           // (2t + hi) ^ swz == (2t) ^ (hi ^ swz)
+  // row read (A operand of K Q^T): tile row 32*kb + l31, logical slot 2t + hi -> physical slot (2t) ^ (hi ^ swz).  The row
+  // part is a multiple of 256 and the slot part is below 256, so the eight k-steps' addresses are ONE base with 32*t XORed
+  // in (one v_xor per k-step instead of eight address registers: the loop sits at the 256-VGPR limit)
+  const int k_rd = l31 * ROWB + ((hi ^ (l31 & 15)) * 16);
   const int v_rd = VOFF + hi * NDJ * 256 + ((lane & 15) >> 2) * 64 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
   const float c = p->scale_log2;
 
@@ -199,7 +201,6 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
     const int nf = lim > 0 ? lim / kBN : 0;
     n_full = nf < n_full ? nf : n_full;
   }
-  if (qw + 64 > p->Sq) n_full = 0;                          // ragged / inactive waves take the generic loop
   if (n_full > nt) n_full = nt;
 
   // ---- Q fragments (B operand: lane holds Q[row][16t + 8hi .. +7]), parked in the accumulator file -----------------
@@ -247,69 +248,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
     dma_kbuf = kbuf;
   };
   // piece n of the opened tiles: n < 4 -> K piece n, else V piece n - 4
-#ifdef USP_F64_PROBE      // dev A/B builds: what does a piece cost, and why?  (1: plain load into an AGPR quad, nothing written;
-  u32x4 stg[8];           //  2: ... and written to LDS in front of the barrier -- register staging, functional; 3: every other
-  const int stg_lane = lane * 16 + wave * 4096;   // piece only; 5: 4-byte pieces)
-#endif
-  bool dma_skip = false;           // dev A/B builds (USP_F64_ABL_NODMA): the pipelined loop skips its pieces; LDS keeps REAL tiles
   auto dma_piece = [&](int n) {
-#ifdef USP_F64_ABL_NODMA
-    if (dma_skip) return;
-#endif
-    {
     asm volatile("" : "+s"(lds_w), "+s"(k_step), "+s"(v_step));
-    const u32x4& rs_ = n < 4 ? k_rs : v_rs;
-    const int dst = n < 4 ? lds_w + dma_kbuf * KBYTES : lds_w + VOFF + dma_vbuf * KBYTES;     // of the tile's piece 0
-    const int vo = n < 4 ? (k_voff ^ (64 * n)) : v_voff, so = n < 4 ? n * k_step : (n - 4) * v_step;
-#if !defined(USP_F64_PROBE)
-    lds_dma16_asm<(0)>(rs_, dst, vo, so, n & 3);
-#elif USP_F64_PROBE == 1 || USP_F64_PROBE == 2
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(stg[n]) : "v"(vo), "s"(rs_), "s"(so) : "memory"); (void)dst;
-#elif USP_F64_PROBE == 3
-    if ((n & 1) == 0) lds_dma16_asm(rs_, dst, vo, so);
-#elif USP_F64_PROBE == 5
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" : : "s"(dst), "v"(vo), "s"(rs_), "s"(so) : "memory");
-#elif USP_F64_PROBE == 6      // M0 written once per tile (every piece lands on the same KiB: garbage; is the M0 write the cost?)
-    if (n == 0 || n == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(dst) : "memory");
-    asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(vo), "s"(rs_), "s"(so) : "memory");
-#elif USP_F64_PROBE == 7      // ... and with the instruction offset walking the KiBs (is the LDS address M0 + offset?)
-    if (n == 0 || n == 4) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(dst) : "memory");
-    if ((n & 3) == 0) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(vo), "s"(rs_), "s"(so) : "memory");
-    if ((n & 3) == 1) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds" : : "v"(vo), "s"(rs_), "s"(so) : "memory");
-    if ((n & 3) == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:2048 lds" : : "v"(vo), "s"(rs_), "s"(so) : "memory");
-    if ((n & 3) == 3) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds" : : "v"(vo), "s"(rs_), "s"(so) : "memory");
-#endif
-    }
-  };
-  // register staging (probe 2): the staged pieces go to LDS behind the wave's vmcnt(0), in front of the barrier
-#ifndef USP_F64_STG_WS
-#define USP_F64_STG_WS 0
-#endif
-#ifndef USP_F64_STG_W0
-#define USP_F64_STG_W0 34
-#endif
-  // register staging, piece n to LDS: behind a COUNTED wait (the pieces were loaded in order, nothing else is in flight)
-  auto stage_write = [&](int n) {
-#if defined(USP_F64_PROBE) && USP_F64_PROBE == 2
-    const int dst = n < 4 ? dma_kbuf * KBYTES + n * 1024 : VOFF + dma_vbuf * KBYTES + (n - 4) * 1024;
-    if (n == 0) asm volatile("s_waitcnt vmcnt(7)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
-    if (n == 1) asm volatile("s_waitcnt vmcnt(6)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
-    if (n == 2) asm volatile("s_waitcnt vmcnt(5)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
-    if (n == 3) asm volatile("s_waitcnt vmcnt(4)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
-    if (n == 4) asm volatile("s_waitcnt vmcnt(3)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
-    if (n == 5) asm volatile("s_waitcnt vmcnt(2)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
-    if (n == 6) asm volatile("s_waitcnt vmcnt(1)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
-    if (n == 7) asm volatile("s_waitcnt vmcnt(0)\n\tds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
-#endif
-  };
-  auto stage_flush = [&]() {
-#if defined(USP_F64_PROBE) && USP_F64_PROBE == 2
-#pragma unroll
-    for (int n = 0; n < 8; ++n) {
-      const int dst = n < 4 ? dma_kbuf * KBYTES + n * 1024 : VOFF + dma_vbuf * KBYTES + (n - 4) * 1024;
-      asm volatile("ds_write_b128 %0, %1" : : "v"(stg_lane + dst), "a"(stg[n]) : "memory");
-    }
-#endif
+    if (n < 4) lds_dma16_asm(k_rs, lds_w + dma_kbuf * KBYTES, k_voff ^ (64 * n), n * k_step, n);
+    else lds_dma16_asm(v_rs, lds_w + VOFF + dma_vbuf * KBYTES, v_voff, (n - 4) * v_step, n - 4);
   };
   auto dma_all = [&](int kbuf, int vbuf) {                  // next K tile -> Kbuf[kbuf], next V tile -> Vbuf[vbuf]
     dma_open(kbuf, vbuf);
@@ -330,19 +272,18 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   float m_run[2] = {USP_NEG_INF, USP_NEG_INF};   // running row max, raw score units
   float l_run[2] = {0.f, 0.f};                   // this lane's share of the row sum
 
-  // ---- unpipelined building blocks (prologue, masked / ragged tiles) -------------------------------------------------
+  // ---- building blocks outside the pipeline (the first tile of an item; the mask of a diagonal / ragged tile) ----------
   // S^T = K Q^T for the K tile in Kbuf[kbuf]
   auto qk = [&](int kbuf, f32x16 (&s)[2][2]) {
-    USP_LDS const char* kb = smem + kbuf * KBYTES + k_rd;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      const int slot = ((2 * kt) ^ k_rd_x) * 16;
-      const u32x4 k0 = *(USP_LDS const u32x4*)(kb + slot);
-      const u32x4 k1 = *(USP_LDS const u32x4*)(kb + 32 * ROWB + slot);
+      USP_LDS const char* kp = smem + kbuf * KBYTES + (k_rd ^ (32 * kt));
+      const u32x4 k0 = *(USP_LDS const u32x4*)kp;
+      const u32x4 k1 = *(USP_LDS const u32x4*)(kp + 32 * ROWB);
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb) {
-        if (kt == 0) { M::s_first(s[qb][0], k0, qf[qb][0]); M::s_first(s[qb][1], k1, qf[qb][0]); }
-        else { M::s_next(s[qb][0], k0, qf[qb][kt]); M::s_next(s[qb][1], k1, qf[qb][kt]); }
+        if (kt == 0) { M::template s_first<true>(s[qb][0], k0, qf[qb][0]); M::template s_first<true>(s[qb][1], k1, qf[qb][0]); }
+        else { M::template s_next<true>(s[qb][0], k0, qf[qb][kt]); M::template s_next<true>(s[qb][1], k1, qf[qb][kt]); }
       }
     }
     mfma_settle(s);
@@ -362,71 +303,6 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
       }
     }
   };
-  // online softmax of one 64-key tile; rescales o (only if some row's max moved), returns P packed for the PV MFMAs
-  auto softmax = [&](f32x16 (&s)[2][2], u32x4 (&pf)[2][4]) {
-    float alpha[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      float mt = s[qb][0][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s[qb][0][r]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s[qb][1][r]);
-      mt = xhalf_max(mt);
-      const float m_new = fmaxf(m_run[qb], mt);
-      const float m_use = (m_new == USP_NEG_INF) ? 0.f : m_new;
-      const float mc = m_use * c;
-      alpha[qb] = (m_new == m_run[qb]) ? 1.f : fast_exp2(m_run[qb] * c - mc);
-      m_run[qb] = m_new;
-      float rs = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s[qb][0][r] = fast_exp2(__builtin_fmaf(s[qb][0][r], c, -mc));
-        s[qb][1][r] = fast_exp2(__builtin_fmaf(s[qb][1][r], c, -mc));
-        rs += s[qb][0][r] + s[qb][1][r];
-      }
-      l_run[qb] = l_run[qb] * alpha[qb] + rs;
-      // P (B operand of V^T P^T): k-step ks = 2*kb + (r>>3), element e = r & 7
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        pf[qb][0][j] = E::pack2(s[qb][0][2 * j], s[qb][0][2 * j + 1]);
-        pf[qb][1][j] = E::pack2(s[qb][0][8 + 2 * j], s[qb][0][8 + 2 * j + 1]);
-        pf[qb][2][j] = E::pack2(s[qb][1][2 * j], s[qb][1][2 * j + 1]);
-        pf[qb][3][j] = E::pack2(s[qb][1][8 + 2 * j], s[qb][1][8 + 2 * j + 1]);
-      }
-    }
-    if (!__all(alpha[0] == 1.f && alpha[1] == 1.f)) {        // the accumulators live in AGPRs: 3 VALU per element
-      mfma_settle(o);
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int dj = 0; dj < NDJ; ++dj)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o[qb][dj][r] *= alpha[qb];
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int dj = 0; dj < NDJ; ++dj) pin_agpr(o[qb][dj]);
-    }
-  };
-  // O^T += V^T P^T for the V tile in Vbuf[vbuf]
-  auto pv = [&](int vbuf, const u32x4 (&pf)[2][4]) {
-    USP_LDS const char* vb = smem + vbuf * KBYTES + v_rd;
-    operand_settle();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-      for (int dj = 0; dj < NDJ; ++dj) {
-        USP_LDS const char* vp = vb + (4 * ks * NDJ + dj) * 256;
-        const u32x2 v0 = lds_read_tr16(vp);
-        const u32x2 v1 = lds_read_tr16(vp + 2 * NDJ * 256);
-        const u32x4 va = {v0[0], v0[1], v1[0], v1[1]};
-        M::o_acc(o[0][dj], va, pf[0][ks]);
-        M::o_acc(o[1][dj], va, pf[1][ks]);
-      }
-    }
-  };
-
   // ---- prologue: K(0), V(0), K(1) resident; S(0) computed -------------------------------------------------------------
   f32x16 sa[2][2], sb[2][2];      // S^T [query block][key block] of the current / the next tile (ping-pong)
 #pragma unroll
@@ -436,36 +312,39 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
 #pragma unroll
       for (int r = 0; r < 16; ++r) { sa[qb][kb][r] = 0.f; sb[qb][kb][r] = 0.f; }
   dma_all(0, 0);                                 // K(0), V(0)
-#if defined(USP_F64_PROBE) && USP_F64_PROBE == 2
-  dma_drain(); stage_flush();
-#endif
   dma_open_k(1);                                 // K(1)
 #pragma unroll
   for (int n = 0; n < 4; ++n) dma_piece(n);
   dma_drain();
-  stage_flush();
   __syncthreads();
   if (nt > 0 && wave_kv_end > 0) qk(0, sa);
   // K(0) must have been read by EVERY wave before the first loop iteration refills Kbuf[0] with K(2)
   __syncthreads();
 
-  // ---- main loop over unmasked tiles: hand-pinned software pipeline, 64 MFMA slots per tile -------------------------
-  //   phase A (32 slots): S(j+1) = K(j+1) Q^T, k-step major, 4 accumulators in turn (no dependent neighbours); every
-  //            K fragment serves two MFMAs; beside them NEA of the 64 exp2 / row-sum / pack elements of tile j;
-  //   phase B (32 slots): O^T += V(j)^T P(j)^T, 8 accumulators in turn, every V fragment serves two MFMAs; the first
-  //            64 - NEA slots finish tile j's elements (k-step 3 of P is first needed by slot 24), slots from MAX0 on
-  //            carry the row-max chain of S(j+1) (v_max3), the last one the defer-max decision.
+  // ---- the tile loop: hand-pinned software pipeline, 64 MFMA slots per tile ------------------------------------------
+  // Iteration jj works on TWO tiles: softmax + PV of tile jj, whose raw scores S(jj) it receives, and the scores of tile
+  // jj + 1, which it hands on.
+  //   phase A (32 slots): S(jj+1) = K(jj+1) Q^T, k-step major, 4 accumulators in turn (no dependent neighbours); every
+  //            K fragment serves two MFMAs; beside them NEA of the 64 exp2 / row-sum / pack elements of tile jj;
+  //   phase B (32 slots): O^T += V(jj)^T P(jj)^T, 8 accumulators in turn, every V fragment serves two MFMAs; the first
+  //            64 - NEA slots finish tile jj's elements (k-step 3 of P is first needed by slot 24), slots from MAX0 on
+  //            carry the row-max chain of S(jj+1) (v_max3), the last one the defer-max decision;
+  //   the 8 LDS-DMA pieces of K(jj+2) / V(jj+1) go out one behind every DMAS-th MFMA from slot DMA0 on.
   //   Defer-max: O and l are rescaled only when some row's max grew by more than 2^kThr (wave-uniform, rare);
   //   otherwise the old reference max is kept (P <= 2^kThr).
   // sched_barrier(0) pins the slots; the asm MFMAs keep their program order among themselves.
+  // MODE 0 is the steady state.  MODE 1: tile jj+1 needs the causal / ragged mask -- applied to S(jj+1) between the
+  // phases, in front of its row-max chain (a wave meets one or two such tiles per item: the diagonal).  MODE 2: there is
+  // no tile jj+1 for this wave -- phase A carries only the element work.  So every tile a wave needs runs through the
+  // pipelined code; with the diagonal on an unpipelined path the four waves of a workgroup, which share the per-tile
+  // barrier, spent the last four iterations of every item at that path's pace (causal C2: 54 % MFMA-pipe occupancy
+  // against 62 % for the unmasked launch, profiles/r04a_pmc_fwd_*.txt).
   constexpr float kThr = 8.f;
   constexpr int NA = 32, NB = 32;
   constexpr int NEA = USP_F64_NEA, LEAD = USP_F64_LEAD, PFK = USP_F64_PFK, PFV = USP_F64_PFV, MAX0 = USP_F64_MAX0;
-  static_assert(NEA >= 42 - 0 || true, "");
+  constexpr int DMA0 = USP_F64_DMA0, DMAS = USP_F64_DMAS;
   static_assert(64 - NEA <= 22, "k-step 3 of P must be complete two slots before slot 24 of phase B");
-  static_assert(MAX0 >= 1 && MAX0 < NB, "");
-  int j = 0;
-  const int n_main = n_full < nt - 1 ? n_full : nt - 1;    // j + 1 < nt holds inside: no branches
+  static_assert(MAX0 >= 1 && MAX0 < NB && DMAS >= 1 && DMA0 + 7 * DMAS < NA + NB, "");
   const float thr_raw = kThr / c;
   float m_thr[2] = {USP_NEG_INF, USP_NEG_INF};   // m_run + kThr / c: a tile whose scores stay below keeps the reference
   float nmc[2] = {0.f, 0.f};                     // -(reference max * c), 0 while the reference is still -inf
@@ -476,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
     for (int qb = 0; qb < 2; ++qb) {
       const float m_new = fmaxf(m_run[qb], xhalf_max(mt_lane[qb]));
       const float m_use = (m_new == USP_NEG_INF) ? 0.f : m_new;
-      const float alpha = fast_exp2(m_run[qb] * c - m_use * c);
+      const float alpha = (m_new == m_run[qb]) ? 1.f : fast_exp2(m_run[qb] * c - m_use * c);
       m_run[qb] = m_new;
       m_thr[qb] = m_new + thr_raw;
       nmc[qb] = -(m_use * c);
@@ -492,56 +371,47 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
       for (int dj = 0; dj < NDJ; ++dj) pin_agpr(o[qb][dj]);
     operand_settle();                                       // v_accvgpr_write -> MFMA SrcC
   };
-  // one pipelined iteration: softmax + PV of tile jj (scores in cs), scores of tile jj+1 into ns
-  // (PAR = jj & 1 as a compile-time constant: every LDS offset of the iteration is an immediate)
-  auto iter = [&](auto par_c, f32x16 (&cs)[2][2], f32x16 (&ns)[2][2]) {
-    constexpr int PAR = decltype(par_c)::value;
-    // K(jj+2) -> Kbuf[jj&1], which held K(jj), and V(jj+1) -> Vbuf[(jj+1)&1], which held V(jj-1): both last read in the
-    // previous iteration.  The eight pieces go out in front of the first MFMA (DMAS == 0) or one behind every DMAS-th MFMA.
-    constexpr int DMA0 = USP_F64_DMA0, DMAS = USP_F64_DMAS;
-#ifdef USP_F64_ABL_NODMA
-    dma_skip = true;
-#endif
-    dma_open(PAR, PAR ^ 1);
-    if (DMAS == 0) {
+  // row max of a complete score tile + the defer-max decision (outside the pipeline: the first tile of an item)
+  auto decide = [&](f32x16 (&s)[2][2]) {
+    float mt[2];
 #pragma unroll
-      for (int n = 0; n < 8; ++n) dma_piece(n);
+    for (int qb = 0; qb < 2; ++qb) {
+      mt[qb] = s[qb][0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mt[qb] = fmaxf(mt[qb], s[qb][0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mt[qb] = fmaxf(mt[qb], s[qb][1][r]);
     }
+    if (!__all(mt[0] <= m_thr[0] && mt[1] <= m_thr[1])) rescale(mt);
+  };
+  // PARV = jj & 1 as a compile-time constant (0 / 1: every LDS offset of the iteration is an immediate) or 2: taken from `jpar`
+  auto iter = [&](auto par_c, auto mode_c, int jpar, int kt0_next, f32x16 (&cs)[2][2], f32x16 (&ns)[2][2])
+      __attribute__((always_inline)) {
+    constexpr int PARV = decltype(par_c)::value, MODE = decltype(mode_c)::value;
+    const int par = PARV < 2 ? PARV : jpar;
+    // K(jj+2) -> Kbuf[jj&1], which held K(jj), and V(jj+1) -> Vbuf[(jj+1)&1], which held V(jj-1): both last read in the
+    // previous iteration
+    dma_open(par, par ^ 1);
     auto dma_slot = [&](int g) {                              // g = slot index over both phases
-      constexpr int DS = DMAS > 0 ? DMAS : 1, DMAW = USP_F64_DMAW;
-      if (DMAS > 0 && DMAW == 0) {
-        if (g >= DMA0 && (g - DMA0) % DS == 0 && (g - DMA0) / DS < 8) dma_piece((g - DMA0) / DS);
-      } else if (DMAS > 0) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const int t = g - DMA0 - DMAW * w;
-          if (t >= 0 && t % DS == 0 && t / DS < 8) { if (wave == w) dma_piece(t / DS); }
-        }
-      }
+      if (g >= DMA0 && (g - DMA0) % DMAS == 0 && (g - DMA0) / DMAS < 8) dma_piece((g - DMA0) / DMAS);
     };
-    USP_LDS const char* kb = smem + (PAR ^ 1) * KBYTES + k_rd;
-    USP_LDS const char* vb = smem + PAR * KBYTES + v_rd;
+    USP_LDS const char* kb = smem + (par ^ 1) * KBYTES;
+    USP_LDS const char* vb = smem + par * KBYTES + v_rd;
+    int kr = k_rd;
+    asm volatile("" : "+v"(kr));     // opaque per iteration: hipcc otherwise hoists the eight k_rd ^ 32t out of the loop and spills them
     u32x4 ka[2 * NKT];                                      // fragment f = 2*kt + key block
     auto rd_k = [&](int f) {
-#ifdef USP_F64_ABL_NOLDS      // dev A/B build: fragments from registers
-      ka[f] = u32x4{(uint32_t)lane, (uint32_t)f, (uint32_t)hi, 0x3f803f80u}; (void)kb;
-#else
-      ka[f] = *(USP_LDS const u32x4*)(kb + (f & 1) * 32 * ROWB + (((2 * (f >> 1)) ^ k_rd_x) * 16));
-#endif
+      ka[f] = *(USP_LDS const u32x4*)(kb + (f & 1) * 32 * ROWB + (kr ^ (32 * (f >> 1))));
     };
     u32x4 va[4 * NDJ];                                      // fragment f = NDJ*ks + dj
-    float rs[2] = {0.f, 0.f};
-    u32x4 pf[2][4];
     auto rd_v = [&](int f) {
-#ifdef USP_F64_ABL_NOLDS
-      va[f] = u32x4{(uint32_t)lane, (uint32_t)f, (uint32_t)hi, 0x3f803f80u}; (void)vb;
-#else
       USP_LDS const char* vp = vb + (4 * (f / NDJ) * NDJ + (f % NDJ)) * 256;
       const u32x2 v0 = lds_read_tr16(vp);
       const u32x2 v1 = lds_read_tr16(vp + 2 * NDJ * 256);
       va[f] = u32x4{v0[0], v0[1], v1[0], v1[1]};
-#endif
     };
+    float rs[2] = {0.f, 0.f};
+    u32x4 pf[2][4];
     // element e of the tile's 64 scores per lane, in the order the PV k-steps need them:
     //   e = 16*ks + 8*qb + r8  ->  cs[qb][ks >> 1][8*(ks & 1) + r8]
     // The consumers of an exp2 result run ONE ELEMENT LATE (row-sum add of e-1, pack of the pair (e-2, e-1)).
@@ -551,16 +421,14 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
       if (e & 1) pf[(e >> 3) & 1][e >> 4][(e & 7) >> 1] = E::pack2(get(e - 1), get(e));
     };
     auto exp_elem = [&](int e) {
-#ifdef USP_F64_ABL_NOEXP      // dev A/B build: no element work at all (P = raw bits of every other score)
-      if (e & 1) pf[(e >> 3) & 1][e >> 4][(e & 7) >> 1] = __builtin_bit_cast(uint32_t, get(e));
-      return;
-#endif
       cs[(e >> 3) & 1][e >> 5][8 * ((e >> 4) & 1) + (e & 7)] = fast_exp2(__builtin_fmaf(get(e), c, nmc[(e >> 3) & 1]));
       if (e > 0) consume(e - 1);
       if (e == 63) consume(63);
     };
+    if (MODE != 2) {
 #pragma unroll
-    for (int f = 0; f < PFK; ++f) rd_k(f);
+      for (int f = 0; f < PFK; ++f) rd_k(f);
+    }
 #pragma unroll
     for (int e = 0; e < LEAD; ++e) exp_elem(e);
     __builtin_amdgcn_sched_barrier(0);
@@ -568,9 +436,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
 #pragma unroll
     for (int sl = 0; sl < NA; ++sl) {
       const int f = sl >> 1, kt = f >> 1, kbk = f & 1, qb = sl & 1;
-      if (qb == 0 && f + PFK < 2 * NKT) rd_k(f + PFK);
-      if (kt == 0) M::s_first(ns[qb][kbk], ka[f], qf[qb][0]);
-      else M::s_next(ns[qb][kbk], ka[f], qf[qb][kt]);
+      if (MODE != 2) {
+        if (qb == 0 && f + PFK < 2 * NKT) rd_k(f + PFK);
+        if (kt == 0) M::template s_first<MODE != 0>(ns[qb][kbk], ka[f], qf[qb][0]);
+        else M::template s_next<MODE != 0>(ns[qb][kbk], ka[f], qf[qb][kt]);
+      }
 #pragma unroll
       for (int e = LEAD + sl * (NEA - LEAD) / NA; e < LEAD + (sl + 1) * (NEA - LEAD) / NA; ++e) exp_elem(e);
       // the V fragments of phase B's first MFMAs are read behind phase A's last ones (V(jj) has been resident since
@@ -578,6 +448,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
       if (sl >= NA - 2 * PFV && ((sl - (NA - 2 * PFV)) & 1) == 0) rd_v((sl - (NA - 2 * PFV)) >> 1);
       dma_slot(sl);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (MODE == 1) {                 // the diagonal / the ragged last tile: mask S(jj+1) before anything looks at it
+      mfma_settle(ns);
+      mask(kt0_next, ns);
     }
     // ---------------- phase B ----------------
     float mt[2] = {USP_NEG_INF, USP_NEG_INF};
@@ -587,81 +461,54 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
     for (int i = 0; i < NB; ++i) {
       const int f = i >> 1, qb = i & 1;
       if (qb == 0 && f + PFV < 4 * NDJ) rd_v(f + PFV);
-      M::o_acc(o[qb][f % NDJ], va[f], pf[qb][f / NDJ]);
+      M::template o_acc<MODE != 0>(o[qb][f % NDJ], va[f], pf[qb][f / NDJ]);
       if (NEA + i < 64) exp_elem(NEA + i);
       if (i == 64 - NEA - 1 || (NEA == 64 && i == 0)) { l_run[0] += rs[0]; l_run[1] += rs[1]; }
-      if (i >= MAX0) {
+      if (MODE != 2 && i >= MAX0) {
 #pragma unroll
         for (int x = (i - MAX0) * 64 / NMAX; x < (i - MAX0 + 1) * 64 / NMAX; ++x)      // value x: qb = x >> 5
           mt[x >> 5] = fmaxf(mt[x >> 5], ns[x >> 5][(x >> 4) & 1][x & 15]);
         if (i == NB - 1) keep = __all(mt[0] <= m_thr[0] && mt[1] <= m_thr[1]);       // behind the last MFMA, not after it
       }
       dma_slot(NA + i);
-      if (USP_F64_STG_WS > 0 && NA + i >= USP_F64_STG_W0 && (NA + i - USP_F64_STG_W0) % (USP_F64_STG_WS > 0 ? USP_F64_STG_WS : 1) == 0 &&
-          (NA + i - USP_F64_STG_W0) / (USP_F64_STG_WS > 0 ? USP_F64_STG_WS : 1) < 8)
-        stage_write((NA + i - USP_F64_STG_W0) / (USP_F64_STG_WS > 0 ? USP_F64_STG_WS : 1));
       __builtin_amdgcn_sched_barrier(0);
     }
     if (!keep) rescale(mt);
-#ifndef USP_F64_ABL_NOBAR
     dma_drain();                 // this wave's pieces of K(jj+2), V(jj+1) have landed ...
-    if (USP_F64_STG_WS == 0) stage_flush();
-#if defined(USP_F64_PROBE) && USP_F64_PROBE == 2
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (staged ds_writes issued from asm are invisible to hipcc's barrier wait)
-#endif
     __syncthreads();             // ... and so have everybody else's
-#endif
   };
 
-  if (n_main > 0) {
-    float mt[2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
-      mt[qb] = sa[qb][0][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mt[qb] = fmaxf(mt[qb], sa[qb][0][r]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mt[qb] = fmaxf(mt[qb], sa[qb][1][r]);
+  // this wave's tiles: [0, n_w); [0, n_full) need no mask.  Iteration jj is plain while jj + 1 < n_full.
+  const int n_w = wave_kv_end > 0 ? (wave_kv_end + kBN - 1) / kBN : 0;
+  if (n_full > n_w) n_full = n_w;
+  int j = 0;
+  if (n_w > 0) {
+    if (n_full == 0) mask(0, sa);
+    decide(sa);
+    const std::integral_constant<int, 0> c0;
+    const std::integral_constant<int, 1> c1;
+    const std::integral_constant<int, 2> c2;
+    const int n_hot = n_full - 1;                            // iterations [0, n_hot) are plain
+    for (; j + 1 < n_hot; j += 2) {
+      iter(c0, c0, 0, 0, sa, sb);
+      iter(c1, c0, 1, 0, sb, sa);
     }
-    if (!__all(mt[0] <= m_thr[0] && mt[1] <= m_thr[1])) rescale(mt);
-    const std::integral_constant<int, 0> even;
-    const std::integral_constant<int, 1> odd;
-    for (; j + 1 < n_main; j += 2) {
-      iter(even, sa, sb);
-      iter(odd, sb, sa);
-    }
-    if (j < n_main) {
-      iter(even, sa, sb);
+    auto adopt = [&]() {                                     // the scores handed on become the current ones
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) sa[qb][kb] = sb[qb][kb];
-      ++j;
+    };
+    if (j < n_hot) { iter(c0, c0, 0, 0, sa, sb); adopt(); ++j; }
+    for (; j < n_w; ++j) {                                   // the diagonal (MODE 1) and this wave's last tile (MODE 2)
+      if (j + 1 >= n_w) iter(c2, c2, j & 1, 0, sa, sb);
+      else { iter(c2, c1, j & 1, (j + 1) * kBN, sa, sb); adopt(); }
     }
-    mfma_settle(sa);             // the chain of the last iteration may end less than 12 states before its first reader
   }
-  // ---- generic tail: masked and/or inactive tiles ------------------------------------------------------------------
-  dma_skip = false;
+  // ---- the tiles other waves of the workgroup still work on: keep the K/V stream and the barrier cadence -------------
   for (; j < nt; ++j) {
-    const int kt0 = j * kBN;
-    dma_all(j & 1, (j + 1) & 1);  // K(j+2), V(j+1): unconditionally, the cursors count tiles
-    const bool next_active = j + 1 < nt && kt0 + kBN < wave_kv_end;
-    if (next_active) qk((j + 1) & 1, sb);
-    if (kt0 < wave_kv_end) {
-      const bool need_mask = (kt0 + kBN > p->Sk) || (CAUSAL && kt0 + kBN - 1 > qw + off);
-      if (need_mask) mask(kt0, sa);
-      u32x4 pf[2][4];
-      softmax(sa, pf);
-      pv(j & 1, pf);
-    }
-    if (next_active) {
-#pragma unroll
-      for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) sa[qb][kb] = sb[qb][kb];
-    }
+    dma_all(j & 1, (j + 1) & 1);
     dma_drain();
-    stage_flush();
     __syncthreads();
   }
 
