@@ -1,0 +1,476 @@
+// Blockwise flash-attention backward for gfx950, dK/dV launch, ONE WAVE PER SIMD.  C ABI: usp_flash_bwd (include/usp_hip.h);
+// replaces -- together with the dQ launch of usp_flash_bwd.hip -- the reference's `bwd-only` block kernel
+// (yunchang/kernels/attention.py:205-250).
+//
+// The 8-wave dK/dV kernel of usp_flash_bwd.hip pairs two 32-key waves per SIMD (role A: S, P, dV; role B: dP, dS, dK) and
+// is bound by the LDS fragment reads every MFMA drags along (1.5 per MFMA and wave: -13 % without them,
+// profiles/r03_bwd_ablations.txt).  Here a wave owns 64 keys and its SIMD's whole register file:
+//   workgroup = 4 waves = 128 keys of one (batch, kv head[, query head]); waves 0,1: role A for key slices 0,1 (64 keys
+//   each), waves 2,3: role B for the same slices, one tile behind A (P reaches B through LDS, ordered by the per-tile
+//   barrier that exists anyway);
+//   a[0:127]   dV^T (A) / dK^T (B) accumulators, 2 key blocks x 4 dim tiles       (asm MFMAs, "+a")
+//   a[128:191] K (A) / V (B) fragments of the wave's 64 keys: B operand of the S / dP chains, never copied
+//   v[...]     S / dP of the two 32-row halves of the streamed tile x 2 key blocks (64), packed P / dS (32), fragments
+// so that every Q / dO fragment read from LDS serves TWO MFMAs (0.75 reads per MFMA) and the element work is 2.5 VALU per
+// MFMA.  A tile is 64 MFMA slots per wave:  chain(h0) | chain(h1) | grad(h0) | grad(h1)  (16 each); the 64 elements
+// (P = exp2(S c - lse) for A, dS = P (dP - delta) for B, + the 16-bit packs) stream through slots 16 .. 53 in the order the
+// gradient MFMAs need them, the tile's 8 LDS-DMA pieces (Q / dO tile two iterations ahead of B) through slots 0 .. 15.
+// MFMAs are inline asm (see usp_mfma64.hpp for why and for the hazards hipcc cannot see); tools/mfma_hazards.py checks
+// the emitted stream.
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "usp_bwd_params.hpp"
+#include "usp_common.hpp"
+#include "usp_hip.h"
+#include "usp_mfma64.hpp"
+
+namespace usp {
+
+#ifndef USP_B64_E0       // first and one-past-last slot of the element stream (64 elements; chain(h0) ends at 16, the
+#define USP_B64_E0 16    // gradient MFMAs of k-step (h, k2) start at 32 + 16 h + 8 k2)
+#endif
+#ifndef USP_B64_E1
+#define USP_B64_E1 54
+#endif
+
+template <int DT, bool CAUSAL>
+__global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParams /* read through the kernarg segment */) {
+  using E = Elem<DT>;
+  using M = M64<DT>;
+  constexpr int D = 128, OWN = 128;
+  constexpr int ROWB = D * 2;
+  constexpr int TILEB = kTile * ROWB;            // one streamed matrix tile (64 rows)
+  constexpr int STATB = 2 * kTile * 4;           // lse2 + (-delta) of the tile's rows
+  constexpr int BUFB = 2 * TILEB + STATB;
+  constexpr int NBUF = 3;
+  constexpr int PSLOT = 8192;                    // P of one 64 x 64 block, 16-bit
+  constexpr int POFF = NBUF * BUFB;              // P exchange: [2 slices][2 slots][PSLOT]
+  constexpr int NKT = D / 16, NDJ = D / 32;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  USP_LDS char* smem = (USP_LDS char*)smem_raw;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 1;                    // 0: A (S, P, dV)   1: B (dP, dS, dK)
+  const int slice = wave & 1;
+  const int l31 = lane & 31;
+  const int hi = lane >> 5;
+  // the argument block stays in the kernarg segment (see usp_flash_fwd64.hip: held in SGPRs it fills the scalar file)
+  typedef const __attribute__((address_space(4))) BwdParams* KArgs;
+  KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(p));
+
+  // ---- lane-constant addresses ----------------------------------------------------------------------------------------
+  // LDS-DMA: this wave fills the contiguous chunks 4*wave .. 4*wave + 3 (rows 16*wave + 4i .. +3) of the Q tile and of the
+  // dO tile; one M0 write per matrix, the pieces by immediate offset (usp_mfma64.hpp).  The slot swizzle of row
+  // 16w + 4i + l/16 is ((l/16) << 2) | i: piece i's per-lane offset is piece 0's with 16*i XORed in.
+  const int dma_row = 16 * wave + (lane >> 4);
+  const int dma_c8 = ((lane & 15) ^ ((lane >> 4) << 2)) * 16;
+  const int q_voff = dma_row * (int)p->q_ss * 2 + dma_c8, do_voff = dma_row * (int)p->do_ss * 2 + dma_c8;
+  // row read (A operand of the S / dP chain): tile row 32h + l31, logical slot 2t + hi; the swizzle does not depend on h
+  const int rd_base = l31 * ROWB + ((hi ^ tile_swz<D>(l31)) * 16);            // ^ (32 t), + h * 32 * ROWB
+  // transpose read (A operand of the gradient MFMAs) for dim tile dj, element half e, k-step ks: the 16-lane group reads
+  // the [4 rows][16 dims] block rows 16ks + 8e + 4hi + (0..3), dims 32dj + 16*grp + (0..15); lane i supplies row i>>2,
+  // dims 4*(i&3)..+3
+  int tr_addr[NDJ][2];
+  {
+    const int i = lane & 15, grp = (lane >> 4) & 1;
+#pragma unroll
+    for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int rr = 8 * e + 4 * hi + (i >> 2);
+        const int slot = 4 * dj + 2 * grp + ((i & 3) >> 1);
+        tr_addr[dj][e] = rr * ROWB + ((slot ^ tile_swz<D>(rr)) * 16) + (i & 1) * 8;
+      }
+  }
+  USP_LDS char* pex = smem + POFF + slice * 2 * PSLOT + lane * 16;   // + slot*PSLOT + ((2h + kb)*2 + k2)*1024
+
+  const ItemWalk walk(p->n_items);               // persistent workgroups (usp_common.hpp)
+  for (int pass = 0;; ++pass) {
+  int w = walk.at(pass);
+  if (w < 0) break;
+  asm volatile("" : "+s"(p));
+  w = walk.dealt(w, p->nblk);
+  const int blk = w % p->nblk;                   // early key blocks are seen by most rows: first
+  int rest = w / p->nblk;
+  int g = 0, cut = 0;
+  if (p->qsplit > 1) { cut = rest % p->qsplit; rest /= p->qsplit; }
+  if (p->split && p->G > 1) { g = rest % p->G; rest /= p->G; }
+  const int hkv = rest % p->Hkv, b = rest / p->Hkv;
+  const int h0 = hkv * p->G + g;
+  const int own0 = blk * OWN;
+  const int off = p->causal_off;
+  const int ow = own0 + slice * 64;              // first key of this wave
+
+  // K (role A) or V (role B) fragments of this wave's 64 keys, loaded straight into the accumulator file.  The loads are
+  // issued from asm and waited for here: with loads hipcc can see, it still counts them as pending at the headers of the
+  // streaming loops and puts a cascade of s_waitcnt vmcnt(20 .. 0) in front of the fragments' first use in EVERY iteration
+  // -- its vmcnt(0) then waits for the statistics wave's fresh loads, a memory round trip per tile.
+  u32x4 rf[2][NKT];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int orow = ow + 32 * kb + l31;
+    const int orow_c = orow < p->Sk ? orow : p->Sk - 1;
+    const char* pr = (role == 0 ? p->k + 2 * (b * p->k_sb + (int64_t)orow_c * p->k_ss + hkv * p->k_sh)
+                                : p->v + 2 * (b * p->v_sb + (int64_t)orow_c * p->v_ss + hkv * p->v_sh)) + 16 * hi;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:32\n\t"
+                 "global_load_dwordx4 %2, %8, off offset:64\n\tglobal_load_dwordx4 %3, %8, off offset:96\n\t"
+                 "global_load_dwordx4 %4, %8, off offset:128\n\tglobal_load_dwordx4 %5, %8, off offset:160\n\t"
+                 "global_load_dwordx4 %6, %8, off offset:192\n\tglobal_load_dwordx4 %7, %8, off offset:224\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&a"(rf[kb][0]), "=&a"(rf[kb][1]), "=&a"(rf[kb][2]), "=&a"(rf[kb][3]), "=&a"(rf[kb][4]), "=&a"(rf[kb][5]),
+                   "=&a"(rf[kb][6]), "=&a"(rf[kb][7])
+                 : "v"(pr) : "memory");
+#endif
+  }
+
+  int t_begin = 0, t_end = (p->Sq + kTile - 1) / kTile;
+  if (CAUSAL) {
+    const int first_q = own0 - off > 0 ? own0 - off : 0;
+    t_begin = first_q / kTile;
+    if (t_begin > t_end) t_begin = t_end;
+  }
+  if (p->qsplit > 1) {                           // this item's cut of the query tiles [t_begin, t_end): equal runs
+    const int per = (t_end - t_begin + p->qsplit - 1) / p->qsplit;
+    t_begin = t_begin + cut * per < t_end ? t_begin + cut * per : t_end;
+    t_end = t_begin + per < t_end ? t_begin + per : t_end;
+  }
+  const int n_iter = t_end - t_begin;             // (one query head per item: launch_dkdv64 leaves the in-workgroup loop
+                                                  // over a GQA group's heads to the 8-wave kernel)
+
+  // ---- LDS-DMA staging of the Q / dO tiles: running cursors (base pointer + remaining bytes, advanced per tile) -------
+  const int tb1 = kTile * (int)p->q_ss * 2, tb2 = kTile * (int)p->do_ss * 2;     // bytes per tile step
+  int q_step = 4 * (int)p->q_ss * 2 - 1024, do_step = 4 * (int)p->do_ss * 2 - 1024;
+  int lds_w = wave * 4096;
+  const char *q_cur = nullptr, *do_cur = nullptr;
+  int q_rem = 0, do_rem = 0;
+  const float *lse_h = nullptr, *dl_h = nullptr;                               // row statistics of the item's head
+  int st_row = 0;                                                             // first row of the cursor's tile
+  float st_lse = 0.f, st_delta = 0.f;
+  bool st_in = false;
+  const bool stat_wave = wave == 2;              // a role-B wave stages the tile's statistics: role A is the longer stream
+  {                                              // base the cursors on head h0, tile t_begin
+    const int h = h0;
+    q_cur = p->q + 2 * (b * p->q_sb + h * p->q_sh) + (int64_t)t_begin * tb1;
+    do_cur = p->dout + 2 * (b * p->do_sb + h * p->do_sh) + (int64_t)t_begin * tb2;
+    q_rem = ((p->Sq - 1) * (int)p->q_ss + D) * 2 - t_begin * tb1;
+    do_rem = ((p->Sq - 1) * (int)p->do_ss + D) * 2 - t_begin * tb2;
+    lse_h = p->lse + b * p->lse_sb + h * p->lse_sh;
+    dl_h = p->delta + b * p->dl_sb + h * p->dl_sh;
+    st_row = t_begin * kTile;
+  }
+  u32x4 q_rs, do_rs;
+  int dma_buf = 0;
+  // open the cursor's tile for LDS buffer `buf` (descriptors) and advance the cursor: scalar work only, no branch -- it
+  // runs inside the MFMA stream.  EVERY memory operation of the loop is issued from asm: a load hipcc can see makes it
+  // guard the LDS reads that follow with vmcnt waits, which drain the DMA queue in the middle of the tile.
+  auto dma_open = [&](int buf) {
+    q_rs = make_rsrc(q_cur, q_rem);
+    do_rs = make_rsrc(do_cur, do_rem);
+    dma_buf = buf;
+    q_cur += tb1; q_rem -= tb1;
+    do_cur += tb2; do_rem -= tb2;
+  };
+  // the statistics wave fetches the 2 x 64 row statistics of the cursor's tile (raw, one row per lane) in front of the
+  // stream ...
+  auto stats_fetch = [&]() {
+    if (stat_wave) {
+      const int r = st_row + lane;
+      st_in = r < p->Sq;                         // rows past the end: P = 0 (their Q / dO rows read as zero)
+      const int rc = st_in ? r : p->Sq - 1;
+      const float* pl = lse_h + rc;
+      const float* pd = dl_h + rc;
+      asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off" : "=&v"(st_lse), "=&v"(st_delta) : "v"(pl), "v"(pd) : "memory");
+    }
+    st_row += kTile;
+  };
+  // piece n of the opened tile: n < 4 -> Q piece n, else dO piece n - 4
+  auto dma_piece = [&](int n) {
+    asm volatile("" : "+s"(lds_w), "+s"(q_step), "+s"(do_step));
+    if (n < 4) lds_dma16_asm(q_rs, lds_w + dma_buf * BUFB, q_voff ^ (16 * n), n * q_step, n);
+    else lds_dma16_asm(do_rs, lds_w + dma_buf * BUFB + TILEB, do_voff ^ (16 * (n - 4)), (n - 4) * do_step, n - 4);
+  };
+  // ... and behind the wave's vmcnt(0) at the end of the iteration stores what the roles consume: lse * log2(e) (+inf for
+  // a row without visible keys: P = 0) and -delta (role B folds it into the dP chain as the C operand)
+  auto stats_store = [&](int buf) {
+    if (stat_wave) {
+      asm volatile("" : "+v"(st_lse), "+v"(st_delta));         // (written by the asm loads above, complete behind dma_drain)
+      const float l2 = (st_in && st_lse != USP_NEG_INF) ? st_lse * kLog2e : __builtin_inff();
+      *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * lane) = l2;
+      *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * kTile + 4 * lane) = st_in ? -st_delta : 0.f;
+    }
+  };
+
+  f32x16 acc[2][NDJ];                            // dV^T (role A) / dK^T (role B): [key block][dim tile]
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int dj = 0; dj < NDJ; ++dj) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[kb][dj][r] = 0.f;
+      pin_agpr(acc[kb][dj]);
+    }
+  const float c = p->scale_log2;
+
+  stats_fetch();
+  dma_open(0);
+#pragma unroll
+  for (int n = 0; n < 8; ++n) dma_piece(n);
+  dma_drain();
+  stats_store(0);
+  __syncthreads();
+
+  // The streaming loop is instantiated per role, with ROLE a compile-time constant, and the role is chosen by ONE branch
+  // around the whole loop: both roles execute the same barrier sequence (n_iter + 1 barriers: role B works one tile
+  // behind role A, so A idles in the last iteration and B in the first).  The tile body is STRAIGHT-LINE code: with the
+  // asm MFMAs under an `if (active)` hipcc copies all 128 accumulator registers twice per tile (the "+a" ties meet a phi).
+  // So nothing in the loop is conditional: a tile no row of which sees the wave's keys (the first tile of a causal range,
+  // for the upper key slice) runs like any other, fully masked -- its P is 0 -- and the diagonal tiles, which are the
+  // FIRST n_mask tiles of a causal item, run in a loop instance of their own (MASK) that applies the mask to S.
+  int n_mask = 0;                                  // leading tiles in which some (row, key) pair of this wave is masked
+  if (CAUSAL) {
+    const int lim = ow + 63 - off;                 // tiles with s0 < lim need the mask
+    const int tm = lim > 0 ? (lim + kTile - 1) / kTile : 0;
+    n_mask = tm - t_begin < 0 ? 0 : (tm - t_begin > n_iter ? n_iter : tm - t_begin);
+  }
+  int tile_cur = t_begin, buf_a = 0, buf_b = NBUF - 1;     // role A's tile / LDS buffers of A's and B's tiles
+  // one iteration: [prefetch the next tile] [the tile body of this role] [publish]
+  auto step = [&](auto role_c, auto mask_c, int it, bool work) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_c)::value;
+    constexpr bool MASK = decltype(mask_c)::value;
+    constexpr int E0 = USP_B64_E0, E1 = USP_B64_E1;
+    static_assert(E0 >= 16 && E1 <= 56 && E1 > E0, "");
+    // the next tile is fetched unconditionally (past the range of the item it is a tile nobody reads; past the end of
+    // the tensor its descriptor is empty): no branch around the pieces
+    const int buf_n = buf_a + 1 == NBUF ? 0 : buf_a + 1;      // (it + 1) % NBUF
+    stats_fetch();
+    if (work) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)        // the resident fragments STAY in the accumulator file (hipcc otherwise gives some
+#pragma unroll
+        for (int t = 0; t < NKT; ++t) pin_agpr4(rf[kb][t]);   // of them VGPR homes and copies them in front of every MFMA)
+      const int my_it = it - ROLE;
+      const int buf = ROLE == 0 ? buf_a : buf_b;
+      const int s0 = (ROLE == 0 ? tile_cur : tile_cur - 1) * kTile;
+      USP_LDS const char* x1 = smem + buf * BUFB;              // Q tile
+      USP_LDS const char* x2 = x1 + TILEB;                     // dO tile
+      USP_LDS const char* xs = ROLE == 0 ? x1 : x2;            // row-read operand of the S / dP chain
+      USP_LDS const char* xg = ROLE == 0 ? x2 : x1;            // transpose-read operand of the gradient
+      USP_LDS const char* stat = x1 + 2 * TILEB + (ROLE == 0 ? 0 : 4 * kTile) + 16 * hi;
+      USP_LDS char* pslot = pex + (my_it & 1) * PSLOT;
+      f32x16 sc[2][2];                                         // S (A) / dP - delta (B): [32-row half][key block]
+      u32x4 pk[2][2][2];                                       // packed P (A) / dS (B): [half][key block][k-step]
+      u32x4 pin[2][2][2];                                      // role B: P received from A
+      f32x4 stq[2][4];                                         // row statistics of the two halves (4 rows per entry)
+      int kr = rd_base;
+      asm volatile("" : "+v"(kr));       // opaque per tile: hipcc otherwise hoists the eight kr ^ 32t and keeps them live
+      auto load_stats = [&](int h) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) stq[h][j] = *(USP_LDS const f32x4*)(stat + 128 * h + 32 * j);
+      };
+      // element n of half h, in the order the gradient k-steps need them: n = 16*k2 + 8*kb + r8 -> sc[h][kb][8*k2 + r8]
+      // role A: P = exp2(S*c - lse2); role B: dS = P * (dP - delta) -- the dP chain STARTS from -delta (its C operand)
+      auto elem = [&](int h, int n) {
+        const int k2 = n >> 4, kb = (n >> 3) & 1, r = 8 * k2 + (n & 7);
+        float val;
+        if (ROLE == 0) {
+#ifdef USP_B64_ABL_NOEXP   // dev A/B build: role A without the transcendental
+          val = __builtin_fmaf(sc[h][kb][r], c, -stq[h][r >> 2][r & 3]) * 1e-3f;
+#else
+          val = fast_exp2(__builtin_fmaf(sc[h][kb][r], c, -stq[h][r >> 2][r & 3]));
+#endif
+        } else {
+          const uint32_t wd = pin[h][kb][k2][(r & 7) >> 1];
+          val = ((r & 1) ? E::hi(wd) : E::lo(wd)) * sc[h][kb][r];
+        }
+        sc[h][kb][r] = val;
+        if (r & 1) pk[h][kb][k2][(r & 7) >> 1] = E::pack2(sc[h][kb][r - 1], sc[h][kb][r]);
+#ifndef USP_B64_ABL_NOPX   // dev A/B build: no hand-off (B multiplies with stale P)
+        if (ROLE == 0 && (r & 7) == 7)                          // 8 elements done: hand one k-step of P to B
+          *(USP_LDS u32x4*)(pslot + ((2 * h + kb) * 2 + k2) * 1024) = pk[h][kb][k2];
+#endif
+      };
+      // the element stream of the tile: 64 elements (half 0, then half 1) over slots [E0, E1)
+      auto elem_slot = [&](int sl) {
+        if (sl < E0 || sl >= E1) return;
+#pragma unroll
+        for (int n = (sl - E0) * 64 / (E1 - E0); n < (sl - E0 + 1) * 64 / (E1 - E0); ++n) elem(n >> 5, n & 31);
+      };
+      auto apply_mask = [&](int h) {                            // role A only: query row i sees key j iff j <= i + off
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+          const int d = ow + 32 * kb + l31 - off - s0 - 4 * hi - 32 * h;     // one VGPR; thresholds are inline constants
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (d > (r & 3) + 8 * (r >> 2)) sc[h][kb][r] = USP_NEG_INF;
+        }
+      };
+      // LDS fragments are read ONE PHASE AHEAD of the MFMAs that take them (a lone wave cannot hide an LDS round trip
+      // behind anything: every s_waitcnt that has to wait idles the matrix pipe): the slots of chain(h0) carry the reads
+      // of chain(h1), those of chain(h1) the reads of grad(h0), those of grad(h0) the reads of grad(h1); only chain(h0)'s
+      // own fragments are read in one burst behind the barrier that published the tile.
+      u32x4 fc[2][NKT];                                        // row-read fragments of the two halves' chains
+      u32x4 xa[2][2 * NDJ];                                    // transpose-read fragments of the two halves' gradients
+      auto rd_c = [&](int h, int kt) { fc[h][kt] = *(USP_LDS const u32x4*)(xs + h * 32 * ROWB + (kr ^ (32 * kt))); };
+      auto rd_g = [&](int h, int f) {                          // fragment f = NDJ*k2 + dj
+        USP_LDS const char* xb = xg + (2 * h + f / NDJ) * 16 * ROWB;
+        const u32x2 a0 = lds_read_tr16(xb + tr_addr[f % NDJ][0]);
+        const u32x2 a1 = lds_read_tr16(xb + tr_addr[f % NDJ][1]);
+        xa[h][f] = u32x4{a0[0], a0[1], a1[0], a1[1]};
+      };
+      auto chain_init = [&](int h) {                           // statistics; role B: the chains' C operand and A's P
+        load_stats(h);
+        if (ROLE == 1) {                                        // -delta of this half's rows: the chains' C operand
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[h][kb][r] = stq[h][r >> 2][r & 3];
+#pragma unroll
+          for (int kb = 0; kb < 2; ++kb)                        // fetch A's P of this half early
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) pin[h][kb][k2] = *(USP_LDS const u32x4*)(pslot + ((2 * h + kb) * 2 + k2) * 1024);
+        }
+      };
+      // ---------------- S / dP chains: slots [16h, 16h + 16) ----------------
+      auto chain_phase = [&](int h) {
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) {
+          const int kt = sl >> 1, kb = sl & 1;
+          if (ROLE == 0 && kt == 0) M::template s_first<MASK>(sc[h][kb], fc[h][kt], rf[kb][kt]);
+          else M::template s_next<MASK>(sc[h][kb], fc[h][kt], rf[kb][kt]);
+          if (h == 0 && sl == 0) dma_open(buf_n);       // behind the first MFMA: its scalar work must not idle the matrix pipe
+          if (kb == 0) { if (h == 0) rd_c(1, kt); else rd_g(0, kt); }        // the next phase's fragment kt
+          if (h == 0 && sl == 8) chain_init(1);
+          elem_slot(16 * h + sl);
+          if (h == 0 && (sl & 1) == 1) dma_piece(sl >> 1);                    // the next tile's 8 pieces: slots 1, 3, .. 15
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      // ---------------- gradient MFMAs: slots [32 + 16h, 48 + 16h) ----------------
+      auto grad_phase = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int f = i >> 1, kb = i & 1;
+          M::template o_acc<MASK>(acc[kb][f % NDJ], xa[h][f], pk[h][kb][f / NDJ]);
+          if (h == 0 && kb == 0) rd_g(1, f);                                  // the next phase's fragment f
+          elem_slot(32 + 16 * h + i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      chain_init(0);
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) rd_c(0, kt);
+      __builtin_amdgcn_sched_barrier(0);
+      chain_phase(0);
+      if (MASK) { mfma_settle(sc[0]); apply_mask(0); }
+      chain_phase(1);
+      if (MASK) { mfma_settle(sc[1]); apply_mask(1); }
+      grad_phase(0);
+      grad_phase(1);
+    } else {
+      dma_open(buf_n);
+#pragma unroll
+      for (int n = 0; n < 8; ++n) dma_piece(n);
+    }
+    buf_b = buf_a;
+    buf_a = buf_n;
+    if (ROLE == 0 || it > 0) ++tile_cur;           // (role B enters its first tile one iteration late)
+    dma_drain();            // this wave's DMA pieces of the staged tile have landed
+    stats_store(buf_n);
+    __syncthreads();
+  };
+  const std::integral_constant<int, 0> rA;
+  const std::integral_constant<int, 1> rB;
+  const std::integral_constant<bool, false> plain;
+  const std::integral_constant<bool, true> masked;
+  // (the vmcnt(0) in front of every loop: hipcc reloads spilled registers -- VMEM loads -- on the way here, and what it
+  // still counts as pending at a loop header it waits for at the first use INSIDE the loop, in every iteration; with the
+  // statistics wave's fresh loads in flight that is a memory round trip per tile)
+  if (role == 0) {
+    int it = 0;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    for (; it < n_mask; ++it) step(rA, masked, it, true);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    for (; it < n_iter; ++it) step(rA, plain, it, true);
+    mfma_settle(acc);            // (whatever hipcc does with the accumulators behind the loop, it does behind these wait states)
+    step(rA, plain, n_iter, false);
+  } else {
+    tile_cur = t_begin;
+    step(rB, plain, 0, false);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    for (int it = 1; it <= n_iter; ++it) step(rB, plain, it, true);
+    mfma_settle(acc);
+  }
+
+  // ---- epilogue -----------------------------------------------------------------------------------------------------------
+  mfma_settle(acc);
+  asm volatile("" : "+s"(p));
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb) {
+    const int orow = ow + 32 * kb + l31;
+    if (orow < p->Sk) {
+      float* o32;
+      char* o16 = nullptr;
+      int accf;
+      const float mul = role == 0 ? 1.f : p->scale;
+      if (p->split) {
+        const int64_t wo = (((int64_t)(g * p->qsplit + cut) * p->ws_rows + (int64_t)b * p->Sk + orow) * p->Hkv + hkv) * D;
+        o32 = (role == 0 ? p->ws_dv : p->ws_dk) + wo; accf = 0;
+      } else if (role == 0) {
+        o32 = p->dv + b * p->dv_sb + (int64_t)orow * p->dv_ss + hkv * p->dv_sh; accf = p->accum_dv;
+        if (p->dv16) o16 = p->dv16 + 2 * (b * p->dv16_sb + (int64_t)orow * p->dv16_ss + hkv * p->dv16_sh);
+      } else {
+        o32 = p->dk + b * p->dk_sb + (int64_t)orow * p->dk_ss + hkv * p->dk_sh; accf = p->accum_dk;
+        if (p->dk16) o16 = p->dk16 + 2 * (b * p->dk16_sb + (int64_t)orow * p->dk16_ss + hkv * p->dk16_sh);
+      }
+#pragma unroll
+      for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int d0 = 32 * dj + 8 * g4 + 4 * hi;
+          f32x4 v = {acc[kb][dj][4 * g4] * mul, acc[kb][dj][4 * g4 + 1] * mul, acc[kb][dj][4 * g4 + 2] * mul,
+                     acc[kb][dj][4 * g4 + 3] * mul};
+          if (accf) v += *(const f32x4*)(o32 + d0);
+          if (o16) *(u32x2*)(o16 + 2 * d0) = u32x2{E::pack2(v[0], v[1]), E::pack2(v[2], v[3])};
+          else *(f32x4*)(o32 + d0) = v;
+        }
+    }
+  }
+  }  // next item
+}
+
+bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st, int* rc) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on || p_in.interleave) return false;
+  // fp16: hipcc's register allocation of that instantiation copies the accumulators between the register files inside the
+  // loop and reads one of them right behind its MFMA (tools/mfma_hazards.py: 22 hazards) -- served by the 8-wave kernel
+  if (dtype != USP_BF16) return false;
+  if (!p_in.split && p_in.G > 1) return false;   // the in-workgroup loop over a GQA group's heads stays with the 8-wave kernel
+  // the Q / dO cursors count remaining bytes in 32 bits; the pieces' swizzle is XORed into the per-lane byte offset
+  if (((int64_t)(p_in.Sq - 1) * p_in.q_ss + 128) * 2 >= (1LL << 31) || ((int64_t)(p_in.Sq - 1) * p_in.do_ss + 128) * 2 >= (1LL << 31))
+    return false;
+  if ((p_in.q_ss * 2) % 256 != 0 || (p_in.do_ss * 2) % 256 != 0) return false;
+  BwdParams p = p_in;
+  p.nblk = (p.Sk + 127) / 128;
+  p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1) * p.qsplit;
+  const int grid = p.n_items > cus ? cus : p.n_items;          // persistent: one workgroup per CU
+  constexpr size_t lds = 3 * (2 * kTile * 128 * 2 + 2 * kTile * 4) + 2 * 2 * 8192;
+  if (causal) hipLaunchKernelGGL((flash_bwd_dkdv64_kernel<0, true>), dim3(grid), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((flash_bwd_dkdv64_kernel<0, false>), dim3(grid), dim3(256), lds, st, p);
+  *rc = hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
+  return true;
+}
+
+}  // namespace usp

@@ -1,0 +1,86 @@
+// One-wave-per-SIMD building blocks shared by usp_flash_fwd64.hip and usp_flash_bwd64.hip: inline-asm MFMA forms that let
+// ONE kernel keep accumulators and resident operands in the accumulator half of the register file (AGPRs) while the score
+// tiles live in arch VGPRs, the wait-state guards hipcc cannot place around asm MFMAs, and LDS-DMA issued from asm.
+#pragma once
+#include "usp_common.hpp"
+
+namespace usp {
+
+// ---- asm MFMA forms ---------------------------------------------------------------------------------------------------
+template <int DT> struct M64;
+#if defined(__HIP_DEVICE_COMPILE__)   // "a" means eax to the host pass, which then drops the kernel stubs
+#define USP_M64_BODY(MN)                                                                                              \
+  /* first MFMA of a score chain: C = 0; D in arch VGPRs; A = K fragment (VGPR), B = Q fragment (AGPR) */            \
+  /* SAFE: two wait states in front ("VALU / v_accvgpr_write -> MFMA operand") for the code outside the steady state, */ \
+  /* where hipcc may re-materialise an operand right in front of the statement                                     */ \
+  template <bool SAFE = false> static USP_DEV void s_first(f32x16& s, const u32x4& a, const u32x4& q) {               \
+    if (SAFE) asm volatile("s_nop 1\n\t" MN " %0, %1, %2, 0" : "=&v"(s) : "v"(a), "a"(q));                          \
+    else asm volatile(MN " %0, %1, %2, 0" : "=&v"(s) : "v"(a), "a"(q));                                               \
+  }                                                                                                                   \
+  template <bool SAFE = false> static USP_DEV void s_next(f32x16& s, const u32x4& a, const u32x4& q) {                \
+    if (SAFE) asm volatile("s_nop 1\n\t" MN " %0, %1, %2, %0" : "+v"(s) : "v"(a), "a"(q));                          \
+    else asm volatile(MN " %0, %1, %2, %0" : "+v"(s) : "v"(a), "a"(q));                                               \
+  }                                                                                                                   \
+  /* O^T accumulate: C/D in AGPRs; A = V^T fragment, B = packed P (VGPRs) */                                           \
+  template <bool SAFE = false> static USP_DEV void o_acc(f32x16& o, const u32x4& a, const u32x4& b) {                 \
+    if (SAFE) asm volatile("s_nop 1\n\t" MN " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                          \
+    else asm volatile(MN " %0, %1, %2, %0" : "+a"(o) : "v"(a), "v"(b));                                               \
+  }
+#else
+#define USP_M64_BODY(MN)                                                                                              \
+  template <bool SAFE = false> static USP_DEV void s_first(f32x16&, const u32x4&, const u32x4&) {}                    \
+  template <bool SAFE = false> static USP_DEV void s_next(f32x16&, const u32x4&, const u32x4&) {}                     \
+  template <bool SAFE = false> static USP_DEV void o_acc(f32x16&, const u32x4&, const u32x4&) {}
+#endif
+template <> struct M64<0> { USP_M64_BODY("v_mfma_f32_32x32x16_bf16") };
+template <> struct M64<1> { USP_M64_BODY("v_mfma_f32_32x32x16_f16") };
+
+USP_DEV void pin_agpr4(u32x4& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+a"(x));
+#endif
+}
+// `n` wait states that hipcc cannot move the readers of the accumulators across (it does not know that the asm
+// statements in front of it are MFMAs: "XDL write -> VALU / v_accvgpr read" needs 12 states for an 8-pass MFMA).
+USP_DEV void mfma_settle(f32x16 (&o)[2][4]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]),
+                            "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));
+#endif
+}
+USP_DEV void mfma_settle(f32x16 (&s)[2][2]) {
+  asm volatile("s_nop 15" : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]));
+}
+USP_DEV void mfma_settle(f32x16 (&s)[2]) { asm volatile("s_nop 15" : "+v"(s[0]), "+v"(s[1])); }
+// VALU write (v_cvt_pk / v_accvgpr_write) -> MFMA operand read: 2 wait states, which hipcc does not pad in front of asm
+USP_DEV void operand_settle() { asm volatile("s_nop 3" ::: "memory"); }
+
+// LDS-DMA from inline asm (buffer_load_dwordx4 ... lds: 64 x 16 bytes at rsrc.base + soffset + voffset land linearly at
+// the wave-uniform LDS address M0).  hipcc does not see these loads: it puts no s_waitcnt vmcnt(0) in front of the first
+// ds_read_b64_tr_b16 behind a DMA (it cannot tell the double buffers apart), so the pieces can be issued anywhere in an
+// iteration; the kernel drains them itself (dma_drain) in front of the barrier that publishes the tile.  M0 is written
+// by piece 0 of a tile and read by pieces 1-3 (hipcc itself never touches M0 in this kernel: tools/mfma_hazards.py checks
+// the .s); the s_nop covers "SALU write M0 -> LDS-DMA".  Descriptor and offsets are SALU results (no VALU -> SGPR hazard).
+USP_DEV void lds_dma16_asm(const u32x4& rsrc, int lds_dst, int voffset, int soffset, int piece) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if (piece == 0)
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 : : "s"(lds_dst), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+  if (piece == 1) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:1024 lds" : : "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+  if (piece == 2) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:2048 lds" : : "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+  if (piece == 3) asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:3072 lds" : : "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+#endif
+}
+// 4-byte pieces (64 x 4 bytes per wave-instruction: one row statistic per lane)
+USP_DEV void lds_dma4_asm(const u32x4& rsrc, int lds_dst, int voffset) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+               : : "s"(lds_dst), "v"(voffset), "s"(rsrc) : "memory");
+#endif
+}
+USP_DEV u32x4 make_rsrc(const char* base, int bytes) {
+  const uint64_t a = (uint64_t)base;
+  return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)(bytes > 0 ? bytes : 0), 0x00020000u};
+}
+
+}  // namespace usp

@@ -7,9 +7,12 @@ per straight-line instruction stream (labels and branches reset nothing: the str
 over-approximates):
   A  VALU / DS-return write of a VGPR  ->  MFMA reading it as SrcA/B/C within < 2 instructions   (needs 2 wait states)
   B  MFMA writing D  ->  any non-MFMA instruction reading or writing a register of D within < 12 wait states
-     (8-pass 32x32x16: 12 states; an s_nop N counts N + 1, every other instruction 1; an MFMA that takes D whole as
-     its SrcC and writes it back is the exempt accumulate chain)
+     (8-pass 32x32x16: 12 states; an s_nop N counts N + 1, an intervening MFMA 8 -- the matrix pipe accepts the next
+     32x32x16 MFMA one 8-pass slot after the previous one, so two MFMAs are never less than 8 states apart --, every
+     other instruction 1; an MFMA that takes D whole as its SrcC and writes it back is the exempt accumulate chain)
   C  v_accvgpr_write  ->  MFMA reading that AGPR within < 3 instructions
+The scan behind an MFMA stops at an unconditional branch (layout order is not execution order there; the target of a
+conditional or unconditional branch is NOT followed -- loops re-enter code that has been checked from its own MFMAs).
 Prints every violation with its line number in the .s file."""
 import re
 import sys
@@ -66,6 +69,8 @@ def main():
             if i + k >= len(ins) or states >= int(__import__("os").environ.get("HZ_STATES", "12")):
                 break
             nl, nop_, nops = ins[i + k]
+            if nop_ in ("s_branch", "s_endpgm", "s_setpc_b64"):
+                break                                       # what follows in layout order is not what executes next
             if nop_.startswith("v_mfma"):
                 nd, nc = regs(nops[0]), regs(nops[3]) if len(nops) > 3 else set()
                 touched = set()
@@ -77,7 +82,7 @@ def main():
                 if (nc & d or nd & d) and not (nc == d and nd == d):
                     print(f"B: line {nl}: MFMA overlaps D of MFMA at line {ln} partially after {states} states")
                     bad += 1
-                states += 1
+                states += 8
                 continue
             touched = set()
             for t in nops:
