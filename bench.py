@@ -178,6 +178,23 @@ def _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, iters, keep=False):
     return res
 
 
+def _layer_fwd_bwd(B, S, Hq, Hkv, D, dev, iters, warm=2):
+    """One fwd+bwd step of the LAYER on one GPU: LongContextAttention.forward + out.backward through autograd (what the
+    reference's own benchmark times, benchmark/benchmark_longctx.py:200-255), on the sequence-parallel group main() has
+    set up (1 x 1 here).  Device events on torch's current stream; fresh N(0,1) leaves, gradients dropped per step.
+    Returns ms per step -- autograd, final_grads, the delta launch and every host-side gap included."""
+    import yunchang_amd as Y
+    q, k, v, do = _kernel_inputs(B, S, Hq, Hkv, D, dev, seed=2)
+    for t in (q, k, v):
+        t.requires_grad_(True)
+    attn = Y.LongContextAttention(ring_impl_type="zigzag", attn_type=Y.AttnType.HIP)
+
+    def step():
+        attn(q, k, v, causal=True).backward(do)
+        q.grad = k.grad = v.grad = None
+    return _time_events(step, iters, warm=warm)
+
+
 def sampled_parity(t, n_rows=8, n_keys=8, seed=0):
     """Sampled rows / keys of a causal forward + backward (batch 0, first and last query head / KV head) against exact
     attention in fp64 on the device: out, LSE and dQ of `n_rows` query rows, dK and dV of `n_keys` keys (summed over the
@@ -235,13 +252,21 @@ def kernel_roofline(cfg, dev, traffic, iters=20):
     _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, 300)                # ~0.5 s of work first: measure at sustained clocks,
     t = _fwd_bwd_kernels(B, S, Hq, Hkv, D, dev, iters)          # not on the DVFS ramp of a device that was idle
     frac = lambda x: round(x / PEAK_BF16_TFLOPS, 4)
-    roof = {"bound": "mfma", "kernel": "usp::flash_fwd_kernel<128,bf16,causal>", "achieved": round(t["fwd"], 1),
+    F = fwd_flops(B, Hq, S, D)
+    layer_ms = _layer_fwd_bwd(B, S, Hq, Hkv, D, dev, max(4, iters // 2))
+    roof = {"bound": "mfma", "kernel": "usp::flash_fwd64_kernel<bf16,causal> (4 waves x 64 query rows, one wave per SIMD)",
+            "achieved": round(t["fwd"], 1),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": frac(t["fwd"]),
             "kernel_ms": t["fwd_ms"], "traffic": traffic,
-            "fwd_bwd": {"kernels": "flash_fwd_kernel + delta_kernel + flash_bwd_dkdv_kernel + flash_bwd_kernel<dQ>",
+            "fwd_bwd": {"kernels": "flash_fwd64_kernel + delta_kernel + flash_bwd_dkdv64_kernel + flash_bwd_kernel<dQ>",
                         "shape_BSHD": [B, S, Hq, D], "kv_heads": Hkv, "fwd_ms": t["fwd_ms"], "bwd_ms": t["bwd_ms"],
                         "bwd_achieved": round(t["bwd"], 1), "bwd_frac": frac(t["bwd"]),
                         "achieved": round(t["fwd_bwd"], 1), "frac": frac(t["fwd_bwd"]),
+                        "layer_ms": round(layer_ms, 4),
+                        "layer_achieved": round(3.5 * F / (layer_ms * 1e-3) / 1e12, 1),
+                        "layer_frac": frac(3.5 * F / (layer_ms * 1e-3) / 1e12),
+                        "layer_over_kernels": round(layer_ms / (t["fwd_ms"] + t["bwd_ms"]), 4),
+                        "layer": "LongContextAttention.forward + out.backward through autograd (1 x 1 grid), device events",
                         "note": "algorithmic FLOPs: backward = 2.5x forward (the two-launch backward executes 3.5x)"}}
     return roof
 
@@ -258,9 +283,16 @@ def seq64k_single_gpu(dev):
             parity = sampled_parity(t64.pop("tensors"))
         except Exception as e:
             parity = {"error": repr(e)[:200]}
+        try:
+            layer_ms = round(_layer_fwd_bwd(c5["B"], c5["S"], c5["Hq"], c5["Hkv"], c5["D"], dev, 2, warm=1), 3)
+        except Exception as e:
+            layer_ms = None
+            print(f"64K layer step failed to run: {e!r}", file=sys.stderr)
         roof["seq64k_single_gpu"] = {
             "shape_BSHD": [c5["B"], c5["S"], c5["Hq"], c5["D"]], "kv_heads": c5["Hkv"], "pass": "fwd+bwd, causal",
             "fwd_ms": t64["fwd_ms"], "bwd_ms": t64["bwd_ms"], "iter_ms": round(t64["fwd_ms"] + t64["bwd_ms"], 3),
+            "layer_ms": layer_ms,
+            "layer_over_kernels": None if layer_ms is None else round(layer_ms / (t64["fwd_ms"] + t64["bwd_ms"]), 4),
             "achieved": round(t64["fwd_bwd"], 1), "frac": frac(t64["fwd_bwd"]),
             "fwd_achieved": round(t64["fwd"], 1), "bwd_achieved": round(t64["bwd"], 1), "sampled_parity": parity}
     except Exception as e:                                   # informative entry: never kill the measurement
@@ -333,7 +365,8 @@ def kernel_source_sha16():
     import hashlib
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "long-context-attention_amd", "csrc")
-    for name in ("usp_common.hpp", "usp_item_deal.h", "usp_flash_fwd.hip", "usp_flash_bwd.hip", "Makefile"):
+    for name in ("usp_common.hpp", "usp_item_deal.h", "usp_mfma64.hpp", "usp_fwd_params.hpp", "usp_bwd_params.hpp",
+                 "usp_flash_fwd.hip", "usp_flash_fwd64.hip", "usp_flash_bwd.hip", "usp_flash_bwd64.hip", "Makefile"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -344,7 +377,7 @@ def pmc_traffic():
     correction + WRITE_SIZE, separate passes, C2 shape).  Hardware counters cannot be collected from inside
     this process, so the numbers come from profiles/r02_rocprof_summary.txt -- but ONLY if that profile was
     taken from the kernel sources of this tree (the summary carries their hash); otherwise null."""
-    name = next((n for n in ("r03_rocprof_summary.txt", "r02_rocprof_summary.txt")
+    name = next((n for n in ("r04_rocprof_summary.txt", "r03_rocprof_summary.txt", "r02_rocprof_summary.txt")
                  if os.path.exists(os.path.join(ROOT, "profiles", n))), "r02_rocprof_summary.txt")
     path = os.path.join(ROOT, "profiles", name)
     try:
@@ -354,9 +387,9 @@ def pmc_traffic():
                 sha = ln.split(":")[1].strip()
             if ln.startswith("roofline_kernel_isa_sha16:"):
                 isa = ln.split(":")[1].split()[0]
-            if "flash_fwd_kernel" in ln and "HBM read bytes/launch" in ln and rd is None:
+            if ("flash_fwd64_kernel" in ln or "flash_fwd_kernel" in ln) and "HBM read bytes/launch" in ln and rd is None:
                 rd = float(ln.split("=")[1].split("MB")[0])
-            if "flash_fwd_kernel" in ln and "HBM write bytes/launch" in ln and wr is None:
+            if ("flash_fwd64_kernel" in ln or "flash_fwd_kernel" in ln) and "HBM write bytes/launch" in ln and wr is None:
                 wr = float(ln.split("=")[1].split("MB")[0])
         if rd is None or wr is None:
             return None
@@ -637,6 +670,8 @@ def main(argv=None, dev=None):
     if own_pg:
         dist.init_process_group(backend, rank=rank, world_size=ws)
 
+    if ws > 1:                            # the benchmark harness opts in to the link-rate probe (comm/link.py): every rank
+        os.environ.setdefault("USP_LINK_PROBE", "1")    # has set its device above, and the line records what was measured
     import yunchang_amd as Y
     if smoke and dev.type == "cuda":      # gloo's p2p is not stream-ordered for device tensors (tests/test_gpu_multiproc.py)
         import yunchang_amd.ring.utils as _U

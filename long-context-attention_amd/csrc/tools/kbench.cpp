@@ -86,6 +86,24 @@ template <typename T> static std::vector<T> dev_download(const T* d, size_t n) {
   return h;
 }
 
+// USP_KBENCH_ROWSTRIDE=<elements> (B = 1 only): the 16-bit inputs of `bwd` / `fwd` live in buffers whose rows are that far
+// apart -- a head's rows then span more than 2^31 bytes with a few thousand rows (the span limits of the kernels' byte
+// arithmetic are what this exercises).  Compact host data is scattered with hipMemcpy2D.
+static int64_t env_rowstride() { const char* e = getenv("USP_KBENCH_ROWSTRIDE"); return e ? atoll(e) : 0; }
+static uint16_t* dev_upload_rows(const std::vector<uint16_t>& h, int S, int row_elems) {
+  const int64_t rs = env_rowstride();
+  if (rs <= 0) return dev_upload(h);
+  uint16_t* d; HIP_OK(hipMalloc(&d, (size_t)S * rs * 2));
+  HIP_OK(hipMemset(d, 0x7f, (size_t)S * rs * 2));             // 0x7f7f = a large finite bf16 between the rows
+  HIP_OK(hipMemcpy2D(d, (size_t)rs * 2, h.data(), (size_t)row_elems * 2, (size_t)row_elems * 2, S, hipMemcpyHostToDevice));
+  return d;
+}
+static usp_tensor bshd_rows(void* p, int S, int H, int D) {
+  const int64_t rs = env_rowstride();
+  usp_tensor t; t.ptr = p; t.stride_s = rs > 0 ? rs : (int64_t)H * D; t.stride_b = (int64_t)S * t.stride_s; t.stride_h = D;
+  return t;
+}
+
 static usp_tensor bshd(void* p, int S, int H, int D) {
   usp_tensor t; t.ptr = p; t.stride_b = (int64_t)S * H * D; t.stride_s = (int64_t)H * D; t.stride_h = D;
   return t;
@@ -382,7 +400,8 @@ static int run_bwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, in
   const size_t nq = (size_t)B * Sq * Hq * D, nk = (size_t)B * Sk * Hkv * D, nl = (size_t)B * Hq * Sq;
   std::vector<uint16_t> qb, kb, vb, dob; std::vector<float> qf, kf, vf, dof;
   fill(qb, qf, nq, dt, 21); fill(kb, kf, nk, dt, 22); fill(vb, vf, nk, dt, 23); fill(dob, dof, nq, dt, 24);
-  uint16_t *dq_ = dev_upload(qb), *dk_ = dev_upload(kb), *dv_ = dev_upload(vb), *ddo = dev_upload(dob);
+  uint16_t *dq_ = dev_upload_rows(qb, Sq, Hq * D), *dk_ = dev_upload_rows(kb, Sk, Hkv * D), *dv_ = dev_upload_rows(vb, Sk, Hkv * D),
+           *ddo = dev_upload_rows(dob, Sq, Hq * D);
   uint16_t* dout = dev_alloc<uint16_t>(nq);
   float* dlse = dev_alloc<float>(nl);
   float* ddelta = dev_alloc<float>(nl);
@@ -391,10 +410,10 @@ static int run_bwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, in
   usp_fwd_args f; memset(&f, 0, sizeof(f));
   f.dtype = dt; f.B = B; f.Sq = Sq; f.Sk = Sk; f.Hq = Hq; f.Hkv = Hkv; f.D = D; f.causal = causal;
   f.softmax_scale = scale;
-  f.q = bshd(dq_, Sq, Hq, D); f.k = bshd(dk_, Sk, Hkv, D); f.v = bshd(dv_, Sk, Hkv, D); f.out = bshd(dout, Sq, Hq, D);
+  f.q = bshd_rows(dq_, Sq, Hq, D); f.k = bshd_rows(dk_, Sk, Hkv, D); f.v = bshd_rows(dv_, Sk, Hkv, D); f.out = bshd(dout, Sq, Hq, D);
   f.lse = dlse; f.lse_stride_b = (int64_t)Hq * Sq; f.lse_stride_h = Sq; f.final_end = Sq;
   int rc = usp_flash_fwd(&f, nullptr);
-  usp_tensor tdo = bshd(ddo, Sq, Hq, D), tout = bshd(dout, Sq, Hq, D);
+  usp_tensor tdo = bshd_rows(ddo, Sq, Hq, D), tout = bshd(dout, Sq, Hq, D);
   rc |= usp_bwd_delta(dt, B, Sq, Hq, D, &tdo, &tout, ddelta, (int64_t)Hq * Sq, Sq, nullptr);
   usp_bwd_args a; memset(&a, 0, sizeof(a)); a.flags = env_flags();
   a.dtype = dt; a.B = B; a.Sq = Sq; a.Sk = Sk; a.Hq = Hq; a.Hkv = Hkv; a.D = D; a.causal = causal;

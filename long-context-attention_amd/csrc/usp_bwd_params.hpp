@@ -65,9 +65,6 @@ USP_DEV bool bind_sequence(BwdParams& p, int b, int64_t* ws_row0) {
 
 constexpr int kTile = 64;           // streamed rows per LDS tile
 
-#ifndef USP_BWD_G      // MFMA slots per pinned scheduling group (A/B builds; 1 = every slot fenced)
-#define USP_BWD_G 1
-#endif
 
 // Swizzle of the 16-byte slot index inside a row-major [rows][D] 16-bit tile.
 template <int D> USP_DEV int tile_swz(int row) {

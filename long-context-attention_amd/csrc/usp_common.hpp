@@ -194,11 +194,7 @@ struct ItemQueue {
 // kernel entry, none in any loop) the kernels report.  By value the call pins the struct in argument registers
 // across the whole kernel and the flash kernels spill 37-70 VGPRs instead (tried in round 2).
 // `state` = lists already drained by this workgroup; returns the item (bh * n_t + t) or -1.
-#ifdef USP_QINLINE
-USP_DEV int item_queue_fetch(
-#else
 __attribute__((noinline)) USP_DEV int item_queue_fetch(
-#endif
     const ItemQueue& q, int& state) {
   const int x = blockIdx.x & 7;
   for (; state < 8; ++state) {

@@ -3,12 +3,11 @@
 // fp32 accumulation the ring schedules do on its results (zigzag_ring_flash_attn.py:147-170).
 //
 // Two launches, no atomics, deterministic:
-//   MODE 0 (dQ)    : workgroup = 8 waves x 32 query rows; streams K,V tiles (64 keys) through LDS.
-//                    lane owns a query row:  S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
-//   MODE 1 (dK,dV) : workgroup = 4 waves x 32 keys (one wave per SIMD, 512-register budget);
-//                    streams Q,dO tiles (64 rows) of every query head of the GQA group through LDS.
-//                    lane owns a key:        S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
-// Both modes are one engine: two LDS tiles X1,X2 (row-major, 16-byte-slot XOR swizzle chosen so that
+//   dQ     (flash_bwd_kernel)      : workgroup = 8 waves x 32 query rows; streams K,V tiles (64 keys) through LDS.
+//                                    lane owns a query row:  S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
+//   dK, dV (flash_bwd_dkdv_kernel) : workgroup = 8 waves, 128 keys, two roles (below); the one-wave-per-SIMD form of it
+//                                    lives in usp_flash_bwd64.hip and serves the dense bf16 D = 128 launches.
+// Both are one engine: two LDS tiles X1,X2 (row-major, 16-byte-slot XOR swizzle chosen so that
 // BOTH ds_read_b128 row reads and ds_read_b64_tr_b16 column reads are bank-conflict free), two
 // register-resident fragment sets R1,R2, S = X1 R1^T, T = X2 R2^T, and tr-read "X^T" operands for
 // the gradient MFMAs.  As in the forward, no cross-lane shuffle is needed for P / dS: the k-step
@@ -23,16 +22,15 @@
 
 namespace usp {
 
-template <int D, int DT, bool CAUSAL, int MODE>
-__global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flash_bwd_kernel(
+template <int D, int DT, bool CAUSAL>
+__global__ __launch_bounds__(512, 2) void flash_bwd_kernel(
     const BwdParams p_in) {
   using E = Elem<DT>;
-  constexpr int NT = MODE == 0 ? 512 : 256;     // threads
+  constexpr int NT = 512;     // threads
   constexpr int OWN = (NT / 64) * 32;           // rows owned by the workgroup (256 q rows / 128 keys)
   constexpr int ROWB = D * 2;
   constexpr int TILEB = kTile * ROWB;           // one streamed matrix tile
-  constexpr int STATB = MODE == 1 ? 2 * kTile * 4 : 0;   // lse2 + delta of the tile's rows
-  constexpr int BUFB = 2 * TILEB + STATB;
+  constexpr int BUFB = 2 * TILEB;
   constexpr int NKT = D / 16;
   constexpr int NDJ = D / 32;
 
@@ -47,8 +45,8 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 
   // ---- work items (persistent workgroups, usp_common.hpp ItemWalk) ------------------------------------
   const ItemWalk walk(p_in.n_items);
-  ItemQueue queue{p_in.sched, MODE == 0 ? p_in.seq_q : p_in.seq_k, p_in.n_items / p_in.nblk, p_in.nblk,
-                  MODE == 0 ? p_in.Hq : p_in.Hkv * (p_in.split ? p_in.G : 1), OWN, (MODE == 0 && CAUSAL) ? 1 : 0};
+  ItemQueue queue{p_in.sched, p_in.seq_q, p_in.n_items / p_in.nblk, p_in.nblk,
+                  p_in.Hq, OWN, CAUSAL ? 1 : 0};
   int qstate = 0;
   USP_LDS int* qslots = (USP_LDS int*)(smem + p_in.sched_lds);
   for (int pass = 0;; ++pass) {
@@ -58,83 +56,68 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   if (!p_in.sched) w = walk.dealt(w, p.nblk);
   const int blk_r = w % p.nblk;
   int rest = w / p.nblk;
-  int b, hkv, h0, blk, split_g = 0, cut = 0;
-  if (MODE == 0) {
+  int b, hkv, h0, blk, cut = 0;
+  
     blk = CAUSAL ? (p.nblk - 1 - blk_r) : blk_r;          // late query blocks see most keys
     if (p.ksplit > 1) { cut = rest % p.ksplit; rest /= p.ksplit; }
     const int g = rest % p.G; rest /= p.G;
     hkv = rest % p.Hkv; b = rest / p.Hkv;
     h0 = hkv * p.G + g;
-  } else {
-    blk = blk_r;                                           // early key blocks are seen by most rows
-    int g = 0;
-    if (p.split) { g = rest % p.G; rest /= p.G; }          // one query head of the GQA group per workgroup
-    hkv = rest % p.Hkv; b = rest / p.Hkv;
-    h0 = hkv * p.G + g;
-    split_g = g;
-  }
+  
   int64_t ws_row0;
   if (!bind_sequence(p, b, &ws_row0)) continue;
   const int own0 = blk * OWN;                  // first owned row (query row / key)
-  if (p.seq_q != nullptr && own0 >= (MODE == 0 ? p.Sq : p.Sk)) continue;   // past the end of its sequence
+  if (p.seq_q != nullptr && own0 >= (p.Sq)) continue;   // past the end of its sequence
   const int off = p.causal_off;
   const int ow = own0 + wave * 32;             // first row owned by this wave
   const int orow = ow + l31;                   // this lane's row
-  const int own_len = MODE == 0 ? p.Sq : p.Sk;
+  const int own_len = p.Sq;
   const int orow_c = orow < own_len ? orow : own_len - 1;
 
   // ---- register-resident fragments R1, R2 (B operands: lane holds row[16t + 8hi .. +7]) -----------
   u32x4 r1[NKT], r2[NKT];
   {
     const char *p1, *p2;
-    if (MODE == 0) {
+    
       p1 = p.q + 2 * (b * p.q_sb + (int64_t)orow_c * p.q_ss + h0 * p.q_sh);
       p2 = p.dout + 2 * (b * p.do_sb + (int64_t)orow_c * p.do_ss + h0 * p.do_sh);
-    } else {
-      p1 = p.k + 2 * (b * p.k_sb + (int64_t)orow_c * p.k_ss + hkv * p.k_sh);
-      p2 = p.v + 2 * (b * p.v_sb + (int64_t)orow_c * p.v_ss + hkv * p.v_sh);
-    }
+    
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
       r1[t] = *(const u32x4*)(p1 + 32 * t + 16 * hi);
       r2[t] = *(const u32x4*)(p2 + 32 * t + 16 * hi);
     }
   }
-  // MODE 0: lane-local row statistics
+  // lane-local row statistics
   float lse2_l = 0.f, delta_l = 0.f;
-  if (MODE == 0) {
+  
     const float l_ = p.lse[b * p.lse_sb + h0 * p.lse_sh + orow_c];
     lse2_l = (l_ == USP_NEG_INF) ? __builtin_inff() : l_ * kLog2e;
     delta_l = p.delta[b * p.dl_sb + h0 * p.dl_sh + orow_c];
-  }
 
   // ---- streamed range ---------------------------------------------------------------------------
-  // MODE 0 streams key tiles [0, nt); MODE 1 streams (head-in-group, query tile) pairs.
-  const int str_len = MODE == 0 ? p.Sk : p.Sq;
+  // key tiles [t_begin, t_end)
+  const int str_len = p.Sk;
   int t_begin = 0, t_end = (str_len + kTile - 1) / kTile;     // tiles per head
   if (CAUSAL) {
-    if (MODE == 0) {
+    
       const int last = (own0 + OWN < p.Sq ? own0 + OWN : p.Sq) - 1;
       const int kv_end = last + off + 1 < p.Sk ? last + off + 1 : p.Sk;
       t_end = kv_end > 0 ? (kv_end + kTile - 1) / kTile : 0;
-    } else {
-      const int first_q = own0 - off > 0 ? own0 - off : 0;     // first row that sees key own0
-      t_begin = first_q / kTile;
-      if (t_begin > t_end) t_begin = t_end;
-    }
+    
   }
-  if (MODE == 0 && p.win_on) {                 // key tiles left of the window of the block's first row: not streamed
+  if (p.win_on) {                 // key tiles left of the window of the block's first row: not streamed
     const int first = own0 + p.win_lo;
     t_begin = first > 0 ? first / kTile : 0;
     if (t_begin > t_end) t_begin = t_end;
   }
-  if (MODE == 0 && p.ksplit > 1) {             // this item's cut of the key tiles [t_begin, t_end): equal runs
+  if (p.ksplit > 1) {             // this item's cut of the key tiles [t_begin, t_end): equal runs
     const int per = (t_end - t_begin + p.ksplit - 1) / p.ksplit;
     t_begin = t_begin + cut * per < t_end ? t_begin + cut * per : t_end;
     t_end = t_begin + per < t_end ? t_begin + per : t_end;
   }
   const int per_head = t_end - t_begin;
-  const int n_iter = (MODE == 0 || p.split) ? per_head : per_head * p.G;
+  const int n_iter = per_head;
 
   // ---- staging: LDS-DMA (buffer_load ... lds), no staging registers, no ds_write ---------------------
   // One wave-instruction fills 1 KiB of LDS linearly (wave-uniform base + lane*16), i.e. 1024/ROWB
@@ -147,8 +130,8 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   constexpr int CPW = (CHUNKS + NW - 1) / NW;     // pieces per wave per matrix
   constexpr int RPC = 1024 / ROWB;                // tile rows per piece
   int dma_voff1[CPW], dma_voff2[CPW];
-  const int64_t ss1 = MODE == 0 ? p.k_ss : p.q_ss;
-  const int64_t ss2 = MODE == 0 ? p.v_ss : p.do_ss;
+  const int64_t ss1 = p.k_ss;
+  const int64_t ss2 = p.v_ss;
 #pragma unroll
   for (int i = 0; i < CPW; ++i) {
     const int cidx = wave + NW * i;
@@ -157,53 +140,25 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
     dma_voff1[i] = r * (int)ss1 * 2 + c8 * 16;
     dma_voff2[i] = r * (int)ss2 * 2 + c8 * 16;
   }
-  float st_lse = 0.f, st_delta = 0.f;
-  // Prefetch cursor: running 64-bit tile pointers / remaining-bytes counters / (tile, head) counters,
-  // advanced by additions only.  (Per-iteration 64-bit multiplies and the it/per_head division cost
-  // ~150 SALU instructions per tile, which nothing hides at one wave per SIMD.)
+  // Prefetch cursor: running 64-bit tile pointers / remaining-bytes counters, advanced by additions only.
   decltype(__builtin_amdgcn_make_buffer_rsrc((void*)nullptr, 0, 0, 0)) rs1, rs2;
   int dma_buf = 0;
   const int64_t tb1 = (int64_t)kTile * ss1 * 2, tb2 = (int64_t)kTile * ss2 * 2;   // bytes per tile step
-  const int heads_here = (MODE == 0 || p.split) ? 1 : p.G;
-  int pf_tile = t_begin, pf_hh = 0;              // next tile to prefetch
   const char *pf_p1 = nullptr, *pf_p2 = nullptr;
   int64_t pf_rem1 = 0, pf_rem2 = 0;
-  auto pf_head = [&]() {                         // (re)base the cursor on head pf_hh, tile t_begin
-    const char *b1, *b2;
-    if (MODE == 0) {
-      b1 = p.k + 2 * (b * p.k_sb + hkv * p.k_sh);
-      b2 = p.v + 2 * (b * p.v_sb + hkv * p.v_sh);
-    } else {
-      b1 = p.q + 2 * (b * p.q_sb + (h0 + pf_hh) * p.q_sh);
-      b2 = p.dout + 2 * (b * p.do_sb + (h0 + pf_hh) * p.do_sh);
-    }
-    pf_tile = t_begin;
-    pf_p1 = b1 + t_begin * tb1;
-    pf_p2 = b2 + t_begin * tb2;
+  {                                              // base the cursor on tile t_begin of the K / V rows of (b, hkv)
+    pf_p1 = p.k + 2 * (b * p.k_sb + hkv * p.k_sh) + t_begin * tb1;
+    pf_p2 = p.v + 2 * (b * p.v_sb + hkv * p.v_sh) + t_begin * tb2;
     pf_rem1 = ((int64_t)(str_len - 1 - t_begin * kTile) * ss1 + D) * 2;
     pf_rem2 = ((int64_t)(str_len - 1 - t_begin * kTile) * ss2 + D) * 2;
-  };
-  pf_head();
-  // build the descriptors for the cursor's tile, fetch its row statistics, then advance the cursor
+  }
+  // build the descriptors for the cursor's tile, then advance the cursor
   auto stage_setup = [&](int buf) {
     auto clampu = [](int64_t r) { return (int)(uint32_t)(r < 0 ? 0 : (r > 0xffffffffLL ? 0xffffffffLL : r)); };
     rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)pf_p1, 0, clampu(pf_rem1), 0x00020000);
     rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)pf_p2, 0, clampu(pf_rem2), 0x00020000);
     dma_buf = buf;
-    if (MODE == 1 && tid < kTile) {
-      const int r = pf_tile * kTile + tid;
-      if (r < p.Sq) {
-        const float l_ = p.lse[b * p.lse_sb + (h0 + pf_hh) * p.lse_sh + r];
-        st_lse = (l_ == USP_NEG_INF) ? __builtin_inff() : l_ * kLog2e;
-        st_delta = p.delta[b * p.dl_sb + (h0 + pf_hh) * p.dl_sh + r];
-      } else {
-        st_lse = __builtin_inff();    // rows past the end contribute P = 0
-        st_delta = 0.f;
-      }
-    }
-    ++pf_tile;
     pf_p1 += tb1; pf_p2 += tb2; pf_rem1 -= tb1; pf_rem2 -= tb2;
-    if (heads_here > 1 && pf_tile == t_end) { ++pf_hh; pf_head(); }
   };
   // piece pi in [0, 2*CPW): matrix pi & 1, chunk wave + NW * (pi >> 1)
   auto stage_piece = [&](int pi) {
@@ -211,23 +166,13 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
     const int cidx = wave + NW * i;
     if (CHUNKS % NW == 0 || cidx < CHUNKS) {
       USP_LDS char* d1 = smem + dma_buf * BUFB + cidx * 1024;
-#ifndef USP_ABLATE_NOSTAGE
       if ((pi & 1) == 0) lds_dma16(rs1, d1, dma_voff1[i]);
       else lds_dma16(rs2, d1 + TILEB, dma_voff2[i]);
-#else
-      (void)d1;
-#endif
     }
   };
   auto stage_all = [&]() {
 #pragma unroll
     for (int pi = 0; pi < 2 * CPW; ++pi) stage_piece(pi);
-  };
-  auto stage_stats = [&](int buf) {
-    if (MODE == 1 && tid < kTile) {
-      *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * tid) = st_lse;
-      *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * kTile + 4 * tid) = st_delta;
-    }
   };
 
   // ---- per-lane LDS read addresses ----------------------------------------------------------------
@@ -251,29 +196,21 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
   }
 
   // ---- accumulators -----------------------------------------------------------------------------
-  f32x16 acc1[NDJ];                      // dQ^T (MODE 0) / dK^T (MODE 1)
-  f32x16 acc2[MODE == 1 ? NDJ : 1];      // dV^T (MODE 1)
+  f32x16 acc1[NDJ];                      // dQ^T
 #pragma unroll
   for (int dj = 0; dj < NDJ; ++dj)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc1[dj][r] = 0.f; if (MODE == 1) acc2[dj][r] = 0.f; }
-  if (MODE == 1) {
-    // give the loop-carried accumulators an AGPR home from the start (see Elem::mfma_agpr)
-#pragma unroll
-    for (int dj = 0; dj < NDJ; ++dj) {
-      pin_agpr(acc1[dj]);
-      pin_agpr(acc2[dj]);
-    }
-  }
+    for (int r = 0; r < 16; ++r) { acc1[dj][r] = 0.f;  }
+  
   const float c = p.scale_log2;
 
-  if (n_iter > 0) { stage_setup(0); stage_all(); stage_stats(0); }
+  if (n_iter > 0) { stage_setup(0); stage_all(); }
   dma_drain();            // this wave's DMA pieces of the staged tile have landed (usp_common.hpp)
   __syncthreads();
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   constexpr int NST = 2 * NKT;                          // MFMAs of one S/T phase
-  constexpr int NGR = 2 * NDJ * (MODE == 1 ? 2 : 1);    // MFMAs of one gradient phase
+  constexpr int NGR = 2 * NDJ;                          // MFMAs of one gradient phase
 
   int cur_tile = t_begin;                              // streamed tile of the current iteration
   for (int it = 0; it < n_iter; ++it) {
@@ -285,7 +222,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
     if (prefetch) stage_setup(buf ^ 1);
 
     bool active = true, need_mask = false;
-    if (MODE == 0) {
+    
       // streamed = keys, owned = query rows
       int wave_kv_end = p.Sk;
       if (CAUSAL) {
@@ -294,11 +231,6 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
       }
       active = ow < p.Sq && s0 < wave_kv_end && (!p.win_on || s0 + kTile - 1 >= ow + p.win_lo);
       need_mask = (s0 + kTile > p.Sk) || (CAUSAL && s0 + kTile - 1 > ow + off) || (p.win_on && s0 < ow + 31 + p.win_lo);
-    } else {
-      // streamed = query rows, owned = keys
-      active = ow < p.Sk && (!CAUSAL || (s0 + kTile - 1 + off >= ow));
-      need_mask = CAUSAL && (s0 + off < ow + 31);
-    }
 
     if (active) {
       // Hand-pinned pipeline over the two 32-row halves h0, h1 of the tile (sched_barrier(0) fences;
@@ -308,20 +240,11 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
       USP_LDS const char* x1 = smem + buf * BUFB;
       USP_LDS const char* x2 = x1 + TILEB;
       f32x16 sS[2], sT[2];
-      u32x4 pk_ds[2][2], pk_p[MODE == 1 ? 2 : 1][2];
-      f32x4 stl, std_;                                  // MODE 1: lse2 / delta of 4 consecutive rows
+      u32x4 pk_ds[2][2];
 
-      // stats of rows 4*g4 .. 4*g4+3 of half h (broadcast ds_read_b128, loaded just in time)
-      auto load_stats = [&](int h, int g4) {
-        if (MODE == 1) {
-          USP_LDS const char* stat = x1 + 2 * TILEB + (32 * h + 4 * hi) * 4 + 32 * g4;
-          stl = *(USP_LDS const f32x4*)stat;
-          std_ = *(USP_LDS const f32x4*)(stat + 4 * kTile);
-        }
-      };
       auto apply_mask = [&](int h) {
         const int sr0 = s0 + 32 * h + 4 * hi;           // streamed row of register r: sr0 + 8(r>>2) + (r&3)
-        if (MODE == 0) {
+        
           int klim = p.Sk - 1;
           if (CAUSAL) klim = orow + off < klim ? orow + off : klim;
           const int klo = p.win_on ? orow + p.win_lo : -0x40000000;
@@ -330,38 +253,15 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
             const int key = sr0 + (r & 3) + 8 * (r >> 2);
             if (key > klim || key < klo) sS[h][r] = USP_NEG_INF;
           }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 16; ++r)                   // query row i sees key j iff j <= i + off
-            if (orow > sr0 + (r & 3) + 8 * (r >> 2) + off) sS[h][r] = USP_NEG_INF;
-        }
+        
       };
       // P and dS of element r of half h (+ pack when a pair completes)
       auto elem = [&](int h, int r) {
-#ifdef USP_ABLATE_NOEXP
-        if (r & 1) {
-          pk_ds[h][r >> 3][(r & 7) >> 1] = __builtin_bit_cast(uint32_t, sT[h][r]);
-          if (MODE == 1) pk_p[h][r >> 3][(r & 7) >> 1] = __builtin_bit_cast(uint32_t, sS[h][r]);
-        }
-        return;
-#endif
         float pr, ds;
-        if (MODE == 0) {
-#if defined(USP_ABLATE_NOTRANS)      // A/B builds: what does the transcendental cost / what do the two dS operations cost
-          pr = __builtin_fmaf(sS[h][r], c, -lse2_l);
-#else
+        
           pr = fast_exp2(__builtin_fmaf(sS[h][r], c, -lse2_l));
-#endif
-#if defined(USP_ABLATE_NODS)
-          ds = sT[h][r];
-#else
           ds = pr * (sT[h][r] - delta_l);
-#endif
-        } else {
-          if ((r & 3) == 0) load_stats(h, r >> 2);
-          pr = fast_exp2(__builtin_fmaf(sS[h][r], c, -stl[r & 3]));
-          ds = pr * (sT[h][r] - std_[r & 3]);
-        }
+        
         sS[h][r] = pr;
         sT[h][r] = ds;
         if (r & 1) {
@@ -371,11 +271,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
           uint32_t w = E::pack2(sT[h][r - 1], sT[h][r]);
           pin_here(w);
           pk_ds[h][r >> 3][(r & 7) >> 1] = w;
-          if (MODE == 1) {
-            uint32_t wp = E::pack2(sS[h][r - 1], sS[h][r]);
-            pin_here(wp);
-            pk_p[h][r >> 3][(r & 7) >> 1] = wp;
-          }
+          
         }
       };
       // S/T phase of half h; `vh` >= 0: interleave the element work of half vh
@@ -383,12 +279,8 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
         u32x4 f1[NKT], f2[NKT];
         auto rd = [&](int kt) {
           const int a = h * 32 * ROWB + rd_row + (((2 * kt) ^ rd_x) * 16);
-#ifdef USP_ABLATE_NOLDS
-          f1[kt] = r1[(kt + 1) % NKT]; f2[kt] = r2[(kt + 1) % NKT]; (void)a;
-#else
           f1[kt] = *(USP_LDS const u32x4*)(x1 + a);
           f2[kt] = *(USP_LDS const u32x4*)(x2 + a);
-#endif
         };
         rd(0);
         if (NKT > 1) rd(1);
@@ -406,24 +298,18 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 #pragma unroll
             for (int e = sl * 16 / NST; e < (sl + 1) * 16 / NST; ++e) elem(vh, e);
           }
-          if (sl % USP_BWD_G == USP_BWD_G - 1) __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
       // gradient phase of half h; `vh` >= 0: interleave the element work of half vh
       auto grad_phase = [&](int h, int vh) {
         u32x4 xa[NGR];
-        auto rd = [&](int i) {                           // i -> (k2, dj, which matrix)
-          const int m = MODE == 1 ? (i & 1) : 0;
-          const int j = MODE == 1 ? (i >> 1) : i;
-          const int k2 = j / NDJ, dj = j % NDJ;
-          USP_LDS const char* xb = (m ? x2 : x1) + (2 * h + k2) * 16 * ROWB;
-#ifdef USP_ABLATE_NOLDS
-          xa[i] = r1[(i + dj) % NKT]; (void)xb;
-#else
+        auto rd = [&](int i) {                           // i -> (k2, dj): K^T fragments of the tile in x1
+          const int k2 = i / NDJ, dj = i % NDJ;
+          USP_LDS const char* xb = x1 + (2 * h + k2) * 16 * ROWB;
           const u32x2 a0 = lds_read_tr16(xb + tr_addr[dj][0]);
           const u32x2 a1 = lds_read_tr16(xb + tr_addr[dj][1]);
           xa[i] = u32x4{a0[0], a0[1], a1[0], a1[1]};
-#endif
         };
         rd(0);
         if (NGR > 1) rd(1);
@@ -431,20 +317,13 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 #pragma unroll
         for (int i = 0; i < NGR; ++i) {
           if (i + 2 < NGR) rd(i + 2);
-          const int m = MODE == 1 ? (i & 1) : 0;
-          const int j = MODE == 1 ? (i >> 1) : i;
-          const int k2 = j / NDJ, dj = j % NDJ;
-          if (MODE == 1) {                                 // 512-register kernel: accumulators pinned to AGPRs
-            if (m == 0) E::mfma_agpr(acc1[dj], xa[i], pk_ds[h][k2]);
-            else E::mfma_agpr(acc2[dj], xa[i], pk_p[h][k2]);
-          } else {
-            acc1[dj] = E::mfma(xa[i], pk_ds[h][k2], acc1[dj]);
-          }
+          const int k2 = i / NDJ, dj = i % NDJ;
+          acc1[dj] = E::mfma(xa[i], pk_ds[h][k2], acc1[dj]);
           if (vh >= 0) {
 #pragma unroll
             for (int e = i * 16 / NGR; e < (i + 1) * 16 / NGR; ++e) elem(vh, e);
           }
-          if (i % USP_BWD_G == USP_BWD_G - 1) __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_sched_barrier(0);
         }
       };
 
@@ -461,34 +340,20 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
       stage_all();
     }
 
-    if (it + 1 < n_iter) stage_stats(buf ^ 1);
-#ifndef USP_ABLATE_NOBARRIER
     dma_drain();            // this wave's DMA pieces of the staged tile have landed (usp_common.hpp)
     __syncthreads();
-#endif
   }
 
   // ---- epilogue: fp32 store / accumulate, or final 16-bit store ---------------------------------------
   if (orow < own_len) {
-    float* o1; float* o2 = nullptr;
-    char* h1 = nullptr; char* h2 = nullptr;      // 16-bit final destinations (row base), if any
-    int acc_f1, acc_f2 = 0;
-    if (MODE == 0 && p.ksplit > 1) {   // partial of this cut, combined (deterministically) by reduce_cuts_kernel
+    float* o1;
+    char* h1 = nullptr;                          // 16-bit final destination (row base), if any
+    int acc_f1;
+    if (p.ksplit > 1) {   // partial of this cut, combined (deterministically) by reduce_cuts_kernel
       o1 = p.ws_dq + ((((int64_t)cut * p.B + b) * p.Sq + orow) * p.Hq + h0) * D; acc_f1 = 0;
-    } else if (MODE == 0) {
+    } else {
       o1 = p.dq + b * p.dq_sb + (int64_t)orow * p.dq_ss + h0 * p.dq_sh; acc_f1 = p.accum_dq;
       if (p.dq16) h1 = p.dq16 + 2 * (b * p.dq16_sb + (int64_t)orow * p.dq16_ss + h0 * p.dq16_sh);
-    } else {
-      if (p.split) {   // per-head partial, combined (deterministically) by reduce_heads_kernel
-        const int64_t wo = (((int64_t)split_g * p.ws_rows + ws_row0 + orow) * p.Hkv + hkv) * D;
-        o1 = p.ws_dk + wo; acc_f1 = 0;
-        o2 = p.ws_dv + wo; acc_f2 = 0;
-      } else {
-        o1 = p.dk + b * p.dk_sb + (int64_t)orow * p.dk_ss + hkv * p.dk_sh; acc_f1 = p.accum_dk;
-        o2 = p.dv + b * p.dv_sb + (int64_t)orow * p.dv_ss + hkv * p.dv_sh; acc_f2 = p.accum_dv;
-        if (p.dk16) h1 = p.dk16 + 2 * (b * p.dk16_sb + (int64_t)orow * p.dk16_ss + hkv * p.dk16_sh);
-        if (p.dv16) h2 = p.dv16 + 2 * (b * p.dv16_sb + (int64_t)orow * p.dv16_ss + hkv * p.dv16_sh);
-      }
     }
 #pragma unroll
     for (int dj = 0; dj < NDJ; ++dj)
@@ -500,13 +365,7 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
         if (acc_f1) v1 += *(const f32x4*)(o1 + d0);
         if (h1) *(u32x2*)(h1 + 2 * d0) = u32x2{E::pack2(v1[0], v1[1]), E::pack2(v1[2], v1[3])};
         else *(f32x4*)(o1 + d0) = v1;
-        if (MODE == 1) {
-          f32x4 v2 = {acc2[dj][4 * g4], acc2[dj][4 * g4 + 1], acc2[dj][4 * g4 + 2],
-                      acc2[dj][4 * g4 + 3]};
-          if (acc_f2) v2 += *(const f32x4*)(o2 + d0);
-          if (h2) *(u32x2*)(h2 + 2 * d0) = u32x2{E::pack2(v2[0], v2[1]), E::pack2(v2[2], v2[3])};
-          else *(f32x4*)(o2 + d0) = v2;
-        }
+        
       }
   }
   if (p_in.sched && p_in.interleave) break;   // one item per workgroup: leave room for other streams' kernels
@@ -515,9 +374,9 @@ __global__ __launch_bounds__(MODE == 0 ? 512 : 256, MODE == 0 ? 2 : 1) void flas
 }
 
 // ======================================================================================================
-// dK/dV, role-specialised waves (the default dK/dV launch; MODE 1 above is the single-role fallback).
+// dK/dV, role-specialised waves.
 //
-// MODE 1 needs K AND V fragments (64 regs) plus dK AND dV accumulators (128 regs) per wave: > 256
+// A single-role wave needs K AND V fragments (64 regs) plus dK AND dV accumulators (128 regs) per wave: > 256
 // registers, i.e. ONE wave per SIMD, and a lone wave can hide only ~5 instructions per MFMA (measured:
 // 57 % of its cycles are active issue, MFMA pipe 32 % busy).  Here every 32-key slice is served by TWO
 // waves that sit on the same SIMD (wave w and w + 4):
@@ -546,6 +405,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   constexpr int CPW = (CHUNKS + NW - 1) / NW;
   constexpr int RPC = 1024 / ROWB;
   constexpr int NGR = 2 * NDJ;                   // gradient MFMAs per half
+  constexpr int PF = 2;                          // LDS operands are fetched this many MFMAs ahead
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   USP_LDS char* smem = (USP_LDS char*)smem_raw;
@@ -666,12 +526,8 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
       const int cidx = wave + NW * i;
       if (CHUNKS % NW == 0 || cidx < CHUNKS) {
         USP_LDS char* d1 = smem + buf * BUFB + cidx * 1024;
-#ifndef USP_ABLATE_DKDV_NOSTAGE
         lds_dma16(rs1, d1, dma_voff1[i], soff1);
         lds_dma16(rs2, d1 + TILEB, dma_voff2[i], soff2);
-#else
-        (void)d1;
-#endif
       }
     }
     ++pf_tile;
@@ -771,35 +627,21 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
             if (ROLE == 0 && (r & 3) == 0) st4 = stq[r >> 2];
             float val;
             if (ROLE == 0) {
-#ifdef USP_ABLATE_A_NOEXP        // A/B builds (tools/abl_bwd.sh): which role is the straggler of the per-tile barrier?
-              val = __builtin_fmaf(sc[h][r], c, -st4[r & 3]);
-#else
               val = fast_exp2(__builtin_fmaf(sc[h][r], c, -st4[r & 3]));
-#endif
             } else {
-#ifdef USP_ABLATE_B_NOELEM
-              val = sc[h][r];
-#else
               const uint32_t wd = pin[h][r >> 3][(r & 7) >> 1];
               const float pr = (r & 1) ? E::hi(wd) : E::lo(wd);
               val = pr * sc[h][r];
-#endif
             }
             sc[h][r] = val;
             if (r & 1) pk[h][r >> 3][(r & 7) >> 1] = E::pack2(sc[h][r - 1], sc[h][r]);
-#ifndef USP_ABLATE_NOPX
             if (ROLE == 0 && (r & 7) == 7)                        // 8 elements done: hand one k-step of P to B
               *(USP_LDS u32x4*)(pslot + (2 * h + (r >> 3)) * 1024) = pk[h][r >> 3];
-#endif
           };
           auto chain_phase = [&](int h, int vh) {
             u32x4 f[NKT];
             auto rd = [&](int kt) {
-#ifdef USP_ABLATE_DKDV_NOLDS     // A/B builds: what do the fragment reads cost?
-              f[kt] = rf[(kt + 1) % NKT];
-#else
               f[kt] = *(USP_LDS const u32x4*)(xs + h * 32 * ROWB + rd_row + (((2 * kt) ^ rd_x) * 16));
-#endif
             };
             f32x16 c0 = zero16;
             if (ROLE == 1) {                                     // -delta of this half's 16 rows: the chain's C operand
@@ -807,30 +649,23 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
 #pragma unroll
               for (int r = 0; r < 16; ++r) c0[r] = stq[r >> 2][r & 3];
             }
-#ifndef USP_DKDV_PF
-#define USP_DKDV_PF 2          // LDS operands are fetched this many MFMAs ahead (A/B builds)
-#endif
 #pragma unroll
-            for (int kt = 0; kt < USP_DKDV_PF && kt < NKT; ++kt) rd(kt);
+            for (int kt = 0; kt < PF && kt < NKT; ++kt) rd(kt);
             if (ROLE == 1) {                                     // fetch A's P of this half early
-#ifdef USP_ABLATE_NOPX
-              pin[h][0] = rf[2 * h]; pin[h][1] = rf[2 * h + 1];
-#else
               pin[h][0] = *(USP_LDS const u32x4*)(pslot + (2 * h) * 1024);
               pin[h][1] = *(USP_LDS const u32x4*)(pslot + (2 * h + 1) * 1024);
-#endif
             }
             if (ROLE == 0 && vh >= 0) load_stats(vh);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt) {
-              if (kt + USP_DKDV_PF < NKT) rd(kt + USP_DKDV_PF);
+              if (kt + PF < NKT) rd(kt + PF);
               sc[h] = E::mfma(f[kt], rf[kt], kt == 0 ? c0 : sc[h]);
               if (vh >= 0) {
 #pragma unroll
                 for (int e = kt * 16 / NKT; e < (kt + 1) * 16 / NKT; ++e) elem(vh, e);
               }
-              if (kt % USP_BWD_G == USP_BWD_G - 1) __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_sched_barrier(0);
             }
           };
           auto grad_phase = [&](int h, int vh) {
@@ -838,27 +673,23 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
             auto rd = [&](int i) {
               const int k2 = i / NDJ, dj = i % NDJ;
               USP_LDS const char* xb = xg + (2 * h + k2) * 16 * ROWB;
-#ifdef USP_ABLATE_DKDV_NOLDS
-              xa[i] = rf[(i + dj) % NKT]; (void)xb;
-#else
               const u32x2 a0 = lds_read_tr16(xb + tr_addr[dj][0]);
               const u32x2 a1 = lds_read_tr16(xb + tr_addr[dj][1]);
               xa[i] = u32x4{a0[0], a0[1], a1[0], a1[1]};
-#endif
             };
 #pragma unroll
-            for (int i = 0; i < USP_DKDV_PF && i < NGR; ++i) rd(i);
+            for (int i = 0; i < PF && i < NGR; ++i) rd(i);
             if (ROLE == 0 && vh >= 0) load_stats(vh);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NGR; ++i) {
-              if (i + USP_DKDV_PF < NGR) rd(i + USP_DKDV_PF);
+              if (i + PF < NGR) rd(i + PF);
               acc[i % NDJ] = E::mfma(xa[i], pk[h][i / NDJ], acc[i % NDJ]);
               if (vh >= 0) {
 #pragma unroll
                 for (int e = i * 16 / NGR; e < (i + 1) * 16 / NGR; ++e) elem(vh, e);
               }
-              if (i % USP_BWD_G == USP_BWD_G - 1) __builtin_amdgcn_sched_barrier(0);
+              __builtin_amdgcn_sched_barrier(0);
             }
           };
           auto apply_mask = [&](int h) {                         // role A only: query row i sees key j iff j <= i + off
@@ -876,60 +707,12 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
             }
           };
 
-#ifdef USP_DKDV_CHAIN2
-          // Both halves' chains as ONE phase, alternating between the two accumulators: consecutive MFMAs never depend on
-          // each other (a chain of eight MFMAs on one accumulator issues at the dependent-accumulate latency, not at the
-          // pipe's 32 cycles, as soon as anything sits between them -- MI355X_MICROARCH.md, "one extra issue slot between
-          // two MFMAs on the same accumulator").  The element work of half 0 then runs bare, half 1's under grad(0).
-          {
-            u32x4 f0[NKT], f1[NKT];
-            auto rd = [&](int kt) {
-              USP_LDS const char* a = xs + rd_row + (((2 * kt) ^ rd_x) * 16);
-              f0[kt] = *(USP_LDS const u32x4*)a;
-              f1[kt] = *(USP_LDS const u32x4*)(a + 32 * ROWB);
-            };
-            f32x16 c0 = zero16, c1 = zero16;
-            if (ROLE == 1) {
-              load_stats(0);
-#pragma unroll
-              for (int r = 0; r < 16; ++r) c0[r] = stq[r >> 2][r & 3];
-              load_stats(1);
-#pragma unroll
-              for (int r = 0; r < 16; ++r) c1[r] = stq[r >> 2][r & 3];
-            }
-            rd(0);
-            if (NKT > 1) rd(1);
-            if (ROLE == 1) {
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                pin[h][0] = *(USP_LDS const u32x4*)(pslot + (2 * h) * 1024);
-                pin[h][1] = *(USP_LDS const u32x4*)(pslot + (2 * h + 1) * 1024);
-              }
-            }
-            if (ROLE == 0) load_stats(0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-              if (kt + 2 < NKT) rd(kt + 2);
-              sc[0] = E::mfma(f0[kt], rf[kt], kt == 0 ? c0 : sc[0]);
-              __builtin_amdgcn_sched_barrier(0);
-              sc[1] = E::mfma(f1[kt], rf[kt], kt == 0 ? c1 : sc[1]);
-              __builtin_amdgcn_sched_barrier(0);
-            }
-          }
-          if (ROLE == 0 && need_mask) { apply_mask(0); apply_mask(1); }
-#pragma unroll
-          for (int e = 0; e < 16; ++e) elem(0, e);
-          grad_phase(0, 1);
-          grad_phase(1, -1);
-#else
           chain_phase(0, -1);
           if (ROLE == 0 && need_mask) apply_mask(0);
           chain_phase(1, 0);
           if (ROLE == 0 && need_mask) apply_mask(1);
           grad_phase(0, 1);
           grad_phase(1, -1);
-#endif
         }
       }
 
@@ -937,9 +720,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
       buf_b = buf_a;
       buf_a = buf_n;
       dma_drain();            // this wave's DMA pieces of the staged tile have landed (usp_common.hpp)
-#ifndef USP_ABLATE_DKDV_NOBAR
       __syncthreads();
-#endif
     }
 
   };
@@ -1083,14 +864,8 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
     }
   }
   if (!dkdv_done) {
-#ifdef USP_BWD_LEGACY   // A/B builds only: the single-role dK/dV formulation (MODE 1 of flash_bwd_kernel, 1.42 ms at C2)
-  constexpr size_t lds1 = 2 * (2 * kTile * D * 2 + 2 * kTile * 4);
-  p.sched_lds = (int)lds1;
-  if (causal)
-    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 1>), dim3(grid), dim3(256), lds1 + qx, st, p);
-  else
-    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 1>), dim3(grid), dim3(256), lds1 + qx, st, p);
-#else
+    // the 8-wave dK/dV kernel addresses the Q / dO tiles of a head by a 32-bit byte offset from the head's first row
+    if ((int64_t)p.Sq * p.q_ss * 2 >= (1LL << 31) || (int64_t)p.Sq * p.do_ss * 2 >= (1LL << 31)) return USP_EUNSUPPORTED;
   {
     constexpr size_t lds2 = 3 * (2 * kTile * D * 2 + 2 * kTile * 4) + 4 * 2 * 4096;
     p.sched_lds = (int)lds2;
@@ -1099,7 +874,6 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
     else
       hipLaunchKernelGGL((flash_bwd_dkdv_kernel<D, DT, false>), dim3(grid), dim3(512), lds2 + qx, st, p);
   }
-#endif
   }
   if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
   if (p.split) {
@@ -1115,9 +889,9 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   grid = (pers && p.n_items > cus) ? cus : p.n_items;
   p.sched_lds = (int)lds0;
   if (causal)
-    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true, 0>), dim3(grid), dim3(512), lds0 + qx, st, p);
+    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, true>), dim3(grid), dim3(512), lds0 + qx, st, p);
   else
-    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false, 0>), dim3(grid), dim3(512), lds0 + qx, st, p);
+    hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false>), dim3(grid), dim3(512), lds0 + qx, st, p);
   if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
   if (p.ksplit > 1) {            // same stream: the partials are complete when this starts
     const int64_t items = (int64_t)p.B * p.Sq * p.Hq * (D / 4);
@@ -1186,9 +960,6 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   const int wr = a->causal ? 0 : (has_win ? a->window_right : -1);
   if ((a->seq_q || a->seq_k) && (wl >= 0 || wr > 0)) return USP_EUNSUPPORTED;       // dense launches only
   if (a->dq_splits < 0 || a->dq_splits > 8 || a->dkdv_splits < 0 || a->dkdv_splits > 8) return USP_EINVAL;
-  // the dK/dV kernel addresses the Q / dO tiles of a head by a 32-bit byte offset from the head's first row
-  if ((int64_t)a->Sq * a->q.stride_s * 2 >= (1LL << 31) || (int64_t)a->Sq * a->dout.stride_s * 2 >= (1LL << 31))
-    return USP_EUNSUPPORTED;
   BwdParams p;
   p.dout = (const char*)a->dout.ptr; p.q = (const char*)a->q.ptr;
   p.k = (const char*)a->k.ptr; p.v = (const char*)a->v.ptr;

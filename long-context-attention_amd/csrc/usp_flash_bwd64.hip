@@ -145,11 +145,11 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
                                                   // over a GQA group's heads to the 8-wave kernel)
 
   // ---- LDS-DMA staging of the Q / dO tiles: running cursors (base pointer + remaining bytes, advanced per tile) -------
-  const int tb1 = kTile * (int)p->q_ss * 2, tb2 = kTile * (int)p->do_ss * 2;     // bytes per tile step
+  const int64_t tb1 = (int64_t)kTile * p->q_ss * 2, tb2 = (int64_t)kTile * p->do_ss * 2;     // bytes per tile step
   int q_step = 4 * (int)p->q_ss * 2 - 1024, do_step = 4 * (int)p->do_ss * 2 - 1024;
   int lds_w = wave * 4096;
   const char *q_cur = nullptr, *do_cur = nullptr;
-  int q_rem = 0, do_rem = 0;
+  int64_t q_rem = 0, do_rem = 0;
   const float *lse_h = nullptr, *dl_h = nullptr;                               // row statistics of the item's head
   int st_row = 0;                                                             // first row of the cursor's tile
   float st_lse = 0.f, st_delta = 0.f;
@@ -157,10 +157,10 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   const bool stat_wave = wave == 2;              // a role-B wave stages the tile's statistics: role A is the longer stream
   {                                              // base the cursors on head h0, tile t_begin
     const int h = h0;
-    q_cur = p->q + 2 * (b * p->q_sb + h * p->q_sh) + (int64_t)t_begin * tb1;
-    do_cur = p->dout + 2 * (b * p->do_sb + h * p->do_sh) + (int64_t)t_begin * tb2;
-    q_rem = ((p->Sq - 1) * (int)p->q_ss + D) * 2 - t_begin * tb1;
-    do_rem = ((p->Sq - 1) * (int)p->do_ss + D) * 2 - t_begin * tb2;
+    q_cur = p->q + 2 * (b * p->q_sb + h * p->q_sh) + t_begin * tb1;
+    do_cur = p->dout + 2 * (b * p->do_sb + h * p->do_sh) + t_begin * tb2;
+    q_rem = ((int64_t)(p->Sq - 1) * p->q_ss + D) * 2 - t_begin * tb1;
+    do_rem = ((int64_t)(p->Sq - 1) * p->do_ss + D) * 2 - t_begin * tb2;
     lse_h = p->lse + b * p->lse_sb + h * p->lse_sh;
     dl_h = p->delta + b * p->dl_sb + h * p->dl_sh;
     st_row = t_begin * kTile;
@@ -458,10 +458,11 @@ bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st
   // loop and reads one of them right behind its MFMA (tools/mfma_hazards.py: 22 hazards) -- served by the 8-wave kernel
   if (dtype != USP_BF16) return false;
   if (!p_in.split && p_in.G > 1) return false;   // the in-workgroup loop over a GQA group's heads stays with the 8-wave kernel
-  // the Q / dO cursors count remaining bytes in 32 bits; the pieces' swizzle is XORed into the per-lane byte offset
-  if (((int64_t)(p_in.Sq - 1) * p_in.q_ss + 128) * 2 >= (1LL << 31) || ((int64_t)(p_in.Sq - 1) * p_in.do_ss + 128) * 2 >= (1LL << 31))
+  // the pieces' swizzle is XORed into the per-lane byte offset (row part a multiple of 256 bytes); per-lane offsets and the
+  // pieces' scalar offsets are 32-bit: 64 rows of Q / dO must span less than 2^31 bytes.  (Base pointer and remaining
+  // bytes are 64-bit: no sequence length is refused -- the 8-wave kernel addresses a head by a 32-bit offset and is.)
+  if ((p_in.q_ss * 2) % 256 != 0 || (p_in.do_ss * 2) % 256 != 0 || p_in.q_ss * 128 >= (1LL << 31) || p_in.do_ss * 128 >= (1LL << 31))
     return false;
-  if ((p_in.q_ss * 2) % 256 != 0 || (p_in.do_ss * 2) % 256 != 0) return false;
   BwdParams p = p_in;
   p.nblk = (p.Sk + 127) / 128;
   p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1) * p.qsplit;

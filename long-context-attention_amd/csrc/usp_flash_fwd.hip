@@ -381,43 +381,23 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdArgs
   // one pipelined iteration: softmax + PV of tile jj (scores in ca/cb), scores of tile jj+1 into na/nb
   auto iter = [&](int jj, f32x16& ca, f32x16& cb, f32x16& na, f32x16& nb) {
     const int jk = jj + 2 < nt ? jj + 2 : nt - 1;           // clamped prefetch (redundant load at the end)
-#ifndef USP_ABLATE_NOSTAGE
     dma_k(jk, jj & 1);            // Kbuf[jj&1] held K(jj): last read in the previous iteration
     dma_v(jj + 1, (jj + 1) & 1);  // Vbuf[(jj+1)&1] held V(jj-1): last read in the previous iteration
-#endif
     // ---------------- phase A ----------------
     USP_LDS const char* kb = smem + ((jj + 1) & 1) * KBYTES + k_rd_row;
     u32x4 ka[NKT], kc[NKT];
     auto rd_k = [&](int kt) {
       const int slot = ((2 * kt) ^ k_rd_x) * 16;
-#ifdef USP_ABLATE_NOLDS
-      ka[kt] = qf[kt]; kc[kt] = qf[(kt + 1) % NKT]; (void)slot;
-#else
       ka[kt] = *(USP_LDS const u32x4*)(kb + slot);
       kc[kt] = *(USP_LDS const u32x4*)(kb + 32 * ROWB + slot);
-#endif
     };
-#ifndef USP_PF
-#define USP_PF 2
-#endif
-#ifndef USP_FWD_G      // MFMA slots per pinned scheduling group (A/B builds; 1 = every slot fenced)
-#define USP_FWD_G 1
-#endif
-    constexpr int PF = USP_PF;                                  // LDS fragment prefetch distance (k-steps / MFMAs)
+    constexpr int PF = 2;                                       // LDS fragment prefetch distance (k-steps / MFMAs)
 #pragma unroll
     for (int t = 0; t < PF && t < NKT; ++t) rd_k(t);
     float rs = 0.f;
     u32x4 pf[4];
     // element e of the tile's 32 scores: e < 16 -> ca[e], else cb[e - 16]
     auto exp_elem = [&](int e) {
-#ifdef USP_ABLATE_NOEXP
-      if (e & 1) {
-        const int r = (e & 15) - 1;
-        if (e < 16) pf[r >> 3][(r & 7) >> 1] = __builtin_bit_cast(uint32_t, ca[r]);
-        else pf[2 + (r >> 3)][(r & 7) >> 1] = __builtin_bit_cast(uint32_t, cb[r]);
-      }
-      return;
-#endif
       // The consumers of an exp2 result run ONE ELEMENT LATE (the row-sum add of element e-1 and the pack of the pair
       // (e-2, e-1) are issued with element e): nothing waits for the transcendental it was just issued behind.
       auto P = [&](int i) -> float { return i < 16 ? ca[i] : cb[i - 16]; };
@@ -441,22 +421,15 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdArgs
     auto rd_v = [&](int i) {                                  // i = ks * NDJ + dj
       const int ks = i / NDJ, dj = i % NDJ;
       USP_LDS const char* vp = vb + (4 * ks * NDJ + dj) * 256;
-#ifdef USP_ABLATE_NOLDS
-      va[i] = qf[i % NKT]; (void)vp;
-#else
       const u32x2 v0 = lds_read_tr16(vp);
       const u32x2 v1 = lds_read_tr16(vp + 2 * NDJ * 256);
       va[i] = u32x4{v0[0], v0[1], v1[0], v1[1]};
-#endif
     };
     // The first MFMA of the phase waits for the K fragments read just above (K(jj+1) is only guaranteed behind the
     // barrier): the first slice of exp work goes IN FRONT of it, every later slice behind the MFMA before it; the V
     // fragments of phase B's first MFMAs are read behind phase A's last ones (V(jj) has been resident since the
     // previous barrier), so phase B starts without an LDS round trip.
-#ifndef USP_FWD_LEAD   // exp elements issued in front of the first MFMA of phase A (A/B builds)
-#define USP_FWD_LEAD (24 / NA)
-#endif
-    constexpr int LEAD = USP_FWD_LEAD < 24 ? USP_FWD_LEAD : 24;
+    constexpr int LEAD = 24 / NA;        // exp elements issued in front of the first MFMA of phase A
 #pragma unroll
     for (int e = 0; e < LEAD; ++e) exp_elem(e);
     __builtin_amdgcn_sched_barrier(0);
@@ -474,7 +447,7 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdArgs
         for (int e = LEAD + sl * (24 - LEAD) / (NA - 1); e < LEAD + (sl + 1) * (24 - LEAD) / (NA - 1); ++e) exp_elem(e);
       }
       if (sl >= NA - PF && sl - (NA - PF) < NB) rd_v(sl - (NA - PF));
-      if (sl % USP_FWD_G == USP_FWD_G - 1) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     // ---------------- phase B ----------------
     float mt = USP_NEG_INF;
@@ -490,20 +463,14 @@ __global__ __launch_bounds__(64 * NWAVES, 2) void flash_fwd_kernel(const FwdArgs
       } else {                                                // row-max chain of S(jj+1), second half of the phase
 #pragma unroll
         for (int e = (i - NB / 2) * 64 / NB; e < (i - NB / 2 + 1) * 64 / NB; ++e)
-#ifdef USP_ABLATE_NOMAX
-          ;
-#else
           mt = fmaxf(mt, e < 16 ? na[e] : nb[e - 16]);
-#endif
         if (i == NB - 1) keep = __all(mt <= m_thr);           // decided behind the last MFMA, not after it
       }
-      if (i % USP_FWD_G == USP_FWD_G - 1) __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (!keep) rescale(mt);
-#ifndef USP_ABLATE_NOBARRIER
     dma_drain();                 // this wave's pieces of K(jj+2), V(jj+1) have landed ...
     __syncthreads();             // ... and so have everybody else's
-#endif
   };
 
   if (n_main > 0) {

@@ -154,12 +154,12 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   // exactly once per loop iteration (also past the last tile the item needs: rows >= Sk read as 0 through num_records,
   // a surplus tile inside the tensor is fetched and ignored), so the descriptor of the next tile is the previous one
   // advanced by two scalar additions -- no per-tile 64-bit multiplies, no clamps (the head of an iteration is otherwise
-  // ~100 scalar instructions that nothing hides at one wave per SIMD).  The host guarantees that one head's K / V rows
-  // span less than 2^31 bytes (launch_fwd64), so the remaining-bytes counter is a 32-bit scalar.
-  const int k_tb = kBN * (int)p->k_ss * 2, v_tb = kBN * (int)p->v_ss * 2;          // bytes per tile step
+  // ~100 scalar instructions that nothing hides at one wave per SIMD).  Base and remaining bytes are 64-bit scalars: no
+  // sequence length or stride is refused.
+  const int64_t k_tb = (int64_t)kBN * p->k_ss * 2, v_tb = (int64_t)kBN * p->v_ss * 2;   // bytes per tile step
   const char* k_cur = p->k + 2 * (b * p->k_sb + hkv * p->k_sh);
   const char* v_cur = p->v + 2 * (b * p->v_sb + hkv * p->v_sh);
-  int k_rem = ((p->Sk - 1) * (int)p->k_ss + D) * 2, v_rem = ((p->Sk - 1) * (int)p->v_ss + D) * 2;
+  int64_t k_rem = ((int64_t)(p->Sk - 1) * p->k_ss + D) * 2, v_rem = ((int64_t)(p->Sk - 1) * p->v_ss + D) * 2;
   // (lds_w / k_step / v_step pass through an opaque asm at every use: hipcc otherwise hoists the sixteen M0 values and the
   // six scalar offsets of the pieces out of the loops as invariants and then SPILLS them -- a v_readlane plus five wait
   // states in front of every LDS-DMA; computed at the use each is one s_add / s_lshl / s_mul)
@@ -529,10 +529,9 @@ bool launch_fwd64(const FwdParams& p_in, int dtype, bool causal, hipStream_t st,
       n = 256;
     return n;
   }();
-  // the kernel's K / V cursors count remaining bytes in 32 bits
-  if (((int64_t)(p_in.Sk - 1) * p_in.k_ss + 128) * 2 >= (1LL << 31) || ((int64_t)(p_in.Sk - 1) * p_in.v_ss + 128) * 2 >= (1LL << 31))
-    return false;
-  if ((p_in.k_ss * 2) % 256 != 0) return false;        // the K pieces' swizzle is XORed into the per-lane byte offset
+  // the K pieces' swizzle is XORed into the per-lane byte offset (row part a multiple of 256 bytes); per-lane offsets and the
+  // pieces' scalar offsets are 32-bit: 64 rows of K / V must span less than 2^31 bytes
+  if ((p_in.k_ss * 2) % 256 != 0 || p_in.k_ss * 128 >= (1LL << 31) || p_in.v_ss * 128 >= (1LL << 31)) return false;
   FwdArgsT<false> p;
   static_cast<FwdParams&>(p) = p_in;
   p.nq = (p.Sq + 255) / 256;

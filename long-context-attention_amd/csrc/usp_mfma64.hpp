@@ -78,9 +78,13 @@ USP_DEV void lds_dma4_asm(const u32x4& rsrc, int lds_dst, int voffset) {
                : : "s"(lds_dst), "v"(voffset), "s"(rsrc) : "memory");
 #endif
 }
-USP_DEV u32x4 make_rsrc(const char* base, int bytes) {
+// Raw buffer descriptor over `bytes` bytes from `base`; `bytes` is a running 64-bit remainder (negative: nothing left,
+// every lane reads 0; beyond 32 bits: the whole 4 GiB window -- a tile never reaches that far, so the clamp is exact for
+// everything a piece can address).  No tensor size is refused because of 32-bit byte arithmetic.
+USP_DEV u32x4 make_rsrc(const char* base, int64_t bytes) {
   const uint64_t a = (uint64_t)base;
-  return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)(bytes > 0 ? bytes : 0), 0x00020000u};
+  const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xffffffffLL ? 0xffffffffu : (uint32_t)bytes);
+  return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, n, 0x00020000u};
 }
 
 }  // namespace usp

@@ -63,9 +63,12 @@ def set_seq_parallel_pg(sp_ulysses_degree, sp_ring_degree, rank, world_size, use
     PROCESS_GROUP.RING_PG = ring_pg
     from .comm import relay_exchange
     relay_exchange.GRID = (sp_ulysses_degree, sp_ring_degree, world_size, bool(use_ulysses_low))      # who is whose peer
-    # every rank is here by contract: the one collective moment to measure what the schedules size themselves by
+    # every rank is here by contract: the one collective moment to measure what the schedules size themselves by --
+    # opt-in (USP_LINK_PROBE=1, comm/link.py): a reference-style script must not meet a hidden collective here
     from .comm.link import probe_link_rate
     probe_link_rate(rank, world_size)
+    from .ring.utils import forget_groups
+    forget_groups()                 # (size, rank) cache of process groups: a re-initialised grid starts empty
 
 
 # Feature flags of the reference (globals.py:83-135), kept so `from yunchang.globals import HAS_*`

@@ -55,6 +55,13 @@ def update_out_and_lse(out: Optional[torch.Tensor], lse: Optional[torch.Tensor],
 _GROUP_INFO = {}
 
 
+def forget_groups():
+    """Drop the cached (size, rank) pairs -- and with them the strong references to the ProcessGroup objects they are
+    keyed by.  Called by set_seq_parallel_pg: after destroy_process_group + re-init (tests, elastic restarts) the old
+    groups and their communicators must be collectable."""
+    _GROUP_INFO.clear()
+
+
 def group_info(dist_mod, process_group):
     """(size, this rank) of a process group.  A group's shape never changes, so torch.distributed is asked once per
     group object (two python-level lookups per launch otherwise, ~10 us of the N = 1 step's 65, tools/host_step_cpu.py).

@@ -18,7 +18,7 @@ import sys
 import tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-ROOFLINE_KERNEL = r"flash_fwd_kernel<128, 0, true, 8(, false)?>"      # D = 128, bf16, causal, 8 waves, plain
+ROOFLINE_KERNEL = r"flash_fwd64_kernel<0, true>"      # the 4 x 64-row forward, bf16, causal (the N=1 roofline kernel)
 
 
 def _disassemble(lib):
@@ -64,10 +64,10 @@ def _sha16(lines):
 
 
 def isa_identity(lib):
-    """(sha16 of the roofline kernel's instruction stream, sha16 over all plain forward kernels, #plain kernels)."""
+    """(sha16 of the roofline kernel's instruction stream, sha16 over all plain 8 / 4-wave forward kernels, their number)."""
     ks = _disassemble(lib)
     plain = {n: b for n, b in ks.items() if re.search(r"usp::flash_fwd_kernel<\d+, \d, (true|false), \d(, false)?>", n)}
-    roof = [b for n, b in plain.items() if re.search(ROOFLINE_KERNEL, n)]
+    roof = [b for n, b in ks.items() if re.search(ROOFLINE_KERNEL, n)]
     if len(roof) != 1:
         raise RuntimeError(f"roofline kernel not found (or ambiguous) in {lib}: {len(roof)} matches")
     allp = []
@@ -77,8 +77,12 @@ def isa_identity(lib):
 
 
 if __name__ == "__main__":
-    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+    lib = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                              "long-context-attention_amd", "libusp_hip.so")
     r, a, n = isa_identity(lib)
     print(f"roofline_kernel_isa_sha16: {r}")
     print(f"plain_forward_kernels_isa_sha16: {a}  ({n} kernels)")
+    if "--all" in sys.argv:                      # every flash kernel of the library, one line each (refactoring proofs)
+        for name, body in sorted(_disassemble(lib).items()):
+            if "flash_" in name and "kernel" in name:
+                print(f"{_sha16(body)}  {len(body):6d}  {name[:110]}")
