@@ -70,10 +70,16 @@ static void fill(std::vector<uint16_t>& bits, std::vector<float>& vals, size_t n
   for (size_t i = 0; i < n; ++i) { bits[i] = enc(r.normal() * scale, dt); vals[i] = dec(bits[i], dt); }
 }
 
+// Every uploaded tensor is followed by kPoisonTail bytes of 0xff (NaN in bf16, fp16 and fp32): a kernel whose bounds handling
+// lets a lane read past the last valid row -- a descriptor clamp that does not cover the scalar offset of a piece, a ragged
+// tail tile -- multiplies a NaN into its result instead of whatever the allocator left behind the buffer, and every CHECK
+// of the suite (they all count NaN as bad) becomes a bounds test.
+static const size_t kPoisonTail = 1 << 20;
 template <typename T> static T* dev_upload(const std::vector<T>& h) {
-  T* d; HIP_OK(hipMalloc(&d, h.size() * sizeof(T)));
+  char* d; HIP_OK(hipMalloc(&d, h.size() * sizeof(T) + kPoisonTail));
+  HIP_OK(hipMemset(d + h.size() * sizeof(T), 0xff, kPoisonTail));
   HIP_OK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
-  return d;
+  return (T*)d;
 }
 template <typename T> static T* dev_alloc(size_t n, int fillbyte = 0xff) {
   T* d; HIP_OK(hipMalloc(&d, n * sizeof(T)));

@@ -28,6 +28,12 @@
 
 namespace usp {
 
+#ifndef USP_B64_STATW
+#define USP_B64_STATW 0
+#endif
+#ifndef USP_B64_DMA_PH
+#define USP_B64_DMA_PH 0     // phase whose odd slots carry the next tile's DMA pieces (0: first chain)
+#endif
 #ifndef USP_B64_E0       // first and one-past-last slot of the element stream (64 elements; chain(h0) ends at 16, the
 #define USP_B64_E0 16    // gradient MFMAs of k-step (h, k2) start at 32 + 16 h + 8 k2)
 #endif
@@ -50,7 +56,10 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   constexpr int NKT = D / 16, NDJ = D / 32;
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  USP_LDS char* smem = (USP_LDS char*)smem_raw;
+  // The dynamic LDS block is the kernel's only LDS object: it starts at LDS address 0.  Addresses are formed from that
+  // integer, not from the symbol -- hipcc does not fold the symbol's value and spends a v_add (of 0) per address on it.
+  if ((uint32_t)(uintptr_t)(USP_LDS char*)smem_raw != 0u) __builtin_trap();
+  USP_LDS char* smem = (USP_LDS char*)(uintptr_t)0;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -71,6 +80,9 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   const int dma_row = 16 * wave + (lane >> 4);
   const int dma_c8 = ((lane & 15) ^ ((lane >> 4) << 2)) * 16;
   const int q_voff = dma_row * (int)p->q_ss * 2 + dma_c8, do_voff = dma_row * (int)p->do_ss * 2 + dma_c8;
+  int q_vo[4], do_vo[4];                         // per-lane offsets of the four pieces (kept in registers: lane constants)
+#pragma unroll
+  for (int n = 0; n < 4; ++n) { q_vo[n] = q_voff ^ (16 * n); do_vo[n] = do_voff ^ (16 * n); }
   // row read (A operand of the S / dP chain): tile row 32h + l31, logical slot 2t + hi; the swizzle does not depend on h
   const int rd_base = l31 * ROWB + ((hi ^ tile_swz<D>(l31)) * 16);            // ^ (32 t), + h * 32 * ROWB
   // transpose read (A operand of the gradient MFMAs) for dim tile dj, element half e, k-step ks: the 16-lane group reads
@@ -130,6 +142,23 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
 #endif
   }
 
+  // Role A's K fragments are pre-multiplied by scale * log2(e) (rounded to the 16-bit type once per item), so that the S
+  // chain, started from -lse * log2(e), ends in the exponent itself: P = exp2(chain) with no per-element multiply-add.
+  // Role B runs the same code with factor 1 (exact): no branch around registers the asm statements own.
+  {
+    const float kf = role == 0 ? p->scale_log2 : 1.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int t = 0; t < NKT; ++t) {
+        u32x4 x = rf[kb][t];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = E::pack2(E::lo(x[e]) * kf, E::hi(x[e]) * kf);
+        rf[kb][t] = x;
+        pin_agpr4(rf[kb][t]);
+      }
+  }
+
   int t_begin = 0, t_end = (p->Sq + kTile - 1) / kTile;
   if (CAUSAL) {
     const int first_q = own0 - off > 0 ? own0 - off : 0;
@@ -149,18 +178,18 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   int q_step = 4 * (int)p->q_ss * 2 - 1024, do_step = 4 * (int)p->do_ss * 2 - 1024;
   int lds_w = wave * 4096;
   const char *q_cur = nullptr, *do_cur = nullptr;
-  int64_t q_rem = 0, do_rem = 0;
+  int rows_left = 0;                             // valid rows from the cursor's tile on (<= 0: nothing left, lanes read 0)
+  const int q_rowb = (int)p->q_ss * 2, do_rowb = (int)p->do_ss * 2;
   const float *lse_h = nullptr, *dl_h = nullptr;                               // row statistics of the item's head
   int st_row = 0;                                                             // first row of the cursor's tile
   float st_lse = 0.f, st_delta = 0.f;
   bool st_in = false;
-  const bool stat_wave = wave == 2;              // a role-B wave stages the tile's statistics: role A is the longer stream
+  const bool stat_wave = wave == USP_B64_STATW;  // the wave that stages the tile's statistics: role A has the shorter stream
   {                                              // base the cursors on head h0, tile t_begin
     const int h = h0;
     q_cur = p->q + 2 * (b * p->q_sb + h * p->q_sh) + t_begin * tb1;
     do_cur = p->dout + 2 * (b * p->do_sb + h * p->do_sh) + t_begin * tb2;
-    q_rem = ((int64_t)(p->Sq - 1) * p->q_ss + D) * 2 - t_begin * tb1;
-    do_rem = ((int64_t)(p->Sq - 1) * p->do_ss + D) * 2 - t_begin * tb2;
+    rows_left = p->Sq - t_begin * kTile;
     lse_h = p->lse + b * p->lse_sb + h * p->lse_sh;
     dl_h = p->delta + b * p->dl_sb + h * p->dl_sh;
     st_row = t_begin * kTile;
@@ -171,11 +200,12 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   // runs inside the MFMA stream.  EVERY memory operation of the loop is issued from asm: a load hipcc can see makes it
   // guard the LDS reads that follow with vmcnt waits, which drain the DMA queue in the middle of the tile.
   auto dma_open = [&](int buf) {
-    q_rs = make_rsrc(q_cur, q_rem);
-    do_rs = make_rsrc(do_cur, do_rem);
+    q_rs = make_rsrc_rows(q_cur, rows_left, kTile, q_rowb, 2 * D);
+    do_rs = make_rsrc_rows(do_cur, rows_left, kTile, do_rowb, 2 * D);
     dma_buf = buf;
-    q_cur += tb1; q_rem -= tb1;
-    do_cur += tb2; do_rem -= tb2;
+    q_cur += tb1;
+    do_cur += tb2;
+    rows_left -= kTile;
   };
   // the statistics wave fetches the 2 x 64 row statistics of the cursor's tile (raw, one row per lane) in front of the
   // stream ...
@@ -191,17 +221,25 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
     st_row += kTile;
   };
   // piece n of the opened tile: n < 4 -> Q piece n, else dO piece n - 4
+  bool dma_live = true;     // dev A/B builds only (USP_B64_ABL_*): timing experiments that keep REAL tiles in LDS
   auto dma_piece = [&](int n) {
+#ifdef USP_B64_ABL_NODMA
+    if (!dma_live) return;
+#endif
     asm volatile("" : "+s"(lds_w), "+s"(q_step), "+s"(do_step));
-    if (n < 4) lds_dma16_asm(q_rs, lds_w + dma_buf * BUFB, q_voff ^ (16 * n), n * q_step, n);
-    else lds_dma16_asm(do_rs, lds_w + dma_buf * BUFB + TILEB, do_voff ^ (16 * (n - 4)), (n - 4) * do_step, n - 4);
+#ifdef USP_B64_ABL_HALFDMA
+    if (!dma_live && n >= 4) return;
+#endif
+    if (n < 4) lds_dma16_asm(q_rs, lds_w + dma_buf * BUFB, q_vo[n], n * q_step, n);
+    else lds_dma16_asm(do_rs, lds_w + dma_buf * BUFB + TILEB, do_vo[n - 4], (n - 4) * do_step, n - 4);
   };
-  // ... and behind the wave's vmcnt(0) at the end of the iteration stores what the roles consume: lse * log2(e) (+inf for
-  // a row without visible keys: P = 0) and -delta (role B folds it into the dP chain as the C operand)
+  // ... and behind the wave's vmcnt(0) at the end of the iteration stores what the roles consume, the constants their
+  // chains START from (the C operand of a chain's first MFMA): -lse * log2(e) for role A (-inf for a row without visible
+  // keys: P = 0) and -delta for role B
   auto stats_store = [&](int buf) {
     if (stat_wave) {
       asm volatile("" : "+v"(st_lse), "+v"(st_delta));         // (written by the asm loads above, complete behind dma_drain)
-      const float l2 = (st_in && st_lse != USP_NEG_INF) ? st_lse * kLog2e : __builtin_inff();
+      const float l2 = (st_in && st_lse != USP_NEG_INF) ? -st_lse * kLog2e : -__builtin_inff();
       *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * lane) = l2;
       *(USP_LDS float*)(smem + buf * BUFB + 2 * TILEB + 4 * kTile + 4 * lane) = st_in ? -st_delta : 0.f;
     }
@@ -216,7 +254,6 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
       for (int r = 0; r < 16; ++r) acc[kb][dj][r] = 0.f;
       pin_agpr(acc[kb][dj]);
     }
-  const float c = p->scale_log2;
 
   stats_fetch();
   dma_open(0);
@@ -240,16 +277,42 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
     n_mask = tm - t_begin < 0 ? 0 : (tm - t_begin > n_iter ? n_iter : tm - t_begin);
   }
   int tile_cur = t_begin, buf_a = 0, buf_b = NBUF - 1;     // role A's tile / LDS buffers of A's and B's tiles
+#ifdef USP_B64_TIMING
+  uint64_t tm_body = 0, tm_drain = 0, tm_bar = 0, tm_last = __builtin_amdgcn_s_memtime();
+#endif
+  // Role B works one tile behind role A: the tile it takes NEXT was published a whole iteration ago, so the operands of
+  // its first chain (dO row fragments, -delta) are read in the bare slots at the END of the iteration in front -- ahead of
+  // the barrier, not behind it, where a lone wave would sit out the LDS round trip with the matrix pipe idle.
+  u32x4 fc0[NKT];
+  f32x16 cst0;
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) fc0[kt] = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) cst0[r] = 0.f;
   // one iteration: [prefetch the next tile] [the tile body of this role] [publish]
+#if defined(USP_B64_ABL_NODMA) || defined(USP_B64_ABL_HALFDMA)
+  dma_live = false;
+#endif
   auto step = [&](auto role_c, auto mask_c, int it, bool work) __attribute__((always_inline)) {
     constexpr int ROLE = decltype(role_c)::value;
     constexpr bool MASK = decltype(mask_c)::value;
     constexpr int E0 = USP_B64_E0, E1 = USP_B64_E1;
+#ifndef USP_B64_ABL_ANYSLOT    // dev A/B build: elements in slots where their inputs / consumers are not ready (wrong results)
     static_assert(E0 >= 16 && E1 <= 56 && E1 > E0, "");
+#endif
     // the next tile is fetched unconditionally (past the range of the item it is a tile nobody reads; past the end of
     // the tensor its descriptor is empty): no branch around the pieces
     const int buf_n = buf_a + 1 == NBUF ? 0 : buf_a + 1;      // (it + 1) % NBUF
     stats_fetch();
+    // role B's next tile is role A's current one (buffer buf_a)
+    int krn = rd_base + buf_a * BUFB + TILEB;
+    asm volatile("" : "+v"(krn));
+    auto next_c = [&](int kt) { fc0[kt] = *(USP_LDS const u32x4*)(smem + (krn ^ (32 * kt))); };
+    auto next_s = [&](int j) {
+      const f32x4 t = *(USP_LDS const f32x4*)(smem + buf_a * BUFB + 2 * TILEB + 4 * kTile + 16 * hi + 32 * j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) cst0[4 * j + e] = t[e];
+    };
     if (work) {
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)        // the resident fragments STAY in the accumulator file (hipcc otherwise gives some
@@ -260,19 +323,25 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
       const int s0 = (ROLE == 0 ? tile_cur : tile_cur - 1) * kTile;
       USP_LDS const char* x1 = smem + buf * BUFB;              // Q tile
       USP_LDS const char* x2 = x1 + TILEB;                     // dO tile
-      USP_LDS const char* xs = ROLE == 0 ? x1 : x2;            // row-read operand of the S / dP chain
       USP_LDS const char* xg = ROLE == 0 ? x2 : x1;            // transpose-read operand of the gradient
       USP_LDS const char* stat = x1 + 2 * TILEB + (ROLE == 0 ? 0 : 4 * kTile) + 16 * hi;
       USP_LDS char* pslot = pex + (my_it & 1) * PSLOT;
       f32x16 sc[2][2];                                         // S (A) / dP - delta (B): [32-row half][key block]
       u32x4 pk[2][2][2];                                       // packed P (A) / dS (B): [half][key block][k-step]
       u32x4 pin[2][2][2];                                      // role B: P received from A
-      f32x4 stq[2][4];                                         // row statistics of the two halves (4 rows per entry)
-      int kr = rd_base;
+      f32x16 cst[2];                                           // the chains' start constants of the two halves' rows
+      // the buffer base goes INTO the swizzled offset before the XOR (bases are multiples of 256, the XOR touches bits 5-7:
+      // (kr ^ 32t) + base == (kr + base) ^ 32t), so a fragment address is one v_xor, not a v_xor and a v_add
+      int kr = rd_base + buf * BUFB + (ROLE == 0 ? 0 : TILEB);
       asm volatile("" : "+v"(kr));       // opaque per tile: hipcc otherwise hoists the eight kr ^ 32t and keeps them live
-      auto load_stats = [&](int h) {
+      auto load_stats = [&](int h) {             // register r of a 32x32 C tile is row (r & 3) + 8 (r >> 2) + 4 hi
+        if (ROLE == 1 && h == 0) { cst[0] = cst0; return; }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) stq[h][j] = *(USP_LDS const f32x4*)(stat + 128 * h + 32 * j);
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 t = *(USP_LDS const f32x4*)(stat + 128 * h + 32 * j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cst[h][4 * j + e] = t[e];
+        }
       };
       // element n of half h, in the order the gradient k-steps need them: n = 16*k2 + 8*kb + r8 -> sc[h][kb][8*k2 + r8]
       // role A: P = exp2(S*c - lse2); role B: dS = P * (dP - delta) -- the dP chain STARTS from -delta (its C operand)
@@ -280,27 +349,34 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
         const int k2 = n >> 4, kb = (n >> 3) & 1, r = 8 * k2 + (n & 7);
         float val;
         if (ROLE == 0) {
-#ifdef USP_B64_ABL_NOEXP   // dev A/B build: role A without the transcendental
-          val = __builtin_fmaf(sc[h][kb][r], c, -stq[h][r >> 2][r & 3]) * 1e-3f;
-#else
-          val = fast_exp2(__builtin_fmaf(sc[h][kb][r], c, -stq[h][r >> 2][r & 3]));
-#endif
+          val = fast_exp2(sc[h][kb][r]);       // the chain computed (K * scale * log2 e) . q - lse * log2 e
         } else {
           const uint32_t wd = pin[h][kb][k2][(r & 7) >> 1];
           val = ((r & 1) ? E::hi(wd) : E::lo(wd)) * sc[h][kb][r];
         }
         sc[h][kb][r] = val;
+      };
+      auto elem_pack = [&](int h, int n) {                      // the odd element of a pair packs it
+        const int k2 = n >> 4, kb = (n >> 3) & 1, r = 8 * k2 + (n & 7);
         if (r & 1) pk[h][kb][k2][(r & 7) >> 1] = E::pack2(sc[h][kb][r - 1], sc[h][kb][r]);
-#ifndef USP_B64_ABL_NOPX   // dev A/B build: no hand-off (B multiplies with stale P)
         if (ROLE == 0 && (r & 7) == 7)                          // 8 elements done: hand one k-step of P to B
           *(USP_LDS u32x4*)(pslot + ((2 * h + kb) * 2 + k2) * 1024) = pk[h][kb][k2];
-#endif
       };
-      // the element stream of the tile: 64 elements (half 0, then half 1) over slots [E0, E1)
+      // the element stream of the tile: 64 elements (half 0, then half 1) over slots [E0, E1).  Role A packs LAG elements
+      // behind the exponentials: a v_cvt_pk straight behind the v_exp that feeds it costs a wait state (trans -> VALU),
+      // which hipcc pads with an s_nop -- an issue slot per pair in the densest part of the stream.
+      constexpr int LAG = ROLE == 0 ? 2 : 0;
       auto elem_slot = [&](int sl) {
         if (sl < E0 || sl >= E1) return;
 #pragma unroll
-        for (int n = (sl - E0) * 64 / (E1 - E0); n < (sl - E0 + 1) * 64 / (E1 - E0); ++n) elem(n >> 5, n & 31);
+        for (int n = (sl - E0) * 64 / (E1 - E0); n < (sl - E0 + 1) * 64 / (E1 - E0); ++n) {
+          elem(n >> 5, n & 31);
+          if (n >= LAG) elem_pack((n - LAG) >> 5, (n - LAG) & 31);
+        }
+        if (sl == E1 - 1) {
+#pragma unroll
+          for (int n = 64 - LAG; n < 64; ++n) elem_pack(n >> 5, n & 31);
+        }
       };
       auto apply_mask = [&](int h) {                            // role A only: query row i sees key j iff j <= i + off
 #pragma unroll
@@ -317,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
       // own fragments are read in one burst behind the barrier that published the tile.
       u32x4 fc[2][NKT];                                        // row-read fragments of the two halves' chains
       u32x4 xa[2][2 * NDJ];                                    // transpose-read fragments of the two halves' gradients
-      auto rd_c = [&](int h, int kt) { fc[h][kt] = *(USP_LDS const u32x4*)(xs + h * 32 * ROWB + (kr ^ (32 * kt))); };
+      auto rd_c = [&](int h, int kt) { fc[h][kt] = *(USP_LDS const u32x4*)(smem + h * 32 * ROWB + (kr ^ (32 * kt))); };
       auto rd_g = [&](int h, int f) {                          // fragment f = NDJ*k2 + dj
         USP_LDS const char* xb = xg + (2 * h + f / NDJ) * 16 * ROWB;
         const u32x2 a0 = lds_read_tr16(xb + tr_addr[f % NDJ][0]);
@@ -326,11 +402,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
       };
       auto chain_init = [&](int h) {                           // statistics; role B: the chains' C operand and A's P
         load_stats(h);
-        if (ROLE == 1) {                                        // -delta of this half's rows: the chains' C operand
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[h][kb][r] = stq[h][r >> 2][r & 3];
+        if (ROLE == 1) {
 #pragma unroll
           for (int kb = 0; kb < 2; ++kb)                        // fetch A's P of this half early
 #pragma unroll
@@ -342,13 +414,16 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
 #pragma unroll
         for (int sl = 0; sl < 16; ++sl) {
           const int kt = sl >> 1, kb = sl & 1;
-          if (ROLE == 0 && kt == 0) M::template s_first<MASK>(sc[h][kb], fc[h][kt], rf[kb][kt]);
+          if (kt == 0) M::template s_first_c<MASK>(sc[h][kb], fc[h][kt], rf[kb][kt], cst[h]);
           else M::template s_next<MASK>(sc[h][kb], fc[h][kt], rf[kb][kt]);
-          if (h == 0 && sl == 0) dma_open(buf_n);       // behind the first MFMA: its scalar work must not idle the matrix pipe
-          if (kb == 0) { if (h == 0) rd_c(1, kt); else rd_g(0, kt); }        // the next phase's fragment kt
+          if (h == USP_B64_DMA_PH && sl == 0) {         // behind the first MFMA: its scalar work must not idle the matrix pipe
+            __builtin_amdgcn_sched_barrier(0);
+            dma_open(buf_n);
+          }
+          if (sl < NKT) { if (h == 0) rd_c(1, sl); else rd_g(0, sl); }       // the next phase's fragments: slots 0 .. 7
           if (h == 0 && sl == 8) chain_init(1);
           elem_slot(16 * h + sl);
-          if (h == 0 && (sl & 1) == 1) dma_piece(sl >> 1);                    // the next tile's 8 pieces: slots 1, 3, .. 15
+          if (h == USP_B64_DMA_PH && (sl & 1) == 1) dma_piece(sl >> 1);      // the next tile's 8 pieces: slots 1, 3, .. 15
           __builtin_amdgcn_sched_barrier(0);
         }
       };
@@ -358,32 +433,63 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
         for (int i = 0; i < 16; ++i) {
           const int f = i >> 1, kb = i & 1;
           M::template o_acc<MASK>(acc[kb][f % NDJ], xa[h][f], pk[h][kb][f / NDJ]);
-          if (h == 0 && kb == 0) rd_g(1, f);                                  // the next phase's fragment f
+          if (h == 0 && i < 2 * NDJ) rd_g(1, i);                              // the next phase's fragments: slots 0 .. 7
+          if (ROLE == 1 && h == 1 && i >= 8) next_c(i - 8);                   // role B: the next tile's first chain
+          if (ROLE == 1 && h == 1 && i >= 4 && i < 8) next_s(i - 4);
+          if (h + 2 == USP_B64_DMA_PH && i == 0) dma_open(buf_n);
+          if (h + 2 == USP_B64_DMA_PH && (i & 1) == 1) dma_piece(i >> 1);
           elem_slot(32 + 16 * h + i);
           __builtin_amdgcn_sched_barrier(0);
         }
       };
       chain_init(0);
+      if (ROLE == 1) {
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) rd_c(0, kt);
+        for (int kt = 0; kt < NKT; ++kt) fc[0][kt] = fc0[kt];
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) rd_c(0, kt);
+      }
       __builtin_amdgcn_sched_barrier(0);
+      // The fragments of a phase were all requested in the first half of the phase in front: ONE s_waitcnt lgkmcnt(0) at the
+      // phase boundary finds them landed, and hipcc then drops the counted wait it otherwise puts in front of every MFMA
+      // that takes a fragment (about twenty issue slots per tile).
       chain_phase(0);
       if (MASK) { mfma_settle(sc[0]); apply_mask(0); }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
       chain_phase(1);
       if (MASK) { mfma_settle(sc[1]); apply_mask(1); }
+      __builtin_amdgcn_s_waitcnt(0xc07f);
       grad_phase(0);
+      __builtin_amdgcn_s_waitcnt(0xc07f);
       grad_phase(1);
     } else {
       dma_open(buf_n);
 #pragma unroll
       for (int n = 0; n < 8; ++n) dma_piece(n);
     }
+    if (ROLE == 1 && !work) {                      // (role B's idle first iteration: the same reads, outside a stream)
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) next_c(kt);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) next_s(j);
+    }
     buf_b = buf_a;
     buf_a = buf_n;
     if (ROLE == 0 || it > 0) ++tile_cur;           // (role B enters its first tile one iteration late)
+#ifdef USP_B64_TIMING        // dev build: where an iteration's time goes (shader cycles, summed per wave; printed for a few waves)
+    const uint64_t tm0 = __builtin_amdgcn_s_memtime();
+    dma_drain();
+    const uint64_t tm1 = __builtin_amdgcn_s_memtime();
+    stats_store(buf_n);
+    __syncthreads();
+    const uint64_t tm2 = __builtin_amdgcn_s_memtime();
+    tm_body += tm0 - tm_last; tm_drain += tm1 - tm0; tm_bar += tm2 - tm1; tm_last = tm2;
+#else
     dma_drain();            // this wave's DMA pieces of the staged tile have landed
     stats_store(buf_n);
     __syncthreads();
+#endif
   };
   const std::integral_constant<int, 0> rA;
   const std::integral_constant<int, 1> rB;
@@ -410,6 +516,13 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
 
   // ---- epilogue -----------------------------------------------------------------------------------------------------------
   mfma_settle(acc);
+#ifdef USP_B64_TIMING
+  if (pass == 0 && lane == 0 && (blockIdx.x % 61) == 0)
+    printf("TM wg %3d wave %d blk %2d n_iter %3d : body %8llu drain %7llu barrier %7llu  (per iteration %5llu / %4llu / %4llu)\n",
+           (int)blockIdx.x, wave, blk, n_iter, (unsigned long long)tm_body, (unsigned long long)tm_drain,
+           (unsigned long long)tm_bar, (unsigned long long)(tm_body / (n_iter + 1)), (unsigned long long)(tm_drain / (n_iter + 1)),
+           (unsigned long long)(tm_bar / (n_iter + 1)));
+#endif
   asm volatile("" : "+s"(p));
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {

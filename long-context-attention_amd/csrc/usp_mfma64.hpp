@@ -17,6 +17,11 @@ template <int DT> struct M64;
     if (SAFE) asm volatile("s_nop 1\n\t" MN " %0, %1, %2, 0" : "=&v"(s) : "v"(a), "a"(q));                          \
     else asm volatile(MN " %0, %1, %2, 0" : "=&v"(s) : "v"(a), "a"(q));                                               \
   }                                                                                                                   \
+  /* first MFMA of a chain that starts from a per-row constant: C = c (16 arch VGPRs of their own), D = s */          \
+  template <bool SAFE = false> static USP_DEV void s_first_c(f32x16& s, const u32x4& a, const u32x4& q, const f32x16& c) { \
+    if (SAFE) asm volatile("s_nop 1\n\t" MN " %0, %1, %2, %3" : "=&v"(s) : "v"(a), "a"(q), "v"(c));                \
+    else asm volatile(MN " %0, %1, %2, %3" : "=&v"(s) : "v"(a), "a"(q), "v"(c));                                      \
+  }                                                                                                                   \
   template <bool SAFE = false> static USP_DEV void s_next(f32x16& s, const u32x4& a, const u32x4& q) {                \
     if (SAFE) asm volatile("s_nop 1\n\t" MN " %0, %1, %2, %0" : "+v"(s) : "v"(a), "a"(q));                          \
     else asm volatile(MN " %0, %1, %2, %0" : "+v"(s) : "v"(a), "a"(q));                                               \
@@ -29,6 +34,7 @@ template <int DT> struct M64;
 #else
 #define USP_M64_BODY(MN)                                                                                              \
   template <bool SAFE = false> static USP_DEV void s_first(f32x16&, const u32x4&, const u32x4&) {}                    \
+  template <bool SAFE = false> static USP_DEV void s_first_c(f32x16&, const u32x4&, const u32x4&, const f32x16&) {}   \
   template <bool SAFE = false> static USP_DEV void s_next(f32x16&, const u32x4&, const u32x4&) {}                     \
   template <bool SAFE = false> static USP_DEV void o_acc(f32x16&, const u32x4&, const u32x4&) {}
 #endif
@@ -85,6 +91,16 @@ USP_DEV u32x4 make_rsrc(const char* base, int64_t bytes) {
   const uint64_t a = (uint64_t)base;
   const uint32_t n = bytes <= 0 ? 0u : (bytes > 0xffffffffLL ? 0xffffffffu : (uint32_t)bytes);
   return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, n, 0x00020000u};
+}
+
+// The same for a tile cursor that counts ROWS: `rows` valid rows (any sign) of `row_bytes` each remain from `base`, a tile
+// addresses at most `tile_rows` of them and `used` bytes of a row.  32-bit scalar arithmetic only (five SALU operations): the
+// caller guarantees tile_rows * row_bytes < 2^31.
+USP_DEV u32x4 make_rsrc_rows(const char* base, int rows, int tile_rows, int row_bytes, int used) {
+  const uint64_t a = (uint64_t)base;
+  const int r = rows < tile_rows ? rows : tile_rows;
+  const int n = r * row_bytes - (row_bytes - used);
+  return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)(n > 0 ? n : 0), 0x00020000u};
 }
 
 }  // namespace usp

@@ -189,12 +189,13 @@ def test_profile_is_quoted_only_for_the_kernel_it_was_taken_from(monkeypatch):
     import kernel_isa
     roof, allp, n = kernel_isa.isa_identity(os.path.join(ROOT, "long-context-attention_amd", "libusp_hip.so"))
     assert n == 24 and len(roof) == 16
-    newest = next(n for n in ("r03_rocprof_summary.txt", "r02_rocprof_summary.txt")
+    newest = next(n for n in ("r04_rocprof_summary.txt", "r03_rocprof_summary.txt", "r02_rocprof_summary.txt")
                   if os.path.exists(os.path.join(ROOT, "profiles", n)))          # what pmc_traffic reads
-    recorded = [ln.split(":")[1].split()[0] for ln in open(os.path.join(ROOT, "profiles", newest))
-                if ln.startswith("roofline_kernel_isa_sha16:")]
+    lines = open(os.path.join(ROOT, "profiles", newest)).read().split("\n")
+    recorded = [ln.split(":")[1].split()[0] for ln in lines if ln.startswith("roofline_kernel_isa_sha16:")]
+    profiled_src = [ln.split(":")[1].strip() for ln in lines if ln.startswith("kernel_src_sha16:")]
     t = b.pmc_traffic()
-    if recorded == [roof] or t.get("kernel_src_sha16") == b.kernel_source_sha16():
+    if recorded == [roof] or profiled_src == [b.kernel_source_sha16()]:
         assert t["read_MB"] > 100 and t["write_MB"] > 50
     else:
         assert t["read_MB"] is None and "stale" in t
