@@ -74,15 +74,14 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   asm volatile("" : "+s"(p));
 
   // ---- lane-constant addresses ----------------------------------------------------------------------------------------
-  // LDS-DMA: this wave fills the contiguous chunks 4*wave .. 4*wave + 3 (rows 16*wave + 4i .. +3) of the Q tile and of the
-  // dO tile; one M0 write per matrix, the pieces by immediate offset (usp_mfma64.hpp).  The slot swizzle of row
-  // 16w + 4i + l/16 is ((l/16) << 2) | i: piece i's per-lane offset is piece 0's with 16*i XORed in.
-  const int dma_row = 16 * wave + (lane >> 4);
+  // LDS-DMA: a tile (64 rows of Q, 64 rows of dO) is 8 GROUPS of 16 rows, a group 4 pieces of 4 rows (1 KiB, one wave
+  // instruction); one M0 write per group, the pieces by immediate offset (usp_mfma64.hpp).  The slot swizzle of row
+  // 16g + 4i + l/16 is ((l/16) << 2) | i: piece i's per-lane offset is piece 0's with 16*i XORed in.  The groups are dealt
+  // UNEVENLY: a role-A wave (whose stream carries the 64 exponentials and is the longer one) stages one group of Q, a
+  // role-B wave one group of Q and two of dO -- a piece costs its wave about 35 cycles (profiles/r04_run18*).
+  const int dma_row = lane >> 4;                 // (+ 16 * group + 4 * piece rows, through the scalar offset)
   const int dma_c8 = ((lane & 15) ^ ((lane >> 4) << 2)) * 16;
   const int q_voff = dma_row * (int)p->q_ss * 2 + dma_c8, do_voff = dma_row * (int)p->do_ss * 2 + dma_c8;
-  int q_vo[4], do_vo[4];                         // per-lane offsets of the four pieces (kept in registers: lane constants)
-#pragma unroll
-  for (int n = 0; n < 4; ++n) { q_vo[n] = q_voff ^ (16 * n); do_vo[n] = do_voff ^ (16 * n); }
   // row read (A operand of the S / dP chain): tile row 32h + l31, logical slot 2t + hi; the swizzle does not depend on h
   const int rd_base = l31 * ROWB + ((hi ^ tile_swz<D>(l31)) * 16);            // ^ (32 t), + h * 32 * ROWB
   // transpose read (A operand of the gradient MFMAs) for dim tile dj, element half e, k-step ks: the 16-lane group reads
@@ -176,20 +175,25 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   // ---- LDS-DMA staging of the Q / dO tiles: running cursors (base pointer + remaining bytes, advanced per tile) -------
   const int64_t tb1 = (int64_t)kTile * p->q_ss * 2, tb2 = (int64_t)kTile * p->do_ss * 2;     // bytes per tile step
   int q_step = 4 * (int)p->q_ss * 2 - 1024, do_step = 4 * (int)p->do_ss * 2 - 1024;
-  int lds_w = wave * 4096;
-  const char *q_cur = nullptr, *do_cur = nullptr;
-  int rows_left = 0;                             // valid rows from the cursor's tile on (<= 0: nothing left, lanes read 0)
+  // groups of this wave: A wave a: Q group a;  B wave b: Q group 2 + b, dO groups 2b and 2b + 1
   const int q_rowb = (int)p->q_ss * 2, do_rowb = (int)p->do_ss * 2;
+  const int gq = role == 0 ? slice : 2 + slice, gd = 2 * slice;
+  int lds_q = gq * 4096, lds_d = TILEB + gd * 4096;                            // LDS offsets of the groups inside a buffer
+  const char *q_cur = nullptr, *do_cur = nullptr;
+  int rows_q = 0, rows_d = 0;                    // valid rows from the cursors on (<= 0: nothing left, lanes read 0)
+
   const float *lse_h = nullptr, *dl_h = nullptr;                               // row statistics of the item's head
   int st_row = 0;                                                             // first row of the cursor's tile
   float st_lse = 0.f, st_delta = 0.f;
   bool st_in = false;
-  const bool stat_wave = wave == USP_B64_STATW;  // the wave that stages the tile's statistics: role A has the shorter stream
+  const bool stat_wave = wave == USP_B64_STATW;  // the wave that stages the tile's statistics (a role-A wave: the branch around its loads breaks role B's register allocation)
   {                                              // base the cursors on head h0, tile t_begin
     const int h = h0;
-    q_cur = p->q + 2 * (b * p->q_sb + h * p->q_sh) + t_begin * tb1;
-    do_cur = p->dout + 2 * (b * p->do_sb + h * p->do_sh) + t_begin * tb2;
-    rows_left = p->Sq - t_begin * kTile;
+    // (the cursors point at this wave's groups: 16 gq / 16 gd rows into the tile)
+    q_cur = p->q + 2 * (b * p->q_sb + h * p->q_sh) + t_begin * tb1 + (int64_t)gq * 16 * q_rowb;
+    do_cur = p->dout + 2 * (b * p->do_sb + h * p->do_sh) + t_begin * tb2 + (int64_t)gd * 16 * do_rowb;
+    rows_q = p->Sq - t_begin * kTile - 16 * gq;
+    rows_d = p->Sq - t_begin * kTile - 16 * gd;
     lse_h = p->lse + b * p->lse_sb + h * p->lse_sh;
     dl_h = p->delta + b * p->dl_sb + h * p->dl_sh;
     st_row = t_begin * kTile;
@@ -200,12 +204,13 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   // runs inside the MFMA stream.  EVERY memory operation of the loop is issued from asm: a load hipcc can see makes it
   // guard the LDS reads that follow with vmcnt waits, which drain the DMA queue in the middle of the tile.
   auto dma_open = [&](int buf) {
-    q_rs = make_rsrc_rows(q_cur, rows_left, kTile, q_rowb, 2 * D);
-    do_rs = make_rsrc_rows(do_cur, rows_left, kTile, do_rowb, 2 * D);
+    q_rs = make_rsrc_rows(q_cur, rows_q, 16, q_rowb, 2 * D);
+    do_rs = make_rsrc_rows(do_cur, rows_d, 32, do_rowb, 2 * D);
     dma_buf = buf;
     q_cur += tb1;
     do_cur += tb2;
-    rows_left -= kTile;
+    rows_q -= kTile;
+    rows_d -= kTile;
   };
   // the statistics wave fetches the 2 x 64 row statistics of the cursor's tile (raw, one row per lane) in front of the
   // stream ...
@@ -221,17 +226,12 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
     st_row += kTile;
   };
   // piece n of the opened tile: n < 4 -> Q piece n, else dO piece n - 4
-  bool dma_live = true;     // dev A/B builds only (USP_B64_ABL_*): timing experiments that keep REAL tiles in LDS
-  auto dma_piece = [&](int n) {
-#ifdef USP_B64_ABL_NODMA
-    if (!dma_live) return;
-#endif
-    asm volatile("" : "+s"(lds_w), "+s"(q_step), "+s"(do_step));
-#ifdef USP_B64_ABL_HALFDMA
-    if (!dma_live && n >= 4) return;
-#endif
-    if (n < 4) lds_dma16_asm(q_rs, lds_w + dma_buf * BUFB, q_vo[n], n * q_step, n);
-    else lds_dma16_asm(do_rs, lds_w + dma_buf * BUFB + TILEB, do_vo[n - 4], (n - 4) * do_step, n - 4);
+  auto dma_piece = [&](int n) {                  // n < 4: the Q group; 4 .. 7 / 8 .. 11: the first / second dO group (role B)
+    asm volatile("" : "+s"(lds_q), "+s"(lds_d), "+s"(q_step), "+s"(do_step));
+    const int i = n & 3;
+    if (n < 4) lds_dma16_asm(q_rs, lds_q + dma_buf * BUFB, q_voff ^ (16 * i), i * q_step, i);
+    else if (n < 8) lds_dma16_asm(do_rs, lds_d + dma_buf * BUFB, do_voff ^ (16 * i), i * do_step, i);
+    else lds_dma16_asm(do_rs, lds_d + 4096 + dma_buf * BUFB, do_voff ^ (16 * i), 4096 + 4 * do_step + i * do_step, i);
   };
   // ... and behind the wave's vmcnt(0) at the end of the iteration stores what the roles consume, the constants their
   // chains START from (the C operand of a chain's first MFMA): -lse * log2(e) for role A (-inf for a row without visible
@@ -258,7 +258,11 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   stats_fetch();
   dma_open(0);
 #pragma unroll
-  for (int n = 0; n < 8; ++n) dma_piece(n);
+  for (int n = 0; n < 4; ++n) dma_piece(n);
+  if (role == 1) {
+#pragma unroll
+    for (int n = 4; n < 12; ++n) dma_piece(n);
+  }
   dma_drain();
   stats_store(0);
   __syncthreads();
@@ -290,9 +294,6 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
 #pragma unroll
   for (int r = 0; r < 16; ++r) cst0[r] = 0.f;
   // one iteration: [prefetch the next tile] [the tile body of this role] [publish]
-#if defined(USP_B64_ABL_NODMA) || defined(USP_B64_ABL_HALFDMA)
-  dma_live = false;
-#endif
   auto step = [&](auto role_c, auto mask_c, int it, bool work) __attribute__((always_inline)) {
     constexpr int ROLE = decltype(role_c)::value;
     constexpr bool MASK = decltype(mask_c)::value;
@@ -423,7 +424,10 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
           if (sl < NKT) { if (h == 0) rd_c(1, sl); else rd_g(0, sl); }       // the next phase's fragments: slots 0 .. 7
           if (h == 0 && sl == 8) chain_init(1);
           elem_slot(16 * h + sl);
-          if (h == USP_B64_DMA_PH && (sl & 1) == 1) dma_piece(sl >> 1);      // the next tile's 8 pieces: slots 1, 3, .. 15
+          if (h == USP_B64_DMA_PH) {                    // the next tile's pieces: role A slots 1, 5, 9, 13; role B slots 1 .. 12
+            if (ROLE == 0 && (sl & 3) == 1) dma_piece(sl >> 2);
+            if (ROLE == 1 && sl >= 1 && sl <= 12) dma_piece(sl - 1);
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       };
@@ -436,8 +440,6 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
           if (h == 0 && i < 2 * NDJ) rd_g(1, i);                              // the next phase's fragments: slots 0 .. 7
           if (ROLE == 1 && h == 1 && i >= 8) next_c(i - 8);                   // role B: the next tile's first chain
           if (ROLE == 1 && h == 1 && i >= 4 && i < 8) next_s(i - 4);
-          if (h + 2 == USP_B64_DMA_PH && i == 0) dma_open(buf_n);
-          if (h + 2 == USP_B64_DMA_PH && (i & 1) == 1) dma_piece(i >> 1);
           elem_slot(32 + 16 * h + i);
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
     } else {
       dma_open(buf_n);
 #pragma unroll
-      for (int n = 0; n < 8; ++n) dma_piece(n);
+      for (int n = 0; n < (ROLE == 0 ? 4 : 12); ++n) dma_piece(n);
     }
     if (ROLE == 1 && !work) {                      // (role B's idle first iteration: the same reads, outside a stream)
 #pragma unroll
