@@ -883,7 +883,12 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
     hipLaunchKernelGGL((reduce_heads_kernel<D, DT>), dim3((int)rg), dim3(256), 0, st, p);
     if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
   }
-  // dQ
+  // dQ: the one-wave-per-SIMD kernel (4 waves x 64 query rows, usp_flash_bwd_dq64.hip) where it applies
+  static const int forced_dq = [] { const char* e = getenv("USP_BWD_DQ_WAVES"); return e ? atoi(e) : 0; }();
+  if (D == 128 && forced_waves != 8 && forced_dq != 8) {
+    int rc64 = USP_ELAUNCH;
+    if (launch_dq64(p, DT, causal, st, &rc64)) return rc64;
+  }
   p.nblk = (p.Sq + 255) / 256;
   p.n_items = p.B * p.Hq * p.nblk * p.ksplit;
   grid = (pers && p.n_items > cus) ? cus : p.n_items;

@@ -33,6 +33,7 @@ SIMDS, XCDS, PEAK_TF, PEAK_HBM = 1024, 8, 2500.0, 8000.0      # MI355X: 256 CUs 
 # (substring of the kernel name, label, matmuls the kernel EXECUTES, matmuls it is credited with algorithmically)
 # in units of one S x S x D matmul pair: forward = 2 matmuls = 4 B H S^2 D / 2 FLOPs (causal)
 FLASH = [("flash_fwd64_kernel", "forward 4x64", 2, 2), ("flash_fwd_kernel", "forward 8x32", 2, 2), ("flash_bwd_dkdv64_kernel", "backward dK/dV 4x64", 4, None), ("flash_bwd_dkdv_kernel", "backward dK/dV 8x32", 4, None),
+         ("flash_bwd_dq64_kernel", "backward dQ 4x64", 3, None),
          ("flash_bwd_kernel", "backward dQ", 3, None)]
 
 
