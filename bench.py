@@ -211,7 +211,15 @@ def sampled_parity(t, n_rows=8, n_keys=8, seed=0):
     rows = sorted(r for r in {0, 255, 256, S // 2 - 1, S // 2, S - 1, *rs.randint(0, S, size=n_rows).tolist()} if 0 <= r < S)
     keys = sorted(j for j in {0, 127, 128, S - 1, *rs.randint(0, S, size=n_keys).tolist()} if 0 <= j < S)
     err = dict(out=0.0, lse=0.0, dq=0.0, dk=0.0, dv=0.0)
-    up = lambda name, a, b: err.__setitem__(name, nanmax(err[name], float((a.double() - b).abs().max())))
+    # ... and the same errors in units of the parity tests' comparator (tests/golden_util.py: an element passes iff
+    # |got - want| <= atol + rtol |want|): a ratio below 1 is a pass, NaN propagates
+    tol = dict(out=(2e-2, 2e-2), lse=(2e-3, 1e-4), dq=(5e-2, 5e-2), dk=(5e-2, 5e-2), dv=(5e-2, 5e-2))
+    ratio = dict(out=0.0, lse=0.0, dq=0.0, dk=0.0, dv=0.0)
+
+    def up(name, a, b):
+        d = (a.double() - b).abs()
+        err[name] = nanmax(err[name], float(d.max()))
+        ratio[name] = nanmax(ratio[name], float((d / (tol[name][0] + tol[name][1] * b.abs())).max()))
     for h in sorted({0, Hq - 1}):
         kd, vd = k[0, :, h // G].double(), v[0, :, h // G].double()
         for i in rows:
@@ -238,7 +246,9 @@ def sampled_parity(t, n_rows=8, n_keys=8, seed=0):
                 rdk += (ds @ qi) * scale
             up("dk", dk[0, j, hk], rdk)
             up("dv", dv[0, j, hk], rdv)
-    return {"max_abs_err": {n: round(e, 6) for n, e in err.items()}, "rows": len(rows), "keys": len(keys),
+    return {"max_abs_err": {n: round(e, 6) for n, e in err.items()},
+            "max_err_over_tolerance": {n: round(e, 4) for n, e in ratio.items()},
+            "tolerance_atol_rtol": {n: list(v) for n, v in tol.items()}, "rows": len(rows), "keys": len(keys),
             "heads": sorted({0, Hq - 1}), "kv_heads": sorted({0, Hkv - 1}),
             "truth": "exact causal attention and its gradients in fp64 on the sampled rows / key columns"}
 
@@ -258,7 +268,7 @@ def kernel_roofline(cfg, dev, traffic, iters=20):
             "achieved": round(t["fwd"], 1),
             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": frac(t["fwd"]),
             "kernel_ms": t["fwd_ms"], "traffic": traffic,
-            "fwd_bwd": {"kernels": "flash_fwd64_kernel + delta_kernel + flash_bwd_dkdv64_kernel + flash_bwd_kernel<dQ>",
+            "fwd_bwd": {"kernels": "flash_fwd64_kernel + delta_kernel + flash_bwd_dkdv64_kernel + flash_bwd_dq64_kernel",
                         "shape_BSHD": [B, S, Hq, D], "kv_heads": Hkv, "fwd_ms": t["fwd_ms"], "bwd_ms": t["bwd_ms"],
                         "bwd_achieved": round(t["bwd"], 1), "bwd_frac": frac(t["bwd"]),
                         "achieved": round(t["fwd_bwd"], 1), "frac": frac(t["fwd_bwd"]),
@@ -267,6 +277,10 @@ def kernel_roofline(cfg, dev, traffic, iters=20):
                         "layer_frac": frac(3.5 * F / (layer_ms * 1e-3) / 1e12),
                         "layer_over_kernels": round(layer_ms / (t["fwd_ms"] + t["bwd_ms"]), 4),
                         "layer": "LongContextAttention.forward + out.backward through autograd (1 x 1 grid), device events",
+                        "layer_over_kernels_note": "the layer step launches exactly these four kernels and nothing else (kernel "
+                                                   "trace: profiles/r04_rocprof_summary.txt, 'layer'); the same kernels run 3-8 % "
+                                                   "longer alternating inside the step than in the same-kernel loops fwd_ms / "
+                                                   "bwd_ms come from (inputs no longer warm in L2 / MALL, another clock state)",
                         "note": "algorithmic FLOPs: backward = 2.5x forward (the two-launch backward executes 3.5x)"}}
     return roof
 
@@ -366,7 +380,8 @@ def kernel_source_sha16():
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "long-context-attention_amd", "csrc")
     for name in ("usp_common.hpp", "usp_item_deal.h", "usp_mfma64.hpp", "usp_fwd_params.hpp", "usp_bwd_params.hpp",
-                 "usp_flash_fwd.hip", "usp_flash_fwd64.hip", "usp_flash_bwd.hip", "usp_flash_bwd64.hip", "Makefile"):
+                 "usp_flash_fwd.hip", "usp_flash_fwd64.hip", "usp_flash_bwd.hip", "usp_flash_bwd64.hip", "usp_flash_bwd_dq64.hip",
+                 "Makefile"):
         with open(os.path.join(csrc, name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -484,6 +499,45 @@ def exchange_mode(attn, lq, lk, cfg, ws):
             + (", sized for the forward K split" if ks else ""))
 
 
+def run_env():
+    """Every environment switch that can change what this run measures (the library reads USP_*; RCCL / HSA / HIP read theirs)."""
+    keys = sorted(k for k in os.environ if k.startswith(("USP_", "NCCL_", "RCCL_", "HSA_", "HIP_", "GPU_MAX_HW_QUEUES", "TORCH_NCCL_")))
+    return {k: os.environ[k] for k in keys}
+
+
+def derived_decisions(cfg, attn, lq, lk, ws):
+    """What the library DERIVED for this configuration, with the figures it derived it from and where each figure came from
+    (a constant, an environment pin, or a probe at set_seq_parallel_pg): so that a scaling line can be read without the source."""
+    import yunchang_amd.hybrid.async_attn_layer as AL
+    from yunchang_amd.comm import link as L
+    import yunchang_amd.comm.relay_exchange as RX
+    ud, rd = cfg["ud"], cfg["rd"]
+    S = lq.shape[1] * ud
+    d = {
+        "link_rate_GBs": round(L.link_bytes_per_s() / 1e9, 1),
+        "link_rate_source": ("USP_LINK_GBS" if os.environ.get("USP_LINK_GBS") else
+                             "measured at set_seq_parallel_pg (comm/link.py, MIN over ranks)" if L.measured() else
+                             "constant (no probe: USP_LINK_PROBE != 1, one rank, or not RCCL)"),
+        "kernel_rate_TFs": round(L.kernel_flops_per_s() / 1e12, 1),
+        "kernel_rate_source": ("USP_KERNEL_TFS" if os.environ.get("USP_KERNEL_TFS") else
+                               "measured at set_seq_parallel_pg (forward kernel, B1 S4096 H16, MIN over ranks)" if L.kernel_measured()
+                               else "constant (no probe)"),
+        "device_cus": L.device_cus(),
+        "head_group_fill_items": {"default": AL.fill_items(), "link_bound": AL.fill_items(True), "link_bound_k_split": AL.fill_items(True, True),
+                                  "source": "2 / 1 / 0.5 work items per CU x device_cus" if AL._FILL_ITEMS is None else "pinned"},
+        "safe_comm": bool(AL.safe_comm()),
+        "pipeline_beside_ring": bool(AL.pipeline_mode(rd)) if ud > 1 else None,
+        "exchange_relay": bool(RX.relay_enabled()),
+    }
+    if ud > 1:
+        lb = AL._link_bound(cfg["Hq"], cfg["Hkv"], ud, cfg["B"], S, lq.shape[-1], lq.element_size(), rd, True)
+        ks = not cfg.get("bwd", False) and AL._k_split_groups(None, cfg["B"], S, True)
+        d["exchange_link_bound"] = bool(lb)
+        d["forward_k_split_groups"] = bool(ks)
+        d["head_groups"] = AL._groups(cfg["Hq"], cfg["Hkv"], ud, cfg["B"], S, link_bound=lb, k_split=ks)[0]
+    return d
+
+
 def barrier(ws):
     if ws > 1:            # a barrier over one rank is empty; NCCL would still launch an all-reduce for it
         if dist.get_backend() == "nccl":      # name the device: without it ProcessGroupNCCL guesses one from the rank
@@ -497,11 +551,12 @@ def _sync(dev):
         torch.cuda.synchronize()
 
 
-def timed(step, steps, ws, dev, device_ms=None):
+def timed(step, steps, ws, dev, device_ms=None, spread=None):
     """K steps bracketed by barrier + synchronize on both sides; max over ranks; seconds per step (host clock).
     `device_ms`: a list that receives this rank's per-step time between two device events recorded on the compute
     stream around the same K steps (diagnostic: host clock minus device clock = launch latency of the first step +
-    the wake-up of the final synchronize)."""
+    the wake-up of the final synchronize).  `spread`: a dict that receives the fastest and the slowest rank's OWN time
+    for the K steps (its clock stopped at its own synchronize, in front of the closing barrier), ms per step."""
     _sync(dev)
     barrier(ws)
     _sync(dev)
@@ -516,15 +571,19 @@ def timed(step, steps, ws, dev, device_ms=None):
     if ev:
         ev[1].record()
     _sync(dev)
+    own = time.perf_counter() - t0
     barrier(ws)
     _sync(dev)
     dt = time.perf_counter() - t0
     if ev:
         device_ms.append(ev[0].elapsed_time(ev[1]) / steps)
+    lo = hi = own
     if ws > 1:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt, own, -own], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt, hi, lo = float(tmax[0].item()), float(tmax[1].item()), -float(tmax[2].item())
+    if spread is not None:
+        spread.update(min=round(lo / steps * 1e3, 4), max=round(hi / steps * 1e3, 4))
     return dt / steps
 
 
@@ -735,6 +794,8 @@ def main(argv=None, dev=None):
                                                                                     # main()), not over gloo (seconds per step)
     flops = fwd_flops(cfg["B"], cfg["Hq"], cfg["S"], cfg["D"]) * (3.5 if cfg["bwd"] else 1.0)
 
+    rank_spread = {}                        # the fastest / slowest rank's own ms per step of the LAST measure() call
+
     def measure():
         """n_heat untimed steps, W warm-up steps, K timed steps, back to back -> (ms per step, device-event ms)."""
         for _ in range(n_heat):
@@ -742,7 +803,7 @@ def main(argv=None, dev=None):
         for _ in range(args.warmup):
             step()
         dms = []
-        sec = timed(step, args.steps, ws, dev, dms)
+        sec = timed(step, args.steps, ws, dev, dms, rank_spread)
         return sec * 1e3, (round(dms[0], 4) if dms else None)
 
     from yunchang_amd.comm import link as _link
@@ -762,13 +823,14 @@ def main(argv=None, dev=None):
                        "layer": "AsyncLongContextAttention" if args.async_ulysses else "LongContextAttention",
                        "ulysses_exchange": exchange_mode(attn, lq, lk, cfg, ws),
                        "comm_mode": comm_mode,
-                       "link_rate_GBs": round(_link.link_bytes_per_s() / 1e9, 1),
-                       "link_rate_source": "measured at set_seq_parallel_pg (comm/link.py)" if _link.measured() else "constant / USP_LINK_GBS",
+                       "env": run_env(),
+                       "derived": derived_decisions(cfg, attn, lq, lk, ws),
                        "tokens_per_gpu": cfg["S"] * cfg["B"] // ws,
                        "assumed": "B=1 and causal=True where BASELINE.json's config string is silent",
                        "host": f"host-only work (gc.collect + gc.freeze, PMC lookup) first, then device work only: kernel "
                                f"timings, {n_heat} untimed steps, W warm-up steps, K timed steps"},
             "ms_per_step_device_events": dms,
+            "ms_per_step_rank_min_max": dict(rank_spread),
             "frac_of_mfma_roofline": round(value / (ws * PEAK_BF16_TFLOPS), 4),
             "parity_max_abs_err_vs_reference_op": parity_op,
             "parity_max_abs_err_vs_fp64_rows": parity_rows,

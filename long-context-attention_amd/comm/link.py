@@ -13,14 +13,23 @@ every rank's probe buffer would land on cuda:0 and RCCL would fail or hang at se
 communicators nobody asked for, and a measured figure makes the head-group schedule vary from run to run.  When it runs,
 the ranks first AGREE to run it (one MIN all-reduce over "this rank can": a rank whose environment says otherwise cannot
 leave the others waiting in a send/recv), it is skipped on more ranks than local devices (the MIN over ranks would measure
-the NIC, not xGMI), and any failure falls back to the constant.  USP_LINK_GBS=<GB/s> pins the figure."""
+the NIC, not xGMI), and any failure falls back to the constant.  USP_LINK_GBS=<GB/s> pins the figure.
+
+The same opt-in moment measures the second figure `_link_bound` compares the link with: the rate of the forward attention
+kernel on a launch large enough to fill the part (B1 S4096 H16 D128 causal, five launches), again reduced with MIN over
+the ranks.  Without the probe it is the constant 1.1e15 FLOP/s (profiles/: 1.10-1.17 PFLOP/s at the C2 shape); USP_KERNEL_TFS
+pins it.  `device_cus()` is where the head-group sizing gets its "work items per CU" unit from (the device's CU count; 256
+when no device is visible)."""
 import os
 
 import torch
 import torch.distributed as dist
 
 DEFAULT_BYTES_PER_S = 64e9
+DEFAULT_KERNEL_FLOPS_PER_S = 1.1e15
 _measured = None          # bytes/s, one link, one direction
+_kernel_measured = None   # FLOP/s of the forward kernel on a part-filling launch
+_cus = None
 
 
 def link_bytes_per_s() -> float:
@@ -35,6 +44,52 @@ def link_bytes_per_s() -> float:
 
 def measured() -> bool:
     return _measured is not None
+
+
+def kernel_flops_per_s() -> float:
+    env = os.environ.get("USP_KERNEL_TFS")
+    if env:
+        try:
+            return float(env) * 1e12
+        except ValueError:
+            pass
+    return _kernel_measured if _kernel_measured else DEFAULT_KERNEL_FLOPS_PER_S
+
+
+def kernel_measured() -> bool:
+    return _kernel_measured is not None
+
+
+def device_cus() -> int:
+    """Compute units of the current device (the unit of the head-group sizing: work items per CU); 256 without a device."""
+    global _cus
+    if _cus is None:
+        try:
+            _cus = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count) \
+                if torch.cuda.is_available() else 256
+        except Exception:
+            _cus = 256
+    return _cus
+
+
+def _probe_kernel_rate(dev):
+    """FLOP/s of the forward kernel on B1 S4096 H16 D128 causal bf16 (68.7 GFLOP per launch), device events."""
+    from .. import _C
+    B, S, H, D = 1, 4096, 16, 128
+    q, k, v = (torch.randn(B, S, H, D, device=dev, dtype=torch.bfloat16) for _ in range(3))
+    out = torch.empty_like(q)
+    lse = torch.empty(B, H, S, device=dev, dtype=torch.float32)
+    for _ in range(3):
+        _C.flash_fwd(q, k, v, D ** -0.5, True, lse, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    n = 5
+    e0.record()
+    for _ in range(n):
+        _C.flash_fwd(q, k, v, D ** -0.5, True, lse, out=out)
+    e1.record()
+    e1.synchronize()
+    return n * 4.0 * B * H * S * S * D * 0.5 / max(e0.elapsed_time(e1) * 1e-3, 1e-9)
 
 
 def probe_link_rate(rank: int, world_size: int, nbytes: int = 16 << 20, rounds: int = 4):
@@ -71,6 +126,16 @@ def probe_link_rate(rank: int, world_size: int, nbytes: int = 16 << 20, rounds: 
         rate = torch.tensor([rounds * nbytes / max(e0.elapsed_time(e1) * 1e-3, 1e-9)], dtype=torch.float64, device=dev)
         dist.all_reduce(rate, op=dist.ReduceOp.MIN)         # one figure for every rank
         _measured = float(rate.item())
+        if not os.environ.get("USP_KERNEL_TFS"):
+            global _kernel_measured
+            try:
+                kr = _probe_kernel_rate(dev)
+            except Exception:
+                kr = 0.0
+            krt = torch.tensor([kr], dtype=torch.float64, device=dev)
+            dist.all_reduce(krt, op=dist.ReduceOp.MIN)       # every rank reaches this all-reduce, with 0 if its probe failed
+            if float(krt.item()) > 0:
+                _kernel_measured = float(krt.item())
         return _measured
     except Exception as e:                                   # a failed probe must not take the set-up down
         import warnings

@@ -568,7 +568,7 @@ bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st
       n = 256;
     return n;
   }();
-  if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on || p_in.interleave) return false;
+  if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on) return false;
   // fp16: hipcc's register allocation of that instantiation copies the accumulators between the register files inside the
   // loop and reads one of them right behind its MFMA (tools/mfma_hazards.py: 22 hazards) -- served by the 8-wave kernel
   if (dtype != USP_BF16) return false;
@@ -581,7 +581,9 @@ bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st
   BwdParams p = p_in;
   p.nblk = (p.Sk + 127) / 128;
   p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1) * p.qsplit;
-  const int grid = p.n_items > cus ? cus : p.n_items;          // persistent: one workgroup per CU
+  // persistent: one workgroup per CU; USP_LAUNCH_INTERLEAVE: one workgroup per item (the same kernel: a workgroup's item
+  // list then has one entry)
+  const int grid = (!p.interleave && p.n_items > cus) ? cus : p.n_items;
   constexpr size_t lds = 3 * (2 * kTile * 128 * 2 + 2 * kTile * 4) + 2 * 2 * 8192;
   if (causal) hipLaunchKernelGGL((flash_bwd_dkdv64_kernel<0, true>), dim3(grid), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((flash_bwd_dkdv64_kernel<0, false>), dim3(grid), dim3(256), lds, st, p);

@@ -128,24 +128,35 @@ _PIPELINE_BESIDE_RING_DEFAULT = True
 _MAX_GROUPS = 4     # deeper pipelines only shrink the per-group kernels (fewer workgroups per launch)
 
 
-# 256-row work items a head group's attention launch must still have.  Measured (kbench, C3 shape = one causal launch
-# per group, interleavable): 8 heads x 64 blocks = 512 items run at 1040-1145 TFLOP/s, 4 heads = 256 items at 814 (905 since
-# the tiles of a head are dealt evenly to its XCDs), 2 heads at 536-565 -- with one item per CU nothing balances the causal
-# triangle.  So two items per CU are asked for ...
-_FILL_ITEMS = 512
+# 256-row work items a head group's attention launch must still have, in units of the device's CU count (comm/link.py:
+# device_cus; 256 on an MI355X).  Measured (kbench, C3 shape = one causal launch per group, interleavable): 8 heads x 64
+# blocks = 512 items (2 per CU) run at 1040-1145 TFLOP/s, 4 heads = 256 items (1 per CU) at 814 (905 since the tiles of a head
+# are dealt evenly to its XCDs), 2 heads at 536-565 -- with one item per CU nothing balances the causal triangle.  So TWO
+# items per CU are asked for ...
+_FILL_PER_CU = 2.0
 # ... unless the exchange is long against the attention it can hide behind: then the pipeline wins even with starved
 # launches.  C3 (2 GPUs, forward only, MHA): 50 MB in + 17 MB out per rank over ONE link = 1.05 ms against 0.5 ms of
 # attention -- sequential 0.79 + 0.54 + 0.26 = 1.59 ms, two groups of 256 items (0.36 ms each) 1.28 ms, four groups
 # 1.33 ms (the schedule: all input exchanges queued first on the lane, group i's output behind its attention).  The
-# one-GPU rank emulation cannot see this (its wire is an HBM copy): its 0.69 vs 0.86 ms is kernel time only.
-_FILL_ITEMS_LINK_BOUND = 256
+# one-GPU rank emulation cannot see this (its wire is an HBM copy): its 0.69 vs 0.86 ms is kernel time only.  ONE per CU ...
+_FILL_PER_CU_LINK_BOUND = 1.0
 # ... and half of that again where the forward kernel cuts few-item launches along K (usp_fwd_args.k_splits, staged behind
 # USP_FWD_KSPLIT): a 2-head group of the 2-GPU config (128 items) then runs at 936 instead of 557 TFLOP/s (kbench ksplit),
 # and four such groups put the iteration on the wire's floor (1.05 ms against 1.22 with two groups, tools/link_model.py).
 # Forward-only calls: the backward kernels have no such cut.
-_FILL_ITEMS_LINK_BOUND_KSPLIT = 128
+_FILL_PER_CU_LINK_BOUND_KSPLIT = 0.5
+_FILL_ITEMS = None            # tests pin an item count here (1: let the pipeline form on tiny problems)
 _LINK_BYTES_PER_S = None      # tests pin a rate here; otherwise comm/link.py: measured at set_seq_parallel_pg time, or 64 GB/s
-_KERNEL_FLOPS_PER_S = 1.1e15  # forward flash kernel on large launches (profiles/)
+_KERNEL_FLOPS_PER_S = None    # likewise: comm/link.py: measured beside the link (USP_LINK_PROBE=1), or 1.1e15
+
+
+def fill_items(link_bound=False, k_split=False):
+    """Work items a head group's launch must still have (see the three per-CU figures above)."""
+    if _FILL_ITEMS is not None:
+        return _FILL_ITEMS
+    from ..comm.link import device_cus
+    per_cu = _FILL_PER_CU if not link_bound else (_FILL_PER_CU_LINK_BOUND_KSPLIT if k_split else _FILL_PER_CU_LINK_BOUND)
+    return max(1, int(per_cu * device_cus()))
 
 
 def _link_bound(Hq, Hkv, P, B, S, D, itemsize, ring, causal):
@@ -154,23 +165,24 @@ def _link_bound(Hq, Hkv, P, B, S, D, itemsize, ring, causal):
     rows = B * (S // P)                                              # local rows before the exchange
     t_comm = rows * (2 * Hq + 2 * Hkv) * D * itemsize / P / (_LINK_BYTES_PER_S or link_bytes_per_s())
     flops = 4.0 * B * (Hq // P) * S * (S * ring) * D * (0.5 if causal else 1.0)
-    return t_comm >= 0.5 * flops / _KERNEL_FLOPS_PER_S
+    from ..comm.link import kernel_flops_per_s
+    return t_comm >= 0.5 * flops / (_KERNEL_FLOPS_PER_S or kernel_flops_per_s())
 
 
 def _groups(Hq, Hkv, P, B=None, S=None, max_groups=None, link_bound=False, k_split=False):
     """(number of head groups, kv heads per rank per group, query heads per kv head).  A group is a
     set of whole KV heads (with their query heads) of every rank's post-exchange share.  With the problem
     size (B, S = sequence after the exchange) given, the pipeline is kept shallow enough that every group's
-    attention launch still has _FILL_ITEMS 256-row work items (_FILL_ITEMS_LINK_BOUND when the caller found the
-    exchange long against the attention, `_link_bound`; _FILL_ITEMS_LINK_BOUND_KSPLIT when, in addition, the forward
-    kernel will cut such launches along K, `k_split`)."""
+    attention launch still has `fill_items` 256-row work items (two per CU; one when the caller found the exchange long
+    against the attention, `_link_bound`; half of one when, in addition, the forward kernel will cut such launches along
+    K, `k_split`)."""
     assert Hq % P == 0 and Hkv % P == 0, f"heads ({Hq}, {Hkv}) not divisible by ulysses degree {P}"
     per_rank = Hkv // P
     ng = 1
     if P > 1:                       # nothing to hide without an exchange
         cap = _MAX_GROUPS if max_groups is None else min(_MAX_GROUPS, max_groups)
         if B is not None and S is not None:
-            fill = min(_FILL_ITEMS, _FILL_ITEMS_LINK_BOUND_KSPLIT if k_split else _FILL_ITEMS_LINK_BOUND) if link_bound else _FILL_ITEMS
+            fill = fill_items(link_bound, k_split)
             cap = max(1, min(cap, (B * (Hq // P) * ((S + 255) // 256)) // fill))
         for cand in range(min(cap, per_rank), 0, -1):
             if per_rank % cand == 0:

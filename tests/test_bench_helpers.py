@@ -157,6 +157,20 @@ def _main_worker(rank, ws):
     assert need <= set(line), need - set(line)
     assert line["n_gpus"] == ws and line["steps"] == 2 and line["ms_per_step"] > 0, line
     assert line["parity_max_abs_err_vs_fp64_rows"] < 2e-2
+    # the line describes itself: environment switches, what the library derived (and from what), per-rank spread
+    c = line["config"]
+    assert c["env"].get("USP_BENCH_BACKEND") == "gloo" and all(k.startswith(("USP_", "NCCL_", "RCCL_", "HSA_", "HIP_", "GPU_", "TORCH_NCCL_")) for k in c["env"])
+    d = c["derived"]
+    assert {"link_rate_GBs", "link_rate_source", "kernel_rate_TFs", "kernel_rate_source", "device_cus", "head_group_fill_items",
+            "safe_comm", "exchange_relay"} <= set(d), d
+    assert d["link_rate_source"].startswith("constant") and d["kernel_rate_source"].startswith("constant")   # gloo: no probe
+    assert d["head_group_fill_items"]["source"] == "pinned"          # this test pins AL._FILL_ITEMS = 1
+    if c["parallelism"].startswith("ulysses1x"):
+        assert "head_groups" not in d
+    else:
+        assert d["head_groups"] >= 1 and isinstance(d["exchange_link_bound"], bool)
+    sp = line["ms_per_step_rank_min_max"]
+    assert 0 < sp["min"] <= sp["max"] <= line["ms_per_step"] * 1.0001 + 1e-3, (sp, line["ms_per_step"])
     if ws == 1:
         assert {"roofline", "cpu_baseline", "reference_kernel_on_this_gpu"} <= set(line) and "overlap" not in line
         assert line["roofline"]["seq64k_single_gpu"] == {"stub": True}
@@ -224,7 +238,11 @@ def test_sampled_parity_reference_equals_autograd():
     assert max(res["max_abs_err"].values()) < 1e-9, res
     t["dk"] = t["dk"].clone()
     t["dk"][0, 0, 0, 3] += 0.25                      # key 0 of kv head 0 is always sampled
-    assert abs(b.sampled_parity(t)["max_abs_err"]["dk"] - 0.25) < 1e-6
+    res = b.sampled_parity(t)
+    assert abs(res["max_abs_err"]["dk"] - 0.25) < 1e-6
+    # the same error in comparator units: 0.25 / (atol + rtol |want|) at that element
+    want = float(kk.grad[0, 0, 0, 3].abs())
+    assert abs(res["max_err_over_tolerance"]["dk"] - 0.25 / (5e-2 + 5e-2 * want)) < 1e-3, res
 
 
 def test_sampled_parity_and_parity_check_propagate_nan():
@@ -244,8 +262,10 @@ def test_sampled_parity_and_parity_check_propagate_nan():
         t = dict(base)
         t[name] = base[name].clone()
         t[name][idx] = float("nan")
-        e = b.sampled_parity(t)["max_abs_err"][name]
+        res = b.sampled_parity(t)
+        e, r = res["max_abs_err"][name], res["max_err_over_tolerance"][name]
         assert e != e and not (e < 1e9), (name, e)
+        assert r != r and not (r < 1.0), (name, r)                  # the comparator-unit figure is gated as `ratio < 1`
     # parity_check (the per-rank check of the layer benchmark): a NaN row of the local output
     cfg = dict(S=64, ud=1, rd=1, impl="basic")
     q16, k16, v16 = (torch.randn(1, 64, 2, 16) for _ in range(3))

@@ -30,8 +30,24 @@ def regs(tok):
     return set()
 
 
-def main():
-    path, pat = sys.argv[1], sys.argv[2]
+def kernels_in(path):
+    """Mangled names of the kernels (functions that contain an MFMA) of a .s file."""
+    names, cur, has = [], None, False
+    for l in open(path).read().split("\n"):
+        m = re.match(r"^(_Z\S*):", l)
+        if m:
+            cur, has = m.group(1), False
+        elif l.startswith(".Lfunc_end"):
+            if cur and has:
+                names.append(cur)
+            cur = None
+        elif cur and "v_mfma" in l:
+            has = True
+    return names
+
+
+def check(path, pat, out=print):
+    """Number of potential hazards of the kernel whose mangled name contains `pat`; every violation goes to `out`."""
     lines = open(path).read().split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^(_Z\S*):", l) and pat in l)
     end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith(".Lfunc_end"))
@@ -61,7 +77,7 @@ def main():
             if pop.startswith(("ds_read", "buffer_load", "global_load", "scratch_load")):
                 continue                                    # returned data is guarded by s_waitcnt, not by wait states
             if w & (a | b | (c - d)):
-                print(f"A: line {pl}: {pop} {pops[0]} feeds MFMA at line {ln} ({k} instruction(s) earlier)")
+                out(f"A: line {pl}: {pop} {pops[0]} feeds MFMA at line {ln} ({k} instruction(s) earlier)")
                 bad += 1
         # B: consumers of D behind
         states = 0
@@ -77,10 +93,10 @@ def main():
                 for t in nops[1:3]:
                     touched |= regs(t)
                 if touched & d:
-                    print(f"B: line {nl}: MFMA reads D of MFMA at line {ln} as SrcA/B after {states} states")
+                    out(f"B: line {nl}: MFMA reads D of MFMA at line {ln} as SrcA/B after {states} states")
                     bad += 1
                 if (nc & d or nd & d) and not (nc == d and nd == d):
-                    print(f"B: line {nl}: MFMA overlaps D of MFMA at line {ln} partially after {states} states")
+                    out(f"B: line {nl}: MFMA overlaps D of MFMA at line {ln} partially after {states} states")
                     bad += 1
                 states += 8
                 continue
@@ -88,11 +104,17 @@ def main():
             for t in nops:
                 touched |= regs(t.split(" ")[0])
             if touched & d and not nop_.startswith("s_"):
-                print(f"B: line {nl}: {nop_} {' '.join(nops)[:50]} touches D of MFMA at line {ln} after {states} states")
+                out(f"B: line {nl}: {nop_} {' '.join(nops)[:50]} touches D of MFMA at line {ln} after {states} states")
                 bad += 1
             m = re.match(r"s_nop", nop_)
             states += (int(nops[0]) + 1) if m else 1
+    return bad
+
+
+def main():
+    bad = check(sys.argv[1], sys.argv[2])
     print(f"{bad} potential hazard(s)")
 
 
-main()
+if __name__ == "__main__":
+    main()
