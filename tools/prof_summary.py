@@ -75,7 +75,10 @@ def derived(merged, shape):
                        f"{2 * mm / us / 1e6 / PEAK_TF:.4f}")
         else:
             bwd_us += us
-    extra = [merged[n]["dur_us"] for n in merged if ("delta_kernel" in n or "reduce_heads" in n) and "dur_us" in merged[n]]
+    # helpers of the same launches only: a reduce_heads that ran a handful of times belongs to another shape's pass (64K, GQA)
+    n_bwd = max([merged[n].get("n_dur", 0) for n in merged if "flash_bwd" in n] or [0])
+    extra = [merged[n]["dur_us"] for n in merged if ("delta_kernel" in n or "reduce_heads" in n) and "dur_us" in merged[n]
+             and merged[n].get("n_dur", 0) >= n_bwd // 2]
     if bwd_us:
         tot = bwd_us + sum(extra)
         out.append(f"  {'backward, all':16s} {tot:9.1f} us | algorithmic (5 matmuls) {5 * mm / tot / 1e6:7.1f} TFLOP/s = "
