@@ -135,6 +135,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   }
   if (n_full > nt) n_full = nt;
 
+#ifdef USP_F64_TIMING          // dev build: where an item's time goes (shader cycles; printed for a few waves)
+  const uint64_t tm_item = __builtin_amdgcn_s_memtime();
+#endif
   // ---- Q fragments (B operand: lane holds Q[row][16t + 8hi .. +7]), parked in the accumulator file -----------------
   u32x4 qf[2][NKT];
 #pragma unroll
@@ -159,24 +162,28 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   const int64_t k_tb = (int64_t)kBN * p->k_ss * 2, v_tb = (int64_t)kBN * p->v_ss * 2;   // bytes per tile step
   const char* k_cur = p->k + 2 * (b * p->k_sb + hkv * p->k_sh);
   const char* v_cur = p->v + 2 * (b * p->v_sb + hkv * p->v_sh);
-  int64_t k_rem = ((int64_t)(p->Sk - 1) * p->k_ss + D) * 2, v_rem = ((int64_t)(p->Sk - 1) * p->v_ss + D) * 2;
+  int rows_kv = p->Sk;                                       // valid rows from the cursors on (<= 0: lanes read 0)
+  const int k_rowb = (int)p->k_ss * 2, v_rowb = (int)p->v_ss * 2;
   // (lds_w / k_step / v_step pass through an opaque asm at every use: hipcc otherwise hoists the sixteen M0 values and the
   // six scalar offsets of the pieces out of the loops as invariants and then SPILLS them -- a v_readlane plus five wait
   // states in front of every LDS-DMA; computed at the use each is one s_add / s_lshl / s_mul)
   int lds_w = wave * 4096, k_step = 4 * (int)p->k_ss * 2 - 1024, v_step = 4 * (int)p->v_ss * 2 - 1024;
   u32x4 k_rs, v_rs;                                         // descriptors of the tiles being fetched
+  int k_ahead = 0;                                          // 0, or -1 once the K cursor is one tile ahead of the V cursor
   int dma_kbuf = 0, dma_vbuf = 0;
   // open the next K / V tile (descriptor for the cursor's tile, then advance the cursor); its four pieces follow
   auto dma_open = [&](int kbuf, int vbuf) {
-    k_rs = make_rsrc(k_cur, k_rem);
-    v_rs = make_rsrc(v_cur, v_rem);
-    k_cur += k_tb; k_rem -= k_tb;
-    v_cur += v_tb; v_rem -= v_tb;
+    k_rs = make_rsrc_rows(k_cur, rows_kv + kBN * k_ahead, kBN, k_rowb, 2 * D);
+    v_rs = make_rsrc_rows(v_cur, rows_kv, kBN, v_rowb, 2 * D);
+    k_cur += k_tb;
+    v_cur += v_tb;
+    rows_kv -= kBN;
     dma_kbuf = kbuf; dma_vbuf = vbuf;
   };
-  auto dma_open_k = [&](int kbuf) {
-    k_rs = make_rsrc(k_cur, k_rem);
-    k_cur += k_tb; k_rem -= k_tb;
+  auto dma_open_k = [&](int kbuf) {                         // (the prologue's extra K tile: the K cursor then runs one tile ahead)
+    k_rs = make_rsrc_rows(k_cur, rows_kv, kBN, k_rowb, 2 * D);
+    k_cur += k_tb;
+    k_ahead = -1;
     dma_kbuf = kbuf;
   };
   // piece n of the opened tiles: n < 4 -> K piece n, else V piece n - 4
@@ -280,6 +287,18 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   const float thr_raw = kThr / c;
   float m_thr[2] = {USP_NEG_INF, USP_NEG_INF};   // m_run + kThr / c: a tile whose scores stay below keeps the reference
   float nmc[2] = {0.f, 0.f};                     // -(reference max * c), 0 while the reference is still -inf
+  // the first tile of an item: O and l are still zero, only the reference max is set (the general path below would read,
+  // scale and write back all 128 accumulator registers: ~2 000 cycles per item that nothing overlaps)
+  auto first_ref = [&](const float (&mt_lane)[2]) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const float m_new = xhalf_max(mt_lane[qb]);
+      const float m_use = (m_new == USP_NEG_INF) ? 0.f : m_new;
+      m_run[qb] = m_new;
+      m_thr[qb] = m_new + thr_raw;
+      nmc[qb] = -(m_use * c);
+    }
+  };
   auto rescale = [&](const float (&mt_lane)[2]) {
     asm volatile("; rescale (rare)" ::: "memory");          // keeps hipcc from if-converting the branch
     mfma_settle(o);
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
 #pragma unroll
       for (int r = 0; r < 16; ++r) mt[qb] = fmaxf(mt[qb], s[qb][1][r]);
     }
-    if (!__all(mt[0] <= m_thr[0] && mt[1] <= m_thr[1])) rescale(mt);
+    first_ref(mt);                                           // (only ever called for the first tile of an item)
   };
   // PARV = jj & 1 as a compile-time constant (0 / 1: every LDS offset of the iteration is an immediate) or 2: taken from `jpar`
   auto iter = [&](auto par_c, auto mode_c, int jpar, int kt0_next, f32x16 (&cs)[2][2], f32x16 (&ns)[2][2])
@@ -414,6 +433,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   const int n_w = wave_kv_end > 0 ? (wave_kv_end + kBN - 1) / kBN : 0;
   if (n_full > n_w) n_full = n_w;
   int j = 0;
+#ifdef USP_F64_TIMING
+  const uint64_t tm_loop = __builtin_amdgcn_s_memtime();
+  uint64_t tm_hot = tm_loop;
+#endif
   if (n_w > 0) {
     if (n_full == 0) mask(0, sa);
     decide(sa);
@@ -431,12 +454,18 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) sa[qb][kb] = sb[qb][kb];
     };
+#ifdef USP_F64_TIMING
+    tm_hot = __builtin_amdgcn_s_memtime();
+#endif
     if (j < n_hot) { iter(c0, c0, 0, 0, sa, sb); adopt(); ++j; }
     for (; j < n_w; ++j) {                                   // the diagonal (MODE 1) and this wave's last tile (MODE 2)
       if (j + 1 >= n_w) iter(c2, c2, j & 1, 0, sa, sb);
       else { iter(c2, c1, j & 1, (j + 1) * kBN, sa, sb); adopt(); }
     }
   }
+#ifdef USP_F64_TIMING
+  const uint64_t tm_own = __builtin_amdgcn_s_memtime();
+#endif
   // ---- the tiles other waves of the workgroup still work on: keep the K/V stream and the barrier cadence -------------
   for (; j < nt; ++j) {
     dma_all(j & 1, (j + 1) & 1);
@@ -444,6 +473,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
     __syncthreads();
   }
 
+#ifdef USP_F64_TIMING
+  const uint64_t tm_idle = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue: normalise, merge with the running result, store (per query block, as in usp_flash_fwd.hip) -------
   mfma_settle(o);
   asm volatile("" : "+s"(p));
@@ -518,6 +550,16 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
       }
     }
   }
+#ifdef USP_F64_TIMING
+  {
+    const uint64_t tm_end = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && (blockIdx.x % 61) == 0 && pass < 4)
+      printf("TF wg %3d pass %d wave %d qt %2d tiles own %3d wg %3d : prologue %6llu hot-loop %8llu (%5llu / tile) tail-tiles %6llu idle %6llu epilogue %6llu\n",
+             (int)blockIdx.x, pass, wave, qt, n_w, nt, (unsigned long long)(tm_loop - tm_item), (unsigned long long)(tm_hot - tm_loop),
+             (unsigned long long)((tm_hot - tm_loop) / (n_full > 2 ? (n_full - 1) / 2 * 2 : 1)), (unsigned long long)(tm_own - tm_hot),
+             (unsigned long long)(tm_idle - tm_own), (unsigned long long)(tm_end - tm_idle));
+  }
+#endif
   }  // next item
 }
 

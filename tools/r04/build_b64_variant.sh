@@ -6,5 +6,5 @@ R=$(cd "$(dirname "$0")/../.." && pwd)
 C="$R/long-context-attention_amd/csrc"
 mkdir -p "$R/abl/$1"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -I"$R/include" $2 -c "$C/usp_flash_bwd64.hip" -o "$R/abl/$1/b64.o"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/abl/$1/libusp_hip.so" "$C/usp_flash_fwd.o" "$C/usp_flash_fwd64.o" "$C/usp_flash_bwd.o" "$R/abl/$1/b64.o" "$C/usp_elementwise.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$R/abl/$1/libusp_hip.so" "$C/usp_flash_fwd.o" "$C/usp_flash_fwd64.o" "$C/usp_flash_bwd.o" "$R/abl/$1/b64.o" "$C/usp_flash_bwd_dq64.o" "$C/usp_elementwise.o"
 rm -f "$R/abl/$1/b64.o"
