@@ -28,17 +28,17 @@
 
 namespace usp {
 
-#ifndef USP_B64_STATW
-#define USP_B64_STATW 0
-#endif
-#ifndef USP_B64_DMA_PH
-#define USP_B64_DMA_PH 0     // phase whose odd slots carry the next tile's DMA pieces (0: first chain)
-#endif
-#ifndef USP_B64_E0       // first and one-past-last slot of the element stream (64 elements; chain(h0) ends at 16, the
-#define USP_B64_E0 16    // gradient MFMAs of k-step (h, k2) start at 32 + 16 h + 8 k2)
-#endif
-#ifndef USP_B64_E1
-#define USP_B64_E1 54
+constexpr int kB64_STATW = 0;    // the wave that stages a tile's statistics (a role-A wave: see stat_wave below)
+constexpr int kB64_DMA_PH = 0;   // phase whose slots carry the next tile's DMA pieces (0: the first chain)
+constexpr int kB64_E0 = 16;      // first and one-past-last slot of the element stream (64 elements; chain(h0) ends at 16, the
+constexpr int kB64_E1 = 54;      // gradient MFMAs of k-step (h, k2) start at 32 + 16 h + 8 k2)
+
+// dev build -DUSP_B64_TIMING: where an iteration's time goes (s_memtime stamps summed per wave, printed for a few waves;
+// profiles/r04_run21..23*.log)
+#ifdef USP_B64_TIMING
+#define USP_TM(...) __VA_ARGS__
+#else
+#define USP_TM(...)
 #endif
 
 template <int DT, bool CAUSAL>
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   int st_row = 0;                                                             // first row of the cursor's tile
   float st_lse = 0.f, st_delta = 0.f;
   bool st_in = false;
-  const bool stat_wave = wave == USP_B64_STATW;  // the wave that stages the tile's statistics (a role-A wave: the branch around its loads breaks role B's register allocation)
+  const bool stat_wave = wave == kB64_STATW;  // the wave that stages the tile's statistics (a role-A wave: the branch around its loads breaks role B's register allocation)
   {                                              // base the cursors on head h0, tile t_begin
     const int h = h0;
     // (the cursors point at this wave's groups: 16 gq / 16 gd rows into the tile)
@@ -281,9 +281,9 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
     n_mask = tm - t_begin < 0 ? 0 : (tm - t_begin > n_iter ? n_iter : tm - t_begin);
   }
   int tile_cur = t_begin, buf_a = 0, buf_b = NBUF - 1;     // role A's tile / LDS buffers of A's and B's tiles
-#ifdef USP_B64_TIMING
+USP_TM(
   uint64_t tm_body = 0, tm_drain = 0, tm_bar = 0, tm_last = __builtin_amdgcn_s_memtime();
-#endif
+)
   // Role B works one tile behind role A: the tile it takes NEXT was published a whole iteration ago, so the operands of
   // its first chain (dO row fragments, -delta) are read in the bare slots at the END of the iteration in front -- ahead of
   // the barrier, not behind it, where a lone wave would sit out the LDS round trip with the matrix pipe idle.
@@ -297,10 +297,8 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   auto step = [&](auto role_c, auto mask_c, int it, bool work) __attribute__((always_inline)) {
     constexpr int ROLE = decltype(role_c)::value;
     constexpr bool MASK = decltype(mask_c)::value;
-    constexpr int E0 = USP_B64_E0, E1 = USP_B64_E1;
-#ifndef USP_B64_ABL_ANYSLOT    // dev A/B build: elements in slots where their inputs / consumers are not ready (wrong results)
+    constexpr int E0 = kB64_E0, E1 = kB64_E1;
     static_assert(E0 >= 16 && E1 <= 56 && E1 > E0, "");
-#endif
     // the next tile is fetched unconditionally (past the range of the item it is a tile nobody reads; past the end of
     // the tensor its descriptor is empty): no branch around the pieces
     const int buf_n = buf_a + 1 == NBUF ? 0 : buf_a + 1;      // (it + 1) % NBUF
@@ -417,14 +415,14 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
           const int kt = sl >> 1, kb = sl & 1;
           if (kt == 0) M::template s_first_c<MASK>(sc[h][kb], fc[h][kt], rf[kb][kt], cst[h]);
           else M::template s_next<MASK>(sc[h][kb], fc[h][kt], rf[kb][kt]);
-          if (h == USP_B64_DMA_PH && sl == 0) {         // behind the first MFMA: its scalar work must not idle the matrix pipe
+          if (h == kB64_DMA_PH && sl == 0) {         // behind the first MFMA: its scalar work must not idle the matrix pipe
             __builtin_amdgcn_sched_barrier(0);
             dma_open(buf_n);
           }
           if (sl < NKT) { if (h == 0) rd_c(1, sl); else rd_g(0, sl); }       // the next phase's fragments: slots 0 .. 7
           if (h == 0 && sl == 8) chain_init(1);
           elem_slot(16 * h + sl);
-          if (h == USP_B64_DMA_PH) {                    // the next tile's pieces: role A slots 1, 5, 9, 13; role B slots 1 .. 12
+          if (h == kB64_DMA_PH) {                    // the next tile's pieces: role A slots 1, 5, 9, 13; role B slots 1 .. 12
             if (ROLE == 0 && (sl & 3) == 1) dma_piece(sl >> 2);
             if (ROLE == 1 && sl >= 1 && sl <= 12) dma_piece(sl - 1);
           }
@@ -479,19 +477,13 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
     buf_b = buf_a;
     buf_a = buf_n;
     if (ROLE == 0 || it > 0) ++tile_cur;           // (role B enters its first tile one iteration late)
-#ifdef USP_B64_TIMING        // dev build: where an iteration's time goes (shader cycles, summed per wave; printed for a few waves)
-    const uint64_t tm0 = __builtin_amdgcn_s_memtime();
-    dma_drain();
-    const uint64_t tm1 = __builtin_amdgcn_s_memtime();
-    stats_store(buf_n);
-    __syncthreads();
-    const uint64_t tm2 = __builtin_amdgcn_s_memtime();
-    tm_body += tm0 - tm_last; tm_drain += tm1 - tm0; tm_bar += tm2 - tm1; tm_last = tm2;
-#else
+    USP_TM(const uint64_t tm0 = __builtin_amdgcn_s_memtime();)
     dma_drain();            // this wave's DMA pieces of the staged tile have landed
+    USP_TM(const uint64_t tm1 = __builtin_amdgcn_s_memtime();)
     stats_store(buf_n);
     __syncthreads();
-#endif
+    USP_TM(const uint64_t tm2 = __builtin_amdgcn_s_memtime();
+           tm_body += tm0 - tm_last; tm_drain += tm1 - tm0; tm_bar += tm2 - tm1; tm_last = tm2;)
   };
   const std::integral_constant<int, 0> rA;
   const std::integral_constant<int, 1> rB;
@@ -518,13 +510,13 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
 
   // ---- epilogue -----------------------------------------------------------------------------------------------------------
   mfma_settle(acc);
-#ifdef USP_B64_TIMING
+USP_TM(
   if (pass == 0 && lane == 0 && (blockIdx.x % 61) == 0)
     printf("TM wg %3d wave %d blk %2d n_iter %3d : body %8llu drain %7llu barrier %7llu  (per iteration %5llu / %4llu / %4llu)\n",
            (int)blockIdx.x, wave, blk, n_iter, (unsigned long long)tm_body, (unsigned long long)tm_drain,
            (unsigned long long)tm_bar, (unsigned long long)(tm_body / (n_iter + 1)), (unsigned long long)(tm_drain / (n_iter + 1)),
            (unsigned long long)(tm_bar / (n_iter + 1)));
-#endif
+)
   asm volatile("" : "+s"(p));
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {

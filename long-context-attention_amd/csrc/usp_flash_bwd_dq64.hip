@@ -32,12 +32,9 @@
 
 namespace usp {
 
-#ifndef USP_Q64_PF       // LDS fragments are read this many fragments ahead of the first MFMA that takes them
-#define USP_Q64_PF 3
-#endif
-#ifndef USP_Q64_Y1       // gaps over which the last element stream (dS of query block 1) is spread, from B5 on
-#define USP_Q64_Y1 24
-#endif
+constexpr int kQ64_PF = 3;     // LDS fragments are read this many fragments ahead of the first MFMA that takes them
+constexpr int kQ64_Y1 = 24;    // gaps over which the last element stream (dS of query block 1) is spread, from B5 on
+                               // (neither moves the kernel by more than 0.5 %: profiles/r04_run26*.log)
 
 template <int DT, bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams /* read through the kernarg segment */) {
@@ -48,7 +45,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
   constexpr int TILEB = kTile * ROWB;            // one K (or V) tile: 64 keys
   constexpr int VOFF = 2 * TILEB;                // LDS: Kbuf[0], Kbuf[1], Vbuf[0], Vbuf[1]
   constexpr int NKT = D / 16, NDJ = D / 32;
-  constexpr int PF = USP_Q64_PF;
+  constexpr int PF = kQ64_PF;
 
   // The dynamic LDS block is the kernel's only LDS object and starts at LDS address 0: addresses are formed from that
   // integer (hipcc does not fold the symbol's value and spends a v_add of 0 per address on it).
@@ -295,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
         __builtin_amdgcn_sched_barrier(0);
       }
       // ---------------- B5: dQ^T[0], the K^T fragments arrive | B6: dQ^T[1] | Y[1] over the first Y1 gaps ----------------
-      constexpr int NY1 = USP_Q64_Y1;
+      constexpr int NY1 = kQ64_Y1;
       static_assert(NY1 >= 16 && NY1 <= 28, "dS of k-step ks must be packed before gap 16 + 4 ks");
 #pragma unroll
       for (int i = 0; i < 16; ++i) {

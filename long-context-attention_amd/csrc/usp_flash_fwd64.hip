@@ -30,27 +30,23 @@
 
 namespace usp {
 
-#ifndef USP_F64_NEA      // exp elements (of 64 per lane and tile) issued in phase A; the rest opens phase B, one per slot
-#define USP_F64_NEA 42
+// Placement of the element work and of the LDS-DMA pieces among the 64 MFMA slots of a tile (tuned on the C2 shape,
+// profiles/r04_dma_probes.txt; constants, not build options):
+constexpr int kF64_NEA = 42;    // exp elements (of 64 per lane and tile) issued in phase A; the rest opens phase B, one per slot
+constexpr int kF64_LEAD = 2;    // ... of which in front of the first MFMA of phase A (it waits for the first K fragments anyway)
+constexpr int kF64_PFK = 2;     // K fragments read this many fragments (= 2 MFMA slots each) ahead of their first MFMA
+constexpr int kF64_PFV = 2;     // likewise the V fragments
+constexpr int kF64_MAX0 = 22;   // first slot of phase B that carries row-max work of the next tile
+constexpr int kF64_DMA0 = 2;    // slot (0..63 over both phases) behind whose MFMA the first of the iteration's 8 LDS-DMA pieces
+constexpr int kF64_DMAS = 6;    // goes out, and the distance to the next one
+
+// dev build -DUSP_F64_TIMING: where an item's time goes (s_memtime stamps, printed for a few waves; profiles/r04_run28*.log)
+#ifdef USP_F64_TIMING
+#define USP_TM(...) __VA_ARGS__
+#else
+#define USP_TM(...)
 #endif
-#ifndef USP_F64_LEAD     // ... of which in front of the first MFMA of phase A (it waits for the first K fragments anyway)
-#define USP_F64_LEAD 2
-#endif
-#ifndef USP_F64_PFK      // K fragments read this many fragments (= 2 MFMA slots each) ahead of their first MFMA
-#define USP_F64_PFK 2
-#endif
-#ifndef USP_F64_PFV      // likewise the V fragments
-#define USP_F64_PFV 2
-#endif
-#ifndef USP_F64_MAX0     // first slot of phase B that carries row-max work of the next tile
-#define USP_F64_MAX0 22
-#endif
-#ifndef USP_F64_DMA0     // slot (0..63 over both phases) behind whose MFMA the first of the iteration's 8 LDS-DMA pieces goes
-#define USP_F64_DMA0 2   // out, and the distance to the next one; step 0 = all eight in front of the first MFMA
-#endif
-#ifndef USP_F64_DMAS
-#define USP_F64_DMAS 6
-#endif
+
 template <int DT, bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<false> /* read through the kernarg segment */) {
   using E = Elem<DT>;
@@ -135,9 +131,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   }
   if (n_full > nt) n_full = nt;
 
-#ifdef USP_F64_TIMING          // dev build: where an item's time goes (shader cycles; printed for a few waves)
+USP_TM(
   const uint64_t tm_item = __builtin_amdgcn_s_memtime();
-#endif
+)
   // ---- Q fragments (B operand: lane holds Q[row][16t + 8hi .. +7]), parked in the accumulator file -----------------
   u32x4 qf[2][NKT];
 #pragma unroll
@@ -280,8 +276,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   // against 62 % for the unmasked launch, profiles/r04a_pmc_fwd_*.txt).
   constexpr float kThr = 8.f;
   constexpr int NA = 32, NB = 32;
-  constexpr int NEA = USP_F64_NEA, LEAD = USP_F64_LEAD, PFK = USP_F64_PFK, PFV = USP_F64_PFV, MAX0 = USP_F64_MAX0;
-  constexpr int DMA0 = USP_F64_DMA0, DMAS = USP_F64_DMAS;
+  constexpr int NEA = kF64_NEA, LEAD = kF64_LEAD, PFK = kF64_PFK, PFV = kF64_PFV, MAX0 = kF64_MAX0;
+  constexpr int DMA0 = kF64_DMA0, DMAS = kF64_DMAS;
   static_assert(64 - NEA <= 22, "k-step 3 of P must be complete two slots before slot 24 of phase B");
   static_assert(MAX0 >= 1 && MAX0 < NB && DMAS >= 1 && DMA0 + 7 * DMAS < NA + NB, "");
   const float thr_raw = kThr / c;
@@ -433,10 +429,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   const int n_w = wave_kv_end > 0 ? (wave_kv_end + kBN - 1) / kBN : 0;
   if (n_full > n_w) n_full = n_w;
   int j = 0;
-#ifdef USP_F64_TIMING
+USP_TM(
   const uint64_t tm_loop = __builtin_amdgcn_s_memtime();
   uint64_t tm_hot = tm_loop;
-#endif
+)
   if (n_w > 0) {
     if (n_full == 0) mask(0, sa);
     decide(sa);
@@ -454,18 +450,18 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) sa[qb][kb] = sb[qb][kb];
     };
-#ifdef USP_F64_TIMING
+USP_TM(
     tm_hot = __builtin_amdgcn_s_memtime();
-#endif
+)
     if (j < n_hot) { iter(c0, c0, 0, 0, sa, sb); adopt(); ++j; }
     for (; j < n_w; ++j) {                                   // the diagonal (MODE 1) and this wave's last tile (MODE 2)
       if (j + 1 >= n_w) iter(c2, c2, j & 1, 0, sa, sb);
       else { iter(c2, c1, j & 1, (j + 1) * kBN, sa, sb); adopt(); }
     }
   }
-#ifdef USP_F64_TIMING
+USP_TM(
   const uint64_t tm_own = __builtin_amdgcn_s_memtime();
-#endif
+)
   // ---- the tiles other waves of the workgroup still work on: keep the K/V stream and the barrier cadence -------------
   for (; j < nt; ++j) {
     dma_all(j & 1, (j + 1) & 1);
@@ -473,9 +469,9 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
     __syncthreads();
   }
 
-#ifdef USP_F64_TIMING
+USP_TM(
   const uint64_t tm_idle = __builtin_amdgcn_s_memtime();
-#endif
+)
   // ---- epilogue: normalise, merge with the running result, store (per query block, as in usp_flash_fwd.hip) -------
   mfma_settle(o);
   asm volatile("" : "+s"(p));
@@ -550,7 +546,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
       }
     }
   }
-#ifdef USP_F64_TIMING
+USP_TM(
   {
     const uint64_t tm_end = __builtin_amdgcn_s_memtime();
     if (lane == 0 && (blockIdx.x % 61) == 0 && pass < 4)
@@ -559,7 +555,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
              (unsigned long long)((tm_hot - tm_loop) / (n_full > 2 ? (n_full - 1) / 2 * 2 : 1)), (unsigned long long)(tm_own - tm_hot),
              (unsigned long long)(tm_idle - tm_own), (unsigned long long)(tm_end - tm_idle));
   }
-#endif
+)
   }  // next item
 }
 
