@@ -68,8 +68,30 @@ def applicable(send: torch.Tensor, group) -> bool:
     return plan is not None and stripe_rows(send.shape[1], len(plan[1]))[1] > 0
 
 
+_AGREED = set()          # (shape, dtype) signatures every rank of the world group has confirmed
+
+
+def _agree_once(send: torch.Tensor):
+    """First use of a buffer signature: ONE all-reduce over the world group confirms that every rank entered the relayed
+    exchange with the same shape and dtype (the two grouped phases below would otherwise pair up buffers of different sizes,
+    or leave a rank waiting for a peer that took the direct path).  Raises on every rank when they disagree."""
+    sig = (tuple(send.shape), str(send.dtype))
+    if sig in _AGREED:
+        return
+    h = 0
+    for x in (*send.shape, send.element_size()):
+        h = (h * 1000003 + int(x)) % (1 << 40)
+    t = torch.tensor([float(h), -float(h)], dtype=torch.float64, device=send.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if float(t[0].item()) != float(h) or -float(t[1].item()) != float(h):
+        raise RuntimeError(f"relayed pair exchange: ranks disagree on the exchanged buffer (here {sig}); "
+                           "USP_EXCHANGE_RELAY needs every rank of the block in the same exchange with the same shape")
+    _AGREED.add(sig)
+
+
 def exchange_relayed(send: torch.Tensor, group) -> torch.Tensor:
     """all_to_all_single(send) for a pair: send (2, rows, ...) contiguous, chunk p goes to pair rank p."""
+    _agree_once(send)
     me, me_g = dist.get_rank(), dist.get_rank(group)
     peer, helpers = pair_and_helpers(me)
     assert dist.get_global_rank(group, 1 - me_g) == peer, "the recorded grid does not match the ulysses group"

@@ -93,6 +93,10 @@ USP_DEV u32x4 make_rsrc(const char* base, int64_t bytes) {
   return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, n, 0x00020000u};
 }
 
+// HARDWARE ASSUMPTION (both descriptor forms): the raw-buffer range check of gfx950 covers voffset + the instruction offset
+// + the SCALAR offset -- a piece's row step and group live in the scalar offset, and rows past the last valid one must read
+// as zero.  Checked, not assumed: kbench puts 1 MiB of NaN behind every tensor it uploads, so a lane that escapes the
+// clamp multiplies a NaN into a ragged shape's result (csrc/tools/kbench.cpp: kPoisonTail; the native suite is green).
 // The same for a tile cursor that counts ROWS: `rows` valid rows (any sign) of `row_bytes` each remain from `base`, a tile
 // addresses at most `tile_rows` of them and `used` bytes of a row.  32-bit scalar arithmetic only (five SALU operations): the
 // caller guarantees tile_rows * row_bytes < 2^31.

@@ -13,6 +13,7 @@ the device-side ordering between compute streams, side streams and the transfers
 import threading
 
 import torch
+import torch.distributed
 
 
 class Group:
@@ -138,6 +139,20 @@ class VirtualGrid:
             assert n_recv == len(pairs), "unmatched receives in a grouped call"
             return pairs
         return [Req(self._joint(group, ops, pairs_of))]
+
+    ReduceOp = torch.distributed.ReduceOp
+
+    def all_reduce(self, t, op=None, group=None):
+        """MAX / MIN / SUM over the members of a virtual group (the relayed exchange agrees on its buffer shape once;
+        comm/relay_exchange.py:_agree_once): values meet on the host, every member gets the result."""
+        group = self.world if group is None else group
+        assert isinstance(group, Group)
+        group.pending[self.tls.rank] = t.detach().to("cpu", copy=True)
+        group.barrier.wait()
+        vals = torch.stack([group.pending[m] for m in group.members])
+        red = {self.ReduceOp.MAX: vals.max(0).values, self.ReduceOp.MIN: vals.min(0).values}.get(op, vals.sum(0))
+        group.barrier.wait()                                    # everyone has read `pending` before it is reused
+        t.copy_(red.to(t.device))
 
     def all_to_all_single(self, recv, send, group=None):
         assert isinstance(group, Group) and group.kind == "ulysses"
