@@ -55,9 +55,36 @@ def _dense_case(rs):
 
 @pytest.mark.parametrize("seed", range(_N_DENSE))
 def test_fuzz_dense(dev, seed):
-    from yunchang_amd import _C
     rs = np.random.RandomState(1000 + seed)
-    B, Sq, Sk, Hq, Hkv, D, causal, dt, win, ks, cuts = _dense_case(rs)
+    _run_dense(dev, rs, _dense_case(rs))
+
+
+_N_ROW64 = int(os.environ.get("USP_FUZZ_ROW64", "24"))      # larger sweeps: USP_FUZZ_ROW64=300
+
+
+def _row64_case(rs):
+    """Shapes the one-wave-per-SIMD kernels serve (D = 128, dense, no window, no cuts): forward in both dtypes, backward in
+    bf16 (fp16 backward: the 8-wave kernels).  Longer sequences than the general sweep: several 256-row query blocks and
+    128-key blocks per head, ragged ends, Sq != Sk in both directions, GQA groups up to 8."""
+    dt = str(rs.choice(["bfloat16", "bfloat16", "float16"]))
+    Hkv = int(rs.choice([1, 2]))
+    Hq = Hkv * int(rs.choice([1, 2, 4, 8]))
+    B = int(rs.choice([1, 2]))
+    Sq = int(rs.choice([rs.randint(1, 130), rs.randint(130, 1400)]))
+    Sk = Sq if rs.rand() < 0.5 else int(rs.choice([rs.randint(1, 130), rs.randint(130, 1400)]))
+    causal = bool(rs.rand() < 0.6)
+    return B, Sq, Sk, Hq, Hkv, 128, causal, dt, None, 0, (0, 0)
+
+
+@pytest.mark.parametrize("seed", range(_N_ROW64))
+def test_fuzz_64row_kernels(dev, seed):
+    rs = np.random.RandomState(5000 + seed)
+    _run_dense(dev, rs, _row64_case(rs))
+
+
+def _run_dense(dev, rs, case):
+    from yunchang_amd import _C
+    B, Sq, Sk, Hq, Hkv, D, causal, dt, win, ks, cuts = case
     what = f"B{B} Sq{Sq} Sk{Sk} Hq{Hq} Hkv{Hkv} D{D} causal={causal} {dt} window={win} k_splits={ks} cuts={cuts}"
     wkw = {} if win is None else {"window": win}
     q, k, v, do = (round_to(rs.standard_normal(s).astype(np.float32), dt)
@@ -90,7 +117,14 @@ def test_fuzz_dense(dev, seed):
     for a_, b_, n_ in zip(grads[0], grads[1], ("dq", "dk", "dv")):
         assert np.array_equal(a_, b_), f"{what}: {n_} differs between two launches"
     for g_, r_, n_ in zip(grads[0], (rdq, rdk, rdv), ("dq", "dk", "dv")):
-        assert_close(g_, r_, *TOL[dt]["grad"], f"{what} {n_}")
+        # A gradient entry is a sum of N products whose 16-bit factors (P, dS) carry a relative rounding error of
+        # 2^-9 / sqrt(3) each: the absolute error of the SUM is about 1.1e-3 x rms(entry) per sigma, whatever the entry's own
+        # value -- an entry near a zero crossing of a tensor whose entries are ~20 (1000+ rows per key, ten keys: P is not
+        # small) misses `atol + rtol |want|` by 2x in the 8-wave AND the 64-row kernels alike (kbench bwd 2 1191 10 8 2 128:
+        # dk 7.8e-2 / 9.5e-2).  So the absolute part of the bound never drops below ~7 sigma of that noise.
+        atol, rtol = TOL[dt]["grad"]
+        atol = max(atol, 8e-3 * float(np.sqrt(np.mean(np.square(r_, dtype=np.float64)))))
+        assert_close(g_, r_, atol, rtol, f"{what} {n_}")
 
 
 @pytest.mark.parametrize("seed", range(_N_PACKED))
