@@ -39,7 +39,14 @@ struct BwdParams {
   int* sched;                         // packed mode: control block of the dynamic item queue, or NULL
   int sched_lds;                      // byte offset of the queue's two LDS slots
   int interleave;                     // USP_LAUNCH_INTERLEAVE: one workgroup per item (collectives can slip in)
+  int wide16;                         // 64-row kernels: bit 0 / 1 / 2 = the dq16 / dk16 / dv16 rows are 16-byte aligned and nothing
+                                      // is accumulated into them: whole-row-piece stores (usp_mfma64.hpp: store_row16_wide)
 };
+
+// rows of a 16-bit output tensor start on 16-byte boundaries (base pointer and every stride)
+inline bool rows16_aligned(const char* ptr, int64_t sb, int64_t ss, int64_t sh) {
+  return ptr && (reinterpret_cast<uintptr_t>(ptr) & 15) == 0 && sb % 8 == 0 && ss % 8 == 0 && sh % 8 == 0;
+}
 
 // Packed variable-length batch: rebase the local copy of the parameters on the rows of sequence b (the
 // host passes batch strides of 0 in this mode, so every `b * stride_b` vanishes).  Returns false if the

@@ -996,6 +996,7 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   p.sched = packed ? a->sched : nullptr;
   p.sched_lds = 0;
   p.interleave = (a->flags & USP_LAUNCH_INTERLEAVE) ? 1 : 0;
+  p.wide16 = 0;                                   // (set by the 64-row launches for their own copy)
   p.ws_rows = ws_rows_of(a);
   if (packed) {
     p.do_sb = p.q_sb = p.k_sb = p.v_sb = p.lse_sb = p.dl_sb = 0;

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   int w = walk.at(pass);
   if (w < 0) break;
   asm volatile("" : "+s"(p));
+  USP_TM(const uint64_t tm_item = __builtin_amdgcn_s_memtime();)
   w = walk.dealt(w, p->nblk);
   const int blk = w % p->nblk;                   // early key blocks are seen by most rows: first
   int rest = w / p->nblk;
@@ -283,6 +284,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   int tile_cur = t_begin, buf_a = 0, buf_b = NBUF - 1;     // role A's tile / LDS buffers of A's and B's tiles
 USP_TM(
   uint64_t tm_body = 0, tm_drain = 0, tm_bar = 0, tm_last = __builtin_amdgcn_s_memtime();
+  const uint64_t tm_loop = tm_last;
 )
   // Role B works one tile behind role A: the tile it takes NEXT was published a whole iteration ago, so the operands of
   // its first chain (dO row fragments, -delta) are read in the bare slots at the END of the iteration in front -- ahead of
@@ -511,6 +513,7 @@ USP_TM(
   // ---- epilogue -----------------------------------------------------------------------------------------------------------
   mfma_settle(acc);
 USP_TM(
+  const uint64_t tm_epi = __builtin_amdgcn_s_memtime();
   if (pass == 0 && lane == 0 && (blockIdx.x % 61) == 0)
     printf("TM wg %3d wave %d blk %2d n_iter %3d : body %8llu drain %7llu barrier %7llu  (per iteration %5llu / %4llu / %4llu)\n",
            (int)blockIdx.x, wave, blk, n_iter, (unsigned long long)tm_body, (unsigned long long)tm_drain,
@@ -518,10 +521,17 @@ USP_TM(
            (unsigned long long)(tm_bar / (n_iter + 1)));
 )
   asm volatile("" : "+s"(p));
+  // 16-bit final output of this role's tensor, rows 16-byte aligned, nothing accumulated, no head-split partials
+  const bool wide = !p->split && (p->wide16 & (role == 0 ? 4 : 2)) != 0;
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb) {
     const int orow = ow + 32 * kb + l31;
-    if (orow < p->Sk) {
+    if (wide) {
+      const int orow_c = orow < p->Sk ? orow : 0;
+      char* row16 = role == 0 ? p->dv16 + 2 * (b * p->dv16_sb + (int64_t)orow_c * p->dv16_ss + hkv * p->dv16_sh)
+                              : p->dk16 + 2 * (b * p->dk16_sb + (int64_t)orow_c * p->dk16_ss + hkv * p->dk16_sh);
+      store_row16_wide<E, NDJ>(row16, acc[kb], role == 0 ? 1.f : p->scale, hi, orow < p->Sk);
+    } else if (orow < p->Sk) {
       float* o32;
       char* o16 = nullptr;
       int accf;
@@ -549,6 +559,12 @@ USP_TM(
         }
     }
   }
+USP_TM(
+  if (pass < 3 && lane == 0 && (blockIdx.x % 61) == 0)
+    printf("TI wg %3d pass %d wave %d blk %2d n_iter %3d n_mask %d : prologue %6llu loops %8llu epilogue %6llu\n", (int)blockIdx.x, pass,
+           wave, blk, n_iter, n_mask, (unsigned long long)(tm_loop - tm_item), (unsigned long long)(tm_epi - tm_loop),
+           (unsigned long long)(__builtin_amdgcn_s_memtime() - tm_epi));
+)
   }  // next item
 }
 
@@ -571,6 +587,8 @@ bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st
   if ((p_in.q_ss * 2) % 256 != 0 || (p_in.do_ss * 2) % 256 != 0 || p_in.q_ss * 128 >= (1LL << 31) || p_in.do_ss * 128 >= (1LL << 31))
     return false;
   BwdParams p = p_in;
+  p.wide16 = ((p.dk16 && !p.accum_dk && rows16_aligned(p.dk16, p.dk16_sb, p.dk16_ss, p.dk16_sh)) ? 2 : 0) |
+             ((p.dv16 && !p.accum_dv && rows16_aligned(p.dv16, p.dv16_sb, p.dv16_ss, p.dv16_sh)) ? 4 : 0);
   p.nblk = (p.Sk + 127) / 128;
   p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1) * p.qsplit;
   // persistent: one workgroup per CU; USP_LAUNCH_INTERLEAVE: one workgroup per item (the same kernel: a workgroup's item

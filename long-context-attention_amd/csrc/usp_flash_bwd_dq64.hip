@@ -36,6 +36,13 @@ constexpr int kQ64_PF = 3;     // LDS fragments are read this many fragments ahe
 constexpr int kQ64_Y1 = 24;    // gaps over which the last element stream (dS of query block 1) is spread, from B5 on
                                // (neither moves the kernel by more than 0.5 %: profiles/r04_run26*.log)
 
+// dev build -DUSP_Q64_TIMING: where an item's time goes (s_memtime stamps, printed for a few waves)
+#ifdef USP_Q64_TIMING
+#define USP_TM(...) __VA_ARGS__
+#else
+#define USP_TM(...)
+#endif
+
 template <int DT, bool CAUSAL>
 __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams /* read through the kernarg segment */) {
   using E = Elem<DT>;
@@ -88,6 +95,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
   int w = walk.at(pass);
   if (w < 0) break;
   asm volatile("" : "+s"(p));
+  USP_TM(const uint64_t tm_item = __builtin_amdgcn_s_memtime();)
   w = walk.dealt(w, p->nblk);
   const int qt_r = w % p->nblk;
   const int rest = w / p->nblk;
@@ -323,20 +331,28 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
   const std::integral_constant<bool, false> plain;
   const std::integral_constant<bool, true> masked;
   int t = 0;
+  USP_TM(const uint64_t tm_loop = __builtin_amdgcn_s_memtime();)
   __builtin_amdgcn_s_waitcnt(0x0f70);            // (usp_flash_bwd64.hip: nothing may still count as pending at a loop header)
   for (; t < n_full; ++t) iter(plain, t, true);
   __builtin_amdgcn_s_waitcnt(0x0f70);
   for (; t < n_w; ++t) iter(masked, t, true);
   mfma_settle(dq);
+  USP_TM(const uint64_t tm_own = __builtin_amdgcn_s_memtime(); const uint64_t tm_plain_n = n_full;)
   for (; t < nt; ++t) iter(plain, t, false);     // tiles other waves of the workgroup still work on: keep the cadence
+  USP_TM(const uint64_t tm_epi = __builtin_amdgcn_s_memtime();)
 
   // ---- epilogue: fp32 store / accumulate, or final 16-bit store (dQ^T: a lane holds 4-dim pieces of ONE query row) --------
   mfma_settle(dq);
   asm volatile("" : "+s"(p));
+  const bool wide = (p->wide16 & 1) != 0;         // 16-bit final output, rows 16-byte aligned, nothing accumulated
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int row = qw + 32 * qb + l31;
-    if (row < p->Sq) {
+    if (wide) {
+      const int row_c = row < p->Sq ? row : 0;
+      store_row16_wide<E, NDJ>(p->dq16 + 2 * (b * p->dq16_sb + (int64_t)row_c * p->dq16_ss + h * p->dq16_sh), dq[qb], p->scale, hi,
+                               row < p->Sq);
+    } else if (row < p->Sq) {
       float* o1 = p->dq + b * p->dq_sb + (int64_t)row * p->dq_ss + h * p->dq_sh;
       char* h1 = p->dq16 ? p->dq16 + 2 * (b * p->dq16_sb + (int64_t)row * p->dq16_ss + h * p->dq16_sh) : nullptr;
       const int acc_f = p->accum_dq;
@@ -355,6 +371,13 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
     }
   }
   __syncthreads();          // the next item's prologue refills the tile buffers
+USP_TM(
+  if (pass < 3 && lane == 0 && (blockIdx.x % 61) == 0)
+    printf("TQ wg %3d pass %d wave %d qt %2d tiles own %3d (plain %3d) wg %3d : prologue %6llu own tiles %8llu (%5llu / tile) idle %6llu epilogue %6llu\n",
+           (int)blockIdx.x, pass, wave, qt, n_w, (int)tm_plain_n, nt, (unsigned long long)(tm_loop - tm_item),
+           (unsigned long long)(tm_own - tm_loop), (unsigned long long)((tm_own - tm_loop) / (n_w > 0 ? n_w : 1)),
+           (unsigned long long)(tm_epi - tm_own), (unsigned long long)(__builtin_amdgcn_s_memtime() - tm_epi));
+)
   }  // next item
 }
 
@@ -374,6 +397,7 @@ bool launch_dq64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st, 
   BwdParams p = p_in;
   p.nblk = (p.Sq + 255) / 256;
   p.n_items = p.B * p.Hq * p.nblk;
+  p.wide16 = (p.dq16 && !p.accum_dq && rows16_aligned(p.dq16, p.dq16_sb, p.dq16_ss, p.dq16_sh)) ? 1 : 0;
   const int grid = (!p.interleave && p.n_items > cus) ? cus : p.n_items;      // persistent: one workgroup per CU
   const size_t lds = 4 * kTile * 128 * 2;
   if (causal) hipLaunchKernelGGL((flash_bwd_dq64_kernel<0, true>), dim3(grid), dim3(256), lds, st, p);

@@ -107,4 +107,28 @@ USP_DEV u32x4 make_rsrc_rows(const char* base, int rows, int tile_rows, int row_
   return u32x4{(uint32_t)a, (uint32_t)(a >> 32) & 0xffffu, (uint32_t)(n > 0 ? n : 0), 0x00020000u};
 }
 
+// 16-bit store of one transposed accumulator row block (O^T / dQ^T / dK^T / dV^T: a lane holds 4-dim pieces of ONE row, the
+// two half-waves interleaved in 8-byte pieces): one v_permlane32_swap per dword regroups two adjacent pieces into 16
+// contiguous bytes per lane, so a row block leaves in 8 dwordx4 stores instead of 16 dwordx2 -- the store tail of these
+// kernels is issue-bound (per-lane stores at a row stride).  EVERY lane of the wave must call it (the swap pairs lane l with
+// l + 32, which hold the same row); `valid` gates the stores only.  `row` must be 16-byte aligned.
+template <class E, int NDJ>
+USP_DEV void store_row16_wide(char* row, const f32x16 (&t)[NDJ], float mul, int hi, bool valid) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+  for (int dj = 0; dj < NDJ; ++dj)
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      const int r0 = 8 * g2;
+      const uint32_t ax = E::pack2(t[dj][r0] * mul, t[dj][r0 + 1] * mul);
+      const uint32_t ay = E::pack2(t[dj][r0 + 2] * mul, t[dj][r0 + 3] * mul);
+      const uint32_t bx = E::pack2(t[dj][r0 + 4] * mul, t[dj][r0 + 5] * mul);
+      const uint32_t by = E::pack2(t[dj][r0 + 6] * mul, t[dj][r0 + 7] * mul);
+      const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+      if (valid) *(u32x4*)(row + 2 * (32 * dj + 16 * g2 + 8 * hi)) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+    }
+#endif
+}
+
 }  // namespace usp
