@@ -124,21 +124,30 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   // streaming loops and puts a cascade of s_waitcnt vmcnt(20 .. 0) in front of the fragments' first use in EVERY iteration
   // -- its vmcnt(0) then waits for the statistics wave's fresh loads, a memory round trip per tile.
   u32x4 rf[2][NKT];
+  {
+    const char* pr[2];
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    const int orow = ow + 32 * kb + l31;
-    const int orow_c = orow < p->Sk ? orow : p->Sk - 1;
-    const char* pr = (role == 0 ? p->k + 2 * (b * p->k_sb + (int64_t)orow_c * p->k_ss + hkv * p->k_sh)
-                                : p->v + 2 * (b * p->v_sb + (int64_t)orow_c * p->v_ss + hkv * p->v_sh)) + 16 * hi;
+    for (int kb = 0; kb < 2; ++kb) {
+      const int orow = ow + 32 * kb + l31;
+      const int orow_c = orow < p->Sk ? orow : p->Sk - 1;
+      pr[kb] = (role == 0 ? p->k + 2 * (b * p->k_sb + (int64_t)orow_c * p->k_ss + hkv * p->k_sh)
+                          : p->v + 2 * (b * p->v_sb + (int64_t)orow_c * p->v_ss + hkv * p->v_sh)) + 16 * hi;
+    }
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:32\n\t"
-                 "global_load_dwordx4 %2, %8, off offset:64\n\tglobal_load_dwordx4 %3, %8, off offset:96\n\t"
-                 "global_load_dwordx4 %4, %8, off offset:128\n\tglobal_load_dwordx4 %5, %8, off offset:160\n\t"
-                 "global_load_dwordx4 %6, %8, off offset:192\n\tglobal_load_dwordx4 %7, %8, off offset:224\n\t"
+    // (both key blocks' 16 loads, ONE wait: one memory round trip per item instead of two)
+    asm volatile("global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\t"
+                 "global_load_dwordx4 %2, %16, off offset:64\n\tglobal_load_dwordx4 %3, %16, off offset:96\n\t"
+                 "global_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"
+                 "global_load_dwordx4 %6, %16, off offset:192\n\tglobal_load_dwordx4 %7, %16, off offset:224\n\t"
+                 "global_load_dwordx4 %8, %17, off\n\tglobal_load_dwordx4 %9, %17, off offset:32\n\t"
+                 "global_load_dwordx4 %10, %17, off offset:64\n\tglobal_load_dwordx4 %11, %17, off offset:96\n\t"
+                 "global_load_dwordx4 %12, %17, off offset:128\n\tglobal_load_dwordx4 %13, %17, off offset:160\n\t"
+                 "global_load_dwordx4 %14, %17, off offset:192\n\tglobal_load_dwordx4 %15, %17, off offset:224\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&a"(rf[kb][0]), "=&a"(rf[kb][1]), "=&a"(rf[kb][2]), "=&a"(rf[kb][3]), "=&a"(rf[kb][4]), "=&a"(rf[kb][5]),
-                   "=&a"(rf[kb][6]), "=&a"(rf[kb][7])
-                 : "v"(pr) : "memory");
+                 : "=&a"(rf[0][0]), "=&a"(rf[0][1]), "=&a"(rf[0][2]), "=&a"(rf[0][3]), "=&a"(rf[0][4]), "=&a"(rf[0][5]),
+                   "=&a"(rf[0][6]), "=&a"(rf[0][7]), "=&a"(rf[1][0]), "=&a"(rf[1][1]), "=&a"(rf[1][2]), "=&a"(rf[1][3]),
+                   "=&a"(rf[1][4]), "=&a"(rf[1][5]), "=&a"(rf[1][6]), "=&a"(rf[1][7])
+                 : "v"(pr[0]), "v"(pr[1]) : "memory");
 #endif
   }
 

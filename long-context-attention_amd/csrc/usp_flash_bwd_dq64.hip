@@ -136,22 +136,20 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
     const char* qp = p->q + 2 * (b * p->q_sb + (int64_t)row_c * p->q_ss + h * p->q_sh) + 16 * hi;
     const char* dp = p->dout + 2 * (b * p->do_sb + (int64_t)row_c * p->do_ss + h * p->do_sh) + 16 * hi;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:32\n\t"
-                 "global_load_dwordx4 %2, %8, off offset:64\n\tglobal_load_dwordx4 %3, %8, off offset:96\n\t"
-                 "global_load_dwordx4 %4, %8, off offset:128\n\tglobal_load_dwordx4 %5, %8, off offset:160\n\t"
-                 "global_load_dwordx4 %6, %8, off offset:192\n\tglobal_load_dwordx4 %7, %8, off offset:224\n\t"
+    // (16 loads, ONE wait: the four groups of an item cost two memory round trips, not four)
+    asm volatile("global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\t"
+                 "global_load_dwordx4 %2, %16, off offset:64\n\tglobal_load_dwordx4 %3, %16, off offset:96\n\t"
+                 "global_load_dwordx4 %4, %16, off offset:128\n\tglobal_load_dwordx4 %5, %16, off offset:160\n\t"
+                 "global_load_dwordx4 %6, %16, off offset:192\n\tglobal_load_dwordx4 %7, %16, off offset:224\n\t"
+                 "global_load_dwordx4 %8, %17, off\n\tglobal_load_dwordx4 %9, %17, off offset:32\n\t"
+                 "global_load_dwordx4 %10, %17, off offset:64\n\tglobal_load_dwordx4 %11, %17, off offset:96\n\t"
+                 "global_load_dwordx4 %12, %17, off offset:128\n\tglobal_load_dwordx4 %13, %17, off offset:160\n\t"
+                 "global_load_dwordx4 %14, %17, off offset:192\n\tglobal_load_dwordx4 %15, %17, off offset:224\n\t"
                  "s_waitcnt vmcnt(0)"
                  : "=&a"(qf[qb][0]), "=&a"(qf[qb][1]), "=&a"(qf[qb][2]), "=&a"(qf[qb][3]), "=&a"(qf[qb][4]), "=&a"(qf[qb][5]),
-                   "=&a"(qf[qb][6]), "=&a"(qf[qb][7])
-                 : "v"(qp) : "memory");
-    asm volatile("global_load_dwordx4 %0, %8, off\n\tglobal_load_dwordx4 %1, %8, off offset:32\n\t"
-                 "global_load_dwordx4 %2, %8, off offset:64\n\tglobal_load_dwordx4 %3, %8, off offset:96\n\t"
-                 "global_load_dwordx4 %4, %8, off offset:128\n\tglobal_load_dwordx4 %5, %8, off offset:160\n\t"
-                 "global_load_dwordx4 %6, %8, off offset:192\n\tglobal_load_dwordx4 %7, %8, off offset:224\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&a"(df[qb][0]), "=&a"(df[qb][1]), "=&a"(df[qb][2]), "=&a"(df[qb][3]), "=&a"(df[qb][4]), "=&a"(df[qb][5]),
-                   "=&a"(df[qb][6]), "=&a"(df[qb][7])
-                 : "v"(dp) : "memory");
+                   "=&a"(qf[qb][6]), "=&a"(qf[qb][7]), "=&a"(df[qb][0]), "=&a"(df[qb][1]), "=&a"(df[qb][2]), "=&a"(df[qb][3]),
+                   "=&a"(df[qb][4]), "=&a"(df[qb][5]), "=&a"(df[qb][6]), "=&a"(df[qb][7])
+                 : "v"(qp), "v"(dp) : "memory");
 #endif
     const float lse = p->lse[b * p->lse_sb + h * p->lse_sh + row_c];
     const float dlt = p->delta[b * p->dl_sb + h * p->dl_sh + row_c];
