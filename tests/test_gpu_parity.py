@@ -1129,3 +1129,11 @@ def test_head_dims_between_the_instantiated_ones(dev, single_rank_pg, D):
     big = torch.zeros((1, 64, 2, 256), dtype=torch.bfloat16, device=dev)
     with pytest.raises(NotImplementedError):
         hip_attn_forward(big, big, big, causal=True)
+
+
+def test_kernel_rate_probe_measures_a_plausible_rate(dev):
+    """comm/link.py:_probe_kernel_rate (run beside the link probe at set_seq_parallel_pg when USP_LINK_PROBE=1): the forward
+    kernel on a part-filling launch, between 0.2 and 2.5 PFLOP/s on an MI355X."""
+    import yunchang_amd.comm.link as L
+    rate = L._probe_kernel_rate(dev)
+    assert 2e14 < rate < 2.5e15, rate
