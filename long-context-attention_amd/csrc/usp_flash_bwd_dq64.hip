@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
   for (int qb = 0; qb < 2; ++qb) {
     const int row = qw + 32 * qb + l31;
     const int row_c = row < p->Sq ? row : p->Sq - 1;
-    const char* qp = p->q + 2 * (b * p->q_sb + (int64_t)row_c * p->q_ss + h * p->q_sh) + 16 * hi;
-    const char* dp = p->dout + 2 * (b * p->do_sb + (int64_t)row_c * p->do_ss + h * p->do_sh) + 16 * hi;
+    [[maybe_unused]] const char* qp = p->q + 2 * (b * p->q_sb + (int64_t)row_c * p->q_ss + h * p->q_sh) + 16 * hi;
+    [[maybe_unused]] const char* dp = p->dout + 2 * (b * p->do_sb + (int64_t)row_c * p->do_ss + h * p->do_sh) + 16 * hi;
 #if defined(__HIP_DEVICE_COMPILE__)
     // (16 loads, ONE wait: the four groups of an item cost two memory round trips, not four)
     asm volatile("global_load_dwordx4 %0, %16, off\n\tglobal_load_dwordx4 %1, %16, off offset:32\n\t"
