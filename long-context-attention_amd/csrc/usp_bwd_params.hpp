@@ -84,7 +84,7 @@ template <int D> USP_DEV int tile_swz(int row) {
 // complete argument block of the dK/dV launch (nblk / n_items are set inside).  Returns false when the launch is not
 // one it serves (the caller then takes the 8-wave kernel).
 bool launch_dkdv64(const BwdParams& p, int dtype, bool causal, hipStream_t st, int* rc);
-// The one-wave-per-SIMD dQ launch (usp_flash_bwd_dq64.hip): dense bf16 launches of D = 128 without a window or a key cut.
+// The one-wave-per-SIMD dQ launch (usp_flash_bwd_dq64.hip): dense launches of D = 128 (bf16 / fp16) without a window or a key cut.
 bool launch_dq64(const BwdParams& p, int dtype, bool causal, hipStream_t st, int* rc);
 
 }  // namespace usp

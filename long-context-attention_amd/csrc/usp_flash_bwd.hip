@@ -6,7 +6,7 @@
 //   dQ     (flash_bwd_kernel)      : workgroup = 8 waves x 32 query rows; streams K,V tiles (64 keys) through LDS.
 //                                    lane owns a query row:  S^T = K Q^T, dP^T = V dO^T, dQ^T += K^T dS^T
 //   dK, dV (flash_bwd_dkdv_kernel) : workgroup = 8 waves, 128 keys, two roles (below); the one-wave-per-SIMD form of it
-//                                    lives in usp_flash_bwd64.hip and serves the dense bf16 D = 128 launches.
+//                                    lives in usp_flash_bwd64.hip and serves the dense D = 128 launches.
 // Both are one engine: two LDS tiles X1,X2 (row-major, 16-byte-slot XOR swizzle chosen so that
 // BOTH ds_read_b128 row reads and ds_read_b64_tr_b16 column reads are bank-conflict free), two
 // register-resident fragment sets R1,R2, S = X1 R1^T, T = X2 R2^T, and tr-read "X^T" operands for

@@ -586,9 +586,8 @@ bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st
     return n;
   }();
   if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on) return false;
-  // fp16: hipcc's register allocation of that instantiation copies the accumulators between the register files inside the
-  // loop and reads one of them right behind its MFMA (tools/mfma_hazards.py: 22 hazards) -- served by the 8-wave kernel
-  if (dtype != USP_BF16) return false;
+  // (fp16: round 4's first build of that instantiation copied accumulators between the register files inside the loop; with the
+  // chains started from the row constants it compiles like the bf16 one -- tools/mfma_hazards.py: 0 -- and is served here too)
   if (!p_in.split && p_in.G > 1) return false;   // the in-workgroup loop over a GQA group's heads stays with the 8-wave kernel
   // the pieces' swizzle is XORed into the per-lane byte offset (row part a multiple of 256 bytes); per-lane offsets and the
   // pieces' scalar offsets are 32-bit: 64 rows of Q / dO must span less than 2^31 bytes.  (Base pointer and remaining
@@ -604,8 +603,13 @@ bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st
   // list then has one entry)
   const int grid = (!p.interleave && p.n_items > cus) ? cus : p.n_items;
   constexpr size_t lds = 3 * (2 * kTile * 128 * 2 + 2 * kTile * 4) + 2 * 2 * 8192;
-  if (causal) hipLaunchKernelGGL((flash_bwd_dkdv64_kernel<0, true>), dim3(grid), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((flash_bwd_dkdv64_kernel<0, false>), dim3(grid), dim3(256), lds, st, p);
+  if (dtype == USP_BF16) {
+    if (causal) hipLaunchKernelGGL((flash_bwd_dkdv64_kernel<0, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((flash_bwd_dkdv64_kernel<0, false>), dim3(grid), dim3(256), lds, st, p);
+  } else {
+    if (causal) hipLaunchKernelGGL((flash_bwd_dkdv64_kernel<1, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((flash_bwd_dkdv64_kernel<1, false>), dim3(grid), dim3(256), lds, st, p);
+  }
   *rc = hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
   return true;
 }

@@ -387,9 +387,9 @@ bool launch_dq64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st, 
       n = 256;
     return n;
   }();
-  // dense bf16 launches without a window, a cut of the key range or the dynamic item queue; the pieces' swizzle is XORed
+  // dense launches (bf16 / fp16) without a window, a cut of the key range or the dynamic item queue; the pieces' swizzle is XORed
   // into the per-lane byte offset (rows a multiple of 256 bytes apart), 64 rows of K / V span less than 2^31 bytes
-  if (dtype != USP_BF16 || p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on || p_in.ksplit > 1) return false;
+  if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on || p_in.ksplit > 1) return false;
   if ((p_in.k_ss * 2) % 256 != 0 || (p_in.v_ss * 2) % 256 != 0 || p_in.k_ss * 128 >= (1LL << 31) || p_in.v_ss * 128 >= (1LL << 31))
     return false;
   BwdParams p = p_in;
@@ -398,8 +398,13 @@ bool launch_dq64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st, 
   p.wide16 = (p.dq16 && !p.accum_dq && rows16_aligned(p.dq16, p.dq16_sb, p.dq16_ss, p.dq16_sh)) ? 1 : 0;
   const int grid = (!p.interleave && p.n_items > cus) ? cus : p.n_items;      // persistent: one workgroup per CU
   const size_t lds = 4 * kTile * 128 * 2;
-  if (causal) hipLaunchKernelGGL((flash_bwd_dq64_kernel<0, true>), dim3(grid), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL((flash_bwd_dq64_kernel<0, false>), dim3(grid), dim3(256), lds, st, p);
+  if (dtype == USP_BF16) {
+    if (causal) hipLaunchKernelGGL((flash_bwd_dq64_kernel<0, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((flash_bwd_dq64_kernel<0, false>), dim3(grid), dim3(256), lds, st, p);
+  } else {
+    if (causal) hipLaunchKernelGGL((flash_bwd_dq64_kernel<1, true>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((flash_bwd_dq64_kernel<1, false>), dim3(grid), dim3(256), lds, st, p);
+  }
   *rc = hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
   return true;
 }
