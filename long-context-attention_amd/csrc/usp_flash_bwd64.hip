@@ -589,6 +589,8 @@ bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st
   // (fp16: round 4's first build of that instantiation copied accumulators between the register files inside the loop; with the
   // chains started from the row constants it compiles like the bf16 one -- tools/mfma_hazards.py: 0 -- and is served here too)
   if (!p_in.split && p_in.G > 1) return false;   // the in-workgroup loop over a GQA group's heads stays with the 8-wave kernel
+  // role A keeps K * scale * log2(e) in the 16-bit type: with fp16 an unusually large softmax scale could overflow it
+  if (dtype != USP_BF16 && !(p_in.scale_log2 <= 8.f)) return false;
   // the pieces' swizzle is XORed into the per-lane byte offset (row part a multiple of 256 bytes); per-lane offsets and the
   // pieces' scalar offsets are 32-bit: 64 rows of Q / dO must span less than 2^31 bytes.  (Base pointer and remaining
   // bytes are 64-bit: no sequence length is refused -- the 8-wave kernel addresses a head by a 32-bit offset and is.)
