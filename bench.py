@@ -499,6 +499,14 @@ def exchange_mode(attn, lq, lk, cfg, ws):
             + (", sized for the forward K split" if ks else ""))
 
 
+def _never_fatal(fn, *a):
+    """A descriptive field must not cost the measurement its line."""
+    try:
+        return fn(*a)
+    except Exception as e:
+        return {"error": repr(e)[:200]}
+
+
 def run_env():
     """Every environment switch that can change what this run measures (the library reads USP_*; RCCL / HSA / HIP read theirs)."""
     keys = sorted(k for k in os.environ if k.startswith(("USP_", "NCCL_", "RCCL_", "HSA_", "HIP_", "GPU_MAX_HW_QUEUES", "TORCH_NCCL_")))
@@ -824,7 +832,7 @@ def main(argv=None, dev=None):
                        "ulysses_exchange": exchange_mode(attn, lq, lk, cfg, ws),
                        "comm_mode": comm_mode,
                        "env": run_env(),
-                       "derived": derived_decisions(cfg, attn, lq, lk, ws),
+                       "derived": _never_fatal(derived_decisions, cfg, attn, lq, lk, ws),
                        "tokens_per_gpu": cfg["S"] * cfg["B"] // ws,
                        "assumed": "B=1 and causal=True where BASELINE.json's config string is silent",
                        "host": f"host-only work (gc.collect + gc.freeze, PMC lookup) first, then device work only: kernel "
