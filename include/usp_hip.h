@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USP_ABI_VERSION 5
+#define USP_ABI_VERSION 6
 
 enum { USP_BF16 = 0, USP_FP16 = 1 };
 
@@ -50,6 +50,19 @@ enum {
 /* USP_ATTN_WINDOW (ABI v5): the window_left / window_right fields are valid (without the bit they are ignored, so a
  * zero-initialised struct means "no window", not "window (0, 0)"). */
 #define USP_ATTN_WINDOW 2
+/* Kernel-family selectors (ABI v6; usp_flash_fwd / usp_flash_bwd).  The library holds two families of flash kernels: the
+ * one-wave-per-SIMD family (a wave owns 64 rows / keys and its SIMD's whole register file: usp_flash_fwd64.hip,
+ * usp_flash_bwd64.hip, usp_flash_bwd_dq64.hip) and the two-waves-per-SIMD family (32 rows per wave, 8 or 4 waves:
+ * usp_flash_fwd.hip, usp_flash_bwd.hip), and picks per launch.  With one of these bits the caller picks -- per CALL, not
+ * per process -- which is what lets a parity test pin the kernel it means to test, and a bench time both families on
+ * the same box:
+ *   USP_FORCE_ROW64   every flash kernel of the call must come from the 64-row family; a call that family does not
+ *                     serve (head dim != 128, packed batch, window, forward K split, GQA without the head-split
+ *                     workspace) returns USP_EUNSUPPORTED and launches nothing;
+ *   USP_FORCE_WAVE32  every flash kernel of the call comes from the 32-rows-per-wave family.
+ * Both bits at once: USP_EINVAL.  usp_last_launch_kinds() reports what a call actually launched. */
+#define USP_FORCE_ROW64 4
+#define USP_FORCE_WAVE32 8
 
 typedef struct usp_tensor {
   void* ptr;
@@ -240,6 +253,23 @@ int usp_cast_from_f32(int32_t dtype, void* dst, int64_t dst_row_stride, const fl
  * at zigzag_ring_flash_attn.py:161-170 / ring_flash_attn.py:130-131. */
 int usp_add_f32(float* dst, int64_t dst_row_stride, const float* a, int64_t a_row_stride,
                 const float* b, int64_t b_row_stride, int64_t rows, int64_t n, void* stream);
+
+/* What the LAST usp_flash_fwd / usp_flash_bwd call of the CALLING THREAD launched: a mask of USP_KIND_* bits (0 before
+ * the first call and after a call that returned an error before launching).  Thread-local: no state is shared between
+ * threads, the entry points stay re-entrant.  For tests ("assert the 64-row forward ran") and bench labels. */
+enum {
+  USP_KIND_FWD_ROW64 = 1,       /* flash_fwd64_kernel        (4 waves x 64 rows) */
+  USP_KIND_FWD_WAVE8 = 2,       /* flash_fwd_kernel, 8 waves (256 rows per item) */
+  USP_KIND_FWD_WAVE4 = 4,       /* flash_fwd_kernel, 4 waves (128 rows per item) */
+  USP_KIND_FWD_SPLIT_MERGE = 8, /* split_merge_kernel behind a K-split launch */
+  USP_KIND_DKDV_ROW64 = 16,     /* flash_bwd_dkdv64_kernel */
+  USP_KIND_DKDV_WAVE8 = 32,     /* flash_bwd_dkdv_kernel */
+  USP_KIND_DQ_ROW64 = 64,       /* flash_bwd_dq64_kernel */
+  USP_KIND_DQ_WAVE8 = 128,      /* flash_bwd_kernel (dQ) */
+  USP_KIND_REDUCE_HEADS = 256,  /* reduce_heads_kernel (GQA head split / dK,dV cuts) */
+  USP_KIND_REDUCE_CUTS = 512    /* reduce_cuts_kernel (dQ key cuts) */
+};
+int usp_last_launch_kinds(void);
 
 int usp_abi_version(void);
 const char* usp_strerror(int code);

@@ -20,7 +20,41 @@ _lib = None
 USP_BF16, USP_FP16 = 0, 1
 USP_LAUNCH_INTERLEAVE = 1      # include/usp_hip.h: launch so that collectives on other streams can slip in
 USP_ATTN_WINDOW = 2            # the window_left / window_right fields are valid
-ABI_VERSION = 5
+USP_FORCE_ROW64 = 4            # ABI v6: the call must be served by the one-wave-per-SIMD (64-row) kernel family ...
+USP_FORCE_WAVE32 = 8           # ... or by the two-waves-per-SIMD (32 rows per wave) family
+ABI_VERSION = 6
+# usp_last_launch_kinds(): bit -> kernel (include/usp_hip.h, USP_KIND_*)
+KINDS = {1: "fwd_row64", 2: "fwd_wave8", 4: "fwd_wave4", 8: "fwd_split_merge", 16: "dkdv_row64", 32: "dkdv_wave8",
+         64: "dq_row64", 128: "dq_wave8", 256: "reduce_heads", 512: "reduce_cuts"}
+_FAMILY_FLAG = {None: 0, "auto": 0, "row64": USP_FORCE_ROW64, "wave32": USP_FORCE_WAVE32}
+# In-process default of the `family` argument of flash_fwd / flash_bwd (tests, A/B runs: bench.py times both families
+# on the same box).  "auto": the library decides per launch.
+_FAMILY_DEFAULT = "auto"
+
+
+def set_kernel_family(family) -> str:
+    """Default kernel family of dense flash launches issued through this binding: "auto" | "row64" | "wave32";
+    returns the previous setting.  Per call the `family` argument overrides it."""
+    global _FAMILY_DEFAULT
+    if family not in _FAMILY_FLAG:
+        raise ValueError(f"kernel family must be one of {sorted(k for k in _FAMILY_FLAG if k)}, got {family!r}")
+    prev, _FAMILY_DEFAULT = _FAMILY_DEFAULT, (family or "auto")
+    return prev
+
+
+def _family_flag(family) -> int:
+    if family is None:
+        family = _FAMILY_DEFAULT
+    try:
+        return _FAMILY_FLAG[family]
+    except KeyError:
+        raise ValueError(f"kernel family must be one of {sorted(k for k in _FAMILY_FLAG if k)}, got {family!r}") from None
+
+
+def last_launch_kinds() -> tuple:
+    """Names of the kernels the calling thread's last flash_fwd / flash_bwd launched (usp_last_launch_kinds)."""
+    m = load().usp_last_launch_kinds()
+    return tuple(name for bit, name in KINDS.items() if m & bit)
 
 
 class UspTensor(ctypes.Structure):
@@ -65,7 +99,7 @@ class UspBwdArgs(ctypes.Structure):
 
 
 EXPORTS = ("usp_flash_fwd", "usp_flash_fwd_workspace_bytes", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
-           "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror")
+           "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror", "usp_last_launch_kinds")
 
 
 def lib_path() -> str:
@@ -88,6 +122,8 @@ def load():
             raise RuntimeError(f"{_LIB_PATH} does not export {name} (stale build?)")
     L.usp_strerror.restype = ctypes.c_char_p
     L.usp_abi_version.restype = ctypes.c_int
+    L.usp_last_launch_kinds.restype = ctypes.c_int
+    L.usp_last_launch_kinds.argtypes = []
     if L.usp_abi_version() != ABI_VERSION:
         raise RuntimeError(f"libusp_hip.so ABI {L.usp_abi_version()} != binding ABI {ABI_VERSION}")
     i32, i64, vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
@@ -253,13 +289,14 @@ def _window(window):
     return None if (wl < 0 and wr < 0) else (wl, wr)
 
 
-def _fwd_args(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end, interleave, n, window=None):
+def _fwd_args(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end, interleave, n, window=None,
+              family_flag=0):
     """The filled usp_fwd_args block of a dense launch.  Everything but the seven pointers is a function of
     (dtype, shapes, strides, flags), and a training loop issues the same few launches over and over: the block is
     cached per thread under that signature and only the pointers are patched (filling 27 ctypes fields and five
     usp_tensor structs costs ~35 us of host time per launch, tools/host_step_cpu.py; a hit costs ~8)."""
     key = (q.dtype, q.shape, q.stride(), k.shape, k.stride(), v.stride(), lse.stride(), _strides(out), _strides(acc),
-           softmax_scale, causal, merge_in, final_begin, final_end, interleave, n, window)
+           softmax_scale, causal, merge_in, final_begin, final_end, interleave, n, window, family_flag)
     cache = _TLS.__dict__.setdefault("fwd", {})
     a = cache.get(key)
     if a is None:
@@ -274,7 +311,7 @@ def _fwd_args(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_beg
         a.merge_in = 1 if merge_in else 0
         a.final_begin = final_begin
         a.final_end = Sq if final_end is None else final_end
-        a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
+        a.flags = (USP_LAUNCH_INTERLEAVE if interleave else 0) | family_flag
         if window is not None:
             a.flags |= USP_ATTN_WINDOW
             a.window_left, a.window_right = window
@@ -291,16 +328,20 @@ def _fwd_args(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_beg
 
 def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=None,
               merge_in: bool = False, final_begin: int = 0, final_end: Optional[int] = None,
-              interleave: bool = False, k_splits: Optional[int] = None, window=None):
+              interleave: bool = False, k_splits: Optional[int] = None, window=None, family=None):
     """usp_flash_fwd (include/usp_hip.h).  q (B,Sq,Hq,D); k,v (B,Sk,Hkv,D); lse (B,Hq,Sq) fp32;
     out 16-bit / acc fp32 (B,Sq,Hq,D).  All may be strided views (unit dim stride).  `k_splits`: cut the keys of
     every query tile into that many work items (None: fwd_k_splits decides; 0 / 1: off).  `window` = flash-attn's
-    window_size (left, right), None / (-1, -1) = none."""
+    window_size (left, right), None / (-1, -1) = none.  `family`: "row64" | "wave32" pins the kernel family of this call
+    (ABI v6; None: set_kernel_family's default, normally "auto"); a forced 64-row call takes no K split."""
     _require_cuda(q, k, v, lse, out, acc)
     B, Sq, Hq, D = q.shape
+    ff = _family_flag(family)
     n = fwd_k_splits(B, Sq, Hq, causal) if k_splits is None else int(k_splits)
+    if ff == USP_FORCE_ROW64 and k_splits is None:
+        n = 0                                      # the policy's cut is an optimisation; the forced family has none
     a = _fwd_args(q, k, v, softmax_scale, bool(causal), lse, out, acc, bool(merge_in), final_begin, final_end,
-                  bool(interleave), n, _window(window))
+                  bool(interleave), n, _window(window), ff)
     L = load()
     if n > 1:
         # scratch for the partial results: one buffer per (device, stream), grown on demand; launches on one stream
@@ -421,11 +462,11 @@ def bwd_delta(dout, out, delta):
 
 def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causal: bool,
               accum_dq=False, accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None,
-              interleave: bool = False, splits=None, window=None):
+              interleave: bool = False, splits=None, window=None, family=None):
     """usp_flash_bwd.  dq/dk/dv are fp32 (B,S,H,D) views, written or accumulated; a 16-bit
     dq16/dk16/dv16 receives the FINAL rounded result instead (the fp32 tensor may then be None
     unless it is accumulated from).  `splits` = (dq_splits, dkdv_splits), None: bwd_splits decides.  `window` =
-    flash-attn's window_size (left, right), None / (-1, -1) = none."""
+    flash-attn's window_size (left, right), None / (-1, -1) = none.  `family`: as flash_fwd."""
     _require_cuda(dout, q, k, v, lse, delta, dq, dk, dv, dq16, dk16, dv16)
     B, Sq, Hq, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
@@ -443,8 +484,11 @@ def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causa
     a.dq, a.dk, a.dv = _t4(dq), _t4(dk), _t4(dv)
     a.dq16, a.dk16, a.dv16 = _t4(dq16), _t4(dk16), _t4(dv16)
     a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
-    a.flags = USP_LAUNCH_INTERLEAVE if interleave else 0
+    ff = _family_flag(family)
+    a.flags = (USP_LAUNCH_INTERLEAVE if interleave else 0) | ff
     a.dq_splits, a.dkdv_splits = bwd_splits(B, Sq, Sk, Hq, bool(causal)) if splits is None else splits
+    if ff == USP_FORCE_ROW64 and splits is None:
+        a.dq_splits = 0                            # the 64-row dQ kernel has no key cut; the policy's cut is optional
     win = _window(window)
     if win is not None:
         a.flags |= USP_ATTN_WINDOW

@@ -84,7 +84,9 @@ template <int D> USP_DEV int tile_swz(int row) {
 // complete argument block of the dK/dV launch (nblk / n_items are set inside).  Returns false when the launch is not
 // one it serves (the caller then takes the 8-wave kernel).
 bool launch_dkdv64(const BwdParams& p, int dtype, bool causal, hipStream_t st, int* rc);
+bool dkdv64_serves(const BwdParams& p, int dtype);     // ... whether it would (no launch)
 // The one-wave-per-SIMD dQ launch (usp_flash_bwd_dq64.hip): dense launches of D = 128 (bf16 / fp16) without a window or a key cut.
 bool launch_dq64(const BwdParams& p, int dtype, bool causal, hipStream_t st, int* rc);
+bool dq64_serves(const BwdParams& p);
 
 }  // namespace usp

@@ -144,6 +144,10 @@ USP_DEV void pin_here(uint32_t& w) { asm volatile("" : "+v"(w)); }
 
 USP_DEV float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// Host side: record which kernels a flash call launches (usp_last_launch_kinds; defined in usp_elementwise.hip)
+void launch_kinds_reset();
+void launch_kinds_note(int kind);
+
 // Persistent workgroups: a launch has min(items, resident workgroup slots) workgroups and each walks a
 // static list of work items.  The dispatcher places workgroup id on XCD id % 8; every XCD owns a
 // contiguous run of the item list (all sharers of one K/V sit behind one L2) and deals it out to its

@@ -261,13 +261,22 @@ extern "C" int usp_add_f32(float* dst, int64_t d_rs, const float* a, int64_t a_r
 
 extern "C" int usp_abi_version(void) { return USP_ABI_VERSION; }
 
+// What the calling thread's last flash call launched (include/usp_hip.h: usp_last_launch_kinds).  Thread-local: the entry
+// points share no mutable state.
+namespace usp {
+static thread_local int t_last_kinds = 0;
+void launch_kinds_reset() { t_last_kinds = 0; }
+void launch_kinds_note(int kind) { t_last_kinds |= kind; }
+}  // namespace usp
+extern "C" int usp_last_launch_kinds(void) { return usp::t_last_kinds; }
+
 extern "C" const char* usp_strerror(int code) {
   switch (code) {
     case USP_OK: return "ok";
     case USP_EINVAL: return "invalid argument (null pointer, non-positive size or bad dtype)";
     case USP_EUNSUPPORTED:
       return "unsupported shape/layout (head_dim must be 32/64/128, Hq % Hkv == 0, 16-byte aligned "
-             "pointers and strides)";
+             "pointers and strides; or a forced kernel family that does not serve the call)";
     case USP_ELAUNCH: return "HIP kernel launch failed";
   }
   return "unknown error";

@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void reduce_cuts_kernel(const BwdParams p) {
 }
 
 template <int D, int DT>
-static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
+static int launch_bwd(BwdParams p, bool causal, hipStream_t st, int force) {
   constexpr size_t lds0 = 2 * (2 * kTile * D * 2);
   // dK,dV
   // persistent launches: one workgroup per CU (both kernels fit once per CU), each walks n_items / grid items
@@ -854,13 +854,17 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   const size_t qx = p.sched ? 16 : 0;            // LDS for the item queue's two slots
   // dK/dV: the one-wave-per-SIMD kernel (4 waves x 64 keys, usp_flash_bwd64.hip) where it applies; USP_BWD_WAVES=8 forces
   // the 8-wave kernel below
-  static const int forced_waves = [] { const char* e = getenv("USP_BWD_WAVES"); return e ? atoi(e) : 0; }();
+  // (per call: `force` = USP_FORCE_ROW64 / USP_FORCE_WAVE32, include/usp_hip.h)
+  static const int forced_env = [] { const char* e = getenv("USP_BWD_WAVES"); return e ? atoi(e) : 0; }();
+  const int forced_waves = (force & USP_FORCE_WAVE32) ? 8 : ((force & USP_FORCE_ROW64) ? 0 : forced_env);
+  if ((force & USP_FORCE_ROW64) && !(D == 128 && dkdv64_serves(p, DT) && dq64_serves(p))) return USP_EUNSUPPORTED;
   bool dkdv_done = false;
   if (D == 128 && forced_waves != 8) {
     int rc64 = USP_ELAUNCH;
     if (launch_dkdv64(p, DT, causal, st, &rc64)) {
       if (rc64 != USP_OK) return rc64;
       dkdv_done = true;
+      launch_kinds_note(USP_KIND_DKDV_ROW64);
     }
   }
   if (!dkdv_done) {
@@ -873,6 +877,7 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
       hipLaunchKernelGGL((flash_bwd_dkdv_kernel<D, DT, true>), dim3(grid), dim3(512), lds2 + qx, st, p);
     else
       hipLaunchKernelGGL((flash_bwd_dkdv_kernel<D, DT, false>), dim3(grid), dim3(512), lds2 + qx, st, p);
+    launch_kinds_note(USP_KIND_DKDV_WAVE8);
   }
   }
   if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
@@ -882,12 +887,17 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
     rg = rg > 2048 ? 2048 : rg;
     hipLaunchKernelGGL((reduce_heads_kernel<D, DT>), dim3((int)rg), dim3(256), 0, st, p);
     if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
+    launch_kinds_note(USP_KIND_REDUCE_HEADS);
   }
   // dQ: the one-wave-per-SIMD kernel (4 waves x 64 query rows, usp_flash_bwd_dq64.hip) where it applies
-  static const int forced_dq = [] { const char* e = getenv("USP_BWD_DQ_WAVES"); return e ? atoi(e) : 0; }();
+  static const int forced_dq_env = [] { const char* e = getenv("USP_BWD_DQ_WAVES"); return e ? atoi(e) : 0; }();
+  const int forced_dq = force ? 0 : forced_dq_env;
   if (D == 128 && forced_waves != 8 && forced_dq != 8) {
     int rc64 = USP_ELAUNCH;
-    if (launch_dq64(p, DT, causal, st, &rc64)) return rc64;
+    if (launch_dq64(p, DT, causal, st, &rc64)) {
+      if (rc64 == USP_OK) launch_kinds_note(USP_KIND_DQ_ROW64);
+      return rc64;
+    }
   }
   p.nblk = (p.Sq + 255) / 256;
   p.n_items = p.B * p.Hq * p.nblk * p.ksplit;
@@ -898,11 +908,13 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st) {
   else
     hipLaunchKernelGGL((flash_bwd_kernel<D, DT, false>), dim3(grid), dim3(512), lds0 + qx, st, p);
   if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
+  launch_kinds_note(USP_KIND_DQ_WAVE8);
   if (p.ksplit > 1) {            // same stream: the partials are complete when this starts
     const int64_t items = (int64_t)p.B * p.Sq * p.Hq * (D / 4);
     int64_t rg = (items + 255) / 256;
     rg = rg > 2048 ? 2048 : rg;
     hipLaunchKernelGGL((reduce_cuts_kernel<D, DT>), dim3((int)rg), dim3(256), 0, st, p);
+    launch_kinds_note(USP_KIND_REDUCE_CUTS);
   }
   return hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
 }
@@ -936,7 +948,10 @@ extern "C" int64_t usp_flash_bwd_workspace_bytes(const usp_bwd_args* a) {
 
 extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   using namespace usp;
+  launch_kinds_reset();
   if (!a || !a->lse || !a->delta) return USP_EINVAL;
+  const int force = a->flags & (USP_FORCE_ROW64 | USP_FORCE_WAVE32);
+  if (force == (USP_FORCE_ROW64 | USP_FORCE_WAVE32)) return USP_EINVAL;
   if (a->dtype != USP_BF16 && a->dtype != USP_FP16) return USP_EINVAL;
   if (a->B <= 0 || a->Sq <= 0 || a->Sk <= 0 || a->Hq <= 0 || a->Hkv <= 0) return USP_EINVAL;
   if (!(a->softmax_scale > 0.f)) return USP_EINVAL;
@@ -1022,12 +1037,12 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool causal = wr >= 0;                    // (a->causal, or a right window bound)
   switch (a->D * 2 + a->dtype) {
-    case 64: return launch_bwd<32, 0>(p, causal, st);
-    case 65: return launch_bwd<32, 1>(p, causal, st);
-    case 128: return launch_bwd<64, 0>(p, causal, st);
-    case 129: return launch_bwd<64, 1>(p, causal, st);
-    case 256: return launch_bwd<128, 0>(p, causal, st);
-    case 257: return launch_bwd<128, 1>(p, causal, st);
+    case 64: return launch_bwd<32, 0>(p, causal, st, force);
+    case 65: return launch_bwd<32, 1>(p, causal, st, force);
+    case 128: return launch_bwd<64, 0>(p, causal, st, force);
+    case 129: return launch_bwd<64, 1>(p, causal, st, force);
+    case 256: return launch_bwd<128, 0>(p, causal, st, force);
+    case 257: return launch_bwd<128, 1>(p, causal, st, force);
   }
   return USP_EUNSUPPORTED;
 }

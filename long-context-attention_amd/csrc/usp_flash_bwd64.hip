@@ -577,14 +577,7 @@ USP_TM(
   }  // next item
 }
 
-bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st, int* rc) {
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-      n = 256;
-    return n;
-  }();
+bool dkdv64_serves(const BwdParams& p_in, int dtype) {
   if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on) return false;
   // (fp16: round 4's first build of that instantiation copied accumulators between the register files inside the loop; with the
   // chains started from the row constants it compiles like the bf16 one -- tools/mfma_hazards.py: 0 -- and is served here too)
@@ -596,6 +589,18 @@ bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st
   // bytes are 64-bit: no sequence length is refused -- the 8-wave kernel addresses a head by a 32-bit offset and is.)
   if ((p_in.q_ss * 2) % 256 != 0 || (p_in.do_ss * 2) % 256 != 0 || p_in.q_ss * 128 >= (1LL << 31) || p_in.do_ss * 128 >= (1LL << 31))
     return false;
+  return true;
+}
+
+bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st, int* rc) {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  if (!dkdv64_serves(p_in, dtype)) return false;
   BwdParams p = p_in;
   p.wide16 = ((p.dk16 && !p.accum_dk && rows16_aligned(p.dk16, p.dk16_sb, p.dk16_ss, p.dk16_sh)) ? 2 : 0) |
              ((p.dv16 && !p.accum_dv && rows16_aligned(p.dv16, p.dv16_sb, p.dv16_ss, p.dv16_sh)) ? 4 : 0);

@@ -379,6 +379,15 @@ USP_TM(
   }  // next item
 }
 
+bool dq64_serves(const BwdParams& p_in) {
+  // dense launches (bf16 / fp16) without a window, a cut of the key range or the dynamic item queue; the pieces' swizzle is XORed
+  // into the per-lane byte offset (rows a multiple of 256 bytes apart), 64 rows of K / V span less than 2^31 bytes
+  if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on || p_in.ksplit > 1) return false;
+  if ((p_in.k_ss * 2) % 256 != 0 || (p_in.v_ss * 2) % 256 != 0 || p_in.k_ss * 128 >= (1LL << 31) || p_in.v_ss * 128 >= (1LL << 31))
+    return false;
+  return true;
+}
+
 bool launch_dq64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st, int* rc) {
   static const int cus = [] {
     int dev = 0, n = 0;
@@ -387,11 +396,7 @@ bool launch_dq64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st, 
       n = 256;
     return n;
   }();
-  // dense launches (bf16 / fp16) without a window, a cut of the key range or the dynamic item queue; the pieces' swizzle is XORed
-  // into the per-lane byte offset (rows a multiple of 256 bytes apart), 64 rows of K / V span less than 2^31 bytes
-  if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on || p_in.ksplit > 1) return false;
-  if ((p_in.k_ss * 2) % 256 != 0 || (p_in.v_ss * 2) % 256 != 0 || p_in.k_ss * 128 >= (1LL << 31) || p_in.v_ss * 128 >= (1LL << 31))
-    return false;
+  if (!dq64_serves(p_in)) return false;
   BwdParams p = p_in;
   p.nblk = (p.Sq + 255) / 256;
   p.n_items = p.B * p.Hq * p.nblk;

@@ -683,15 +683,24 @@ static int launch_fwd_w(FwdArgsT<true> p, bool causal, hipStream_t st) {
 }
 
 template <int D, int DT>
-static int launch_fwd(const FwdArgsT<true>& p, bool causal, hipStream_t st) {
+static int launch_fwd(const FwdArgsT<true>& p, bool causal, hipStream_t st, int force) {
   // Workgroup shape: 8 waves (256 query rows, one workgroup per CU) stage K/V once per 256 rows and win by
   // 3-4 % whenever they can give every CU work; 4 waves (128 rows, two workgroups per CU) are used only
   // when the 8-wave item list is shorter than the CU count, or for short causal sequences (<= 1024 rows:
-  // +3...8 %) (measured with persistent workgroups, profiles/).  USP_FWD_WAVES=4|8|64 forces a shape (64 = the
+  // +3...8 %) (measured with persistent workgroups, profiles/).  Per call, `force` (USP_FORCE_ROW64 / USP_FORCE_WAVE32,
+  // include/usp_hip.h) picks the family; per process, USP_FWD_WAVES=4|8|64 forces a shape for A/B runs (64 = the
   // 4 x 64-row kernel of usp_flash_fwd64.hip, where it applies).
-  static const int forced = [] { const char* e = getenv("USP_FWD_WAVES"); return e ? atoi(e) : 0; }();
-  int waves = forced;
+  static const int forced_env = [] { const char* e = getenv("USP_FWD_WAVES"); return e ? atoi(e) : 0; }();
   const bool fwd64_ok = D == 128 && !p.seq_q && p.ksplit <= 1 && !p.win_on;   // what usp_flash_fwd64.hip serves
+  if (force & USP_FORCE_ROW64) {
+    int rc = USP_ELAUNCH;
+    if (fwd64_ok && launch_fwd64(p, DT, causal, st, &rc)) {
+      if (rc == USP_OK) launch_kinds_note(USP_KIND_FWD_ROW64);
+      return rc;
+    }
+    return USP_EUNSUPPORTED;
+  }
+  int waves = (force & USP_FORCE_WAVE32) ? 0 : forced_env;
   if (waves != 4 && waves != 8 && waves != 64) {
     const int64_t grid8 = (int64_t)p.B * p.Hq * ((p.Sq + 255) / 256) * p.ksplit;
     // short causal sequences: less diagonal waste (dense only: in packed mode twice the items cost more to fetch)
@@ -701,14 +710,19 @@ static int launch_fwd(const FwdArgsT<true>& p, bool causal, hipStream_t st) {
     // beside the copies (512 items: 2.054 vs 2.084 ms) -- profiles/r02_rank_emulation.txt
     waves = (grid8 < 256 || (p.interleave && grid8 < 512) || (!p.seq_q && causal && p.Sq <= 1024)) ? 4 : 8;
     // where the 256-row item wins, the one-wave-per-SIMD kernel (4 waves x 64 rows, usp_flash_fwd64.hip) serves it
-    if (waves == 8 && fwd64_ok) waves = 64;
+    if (waves == 8 && fwd64_ok && !(force & USP_FORCE_WAVE32)) waves = 64;
   }
   if (waves == 64) {
     int rc = USP_ELAUNCH;
-    if (fwd64_ok && launch_fwd64(p, DT, causal, st, &rc)) return rc;
+    if (fwd64_ok && launch_fwd64(p, DT, causal, st, &rc)) {
+      if (rc == USP_OK) launch_kinds_note(USP_KIND_FWD_ROW64);
+      return rc;
+    }
     waves = 8;
   }
-  return waves == 4 ? launch_fwd_w<D, DT, 4>(p, causal, st) : launch_fwd_w<D, DT, 8>(p, causal, st);
+  const int rc = waves == 4 ? launch_fwd_w<D, DT, 4>(p, causal, st) : launch_fwd_w<D, DT, 8>(p, causal, st);
+  if (rc == USP_OK) launch_kinds_note((waves == 4 ? USP_KIND_FWD_WAVE4 : USP_KIND_FWD_WAVE8) | (p.ksplit > 1 ? USP_KIND_FWD_SPLIT_MERGE : 0));
+  return rc;
 }
 
 static bool aligned16(const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 15) == 0; }
@@ -728,7 +742,10 @@ extern "C" int64_t usp_flash_fwd_workspace_bytes(const usp_fwd_args* a, int32_t 
 
 extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   using namespace usp;
+  launch_kinds_reset();
   if (!a || !a->lse) return USP_EINVAL;
+  const int force = a->flags & (USP_FORCE_ROW64 | USP_FORCE_WAVE32);
+  if (force == (USP_FORCE_ROW64 | USP_FORCE_WAVE32)) return USP_EINVAL;
   if (a->dtype != USP_BF16 && a->dtype != USP_FP16) return USP_EINVAL;
   if (a->B <= 0 || a->Sq <= 0 || a->Sk <= 0 || a->Hq <= 0 || a->Hkv <= 0) return USP_EINVAL;
   if (!(a->softmax_scale > 0.f)) return USP_EINVAL;
@@ -792,12 +809,12 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool causal = wr >= 0;                    // (a->causal, or a right window bound)
   switch (a->D * 2 + a->dtype) {
-    case 32 * 2 + 0: return launch_fwd<32, 0>(p, causal, st);
-    case 32 * 2 + 1: return launch_fwd<32, 1>(p, causal, st);
-    case 64 * 2 + 0: return launch_fwd<64, 0>(p, causal, st);
-    case 64 * 2 + 1: return launch_fwd<64, 1>(p, causal, st);
-    case 128 * 2 + 0: return launch_fwd<128, 0>(p, causal, st);
-    case 128 * 2 + 1: return launch_fwd<128, 1>(p, causal, st);
+    case 32 * 2 + 0: return launch_fwd<32, 0>(p, causal, st, force);
+    case 32 * 2 + 1: return launch_fwd<32, 1>(p, causal, st, force);
+    case 64 * 2 + 0: return launch_fwd<64, 0>(p, causal, st, force);
+    case 64 * 2 + 1: return launch_fwd<64, 1>(p, causal, st, force);
+    case 128 * 2 + 0: return launch_fwd<128, 0>(p, causal, st, force);
+    case 128 * 2 + 1: return launch_fwd<128, 1>(p, causal, st, force);
   }
   return USP_EUNSUPPORTED;
 }

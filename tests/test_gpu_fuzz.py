@@ -63,9 +63,12 @@ _N_ROW64 = int(os.environ.get("USP_FUZZ_ROW64", "24"))      # larger sweeps: USP
 
 
 def _row64_case(rs):
-    """Shapes the one-wave-per-SIMD kernels serve (D = 128, dense, no window, no cuts): forward in both dtypes, backward in
-    bf16 (fp16 backward: the 8-wave kernels).  Longer sequences than the general sweep: several 256-row query blocks and
-    128-key blocks per head, ragged ends, Sq != Sk in both directions, GQA groups up to 8."""
+    """Shapes the one-wave-per-SIMD BACKWARD kernels serve by the library's own dispatch (D = 128, dense, no window, no
+    cuts; both dtypes): they take every such launch, however small.  The 4 x 64 FORWARD is dispatched from 256 work items
+    up, which no shape here has -- this sweep's forward runs on the 4-wave kernel; the forced sweep of
+    tests/test_gpu_row64.py is the one that puts ragged shapes through `flash_fwd64_kernel`.  Longer sequences than the
+    general sweep: several 256-row query blocks and 128-key blocks per head, ragged ends, Sq != Sk in both directions,
+    GQA groups up to 8."""
     dt = str(rs.choice(["bfloat16", "bfloat16", "float16"]))
     Hkv = int(rs.choice([1, 2]))
     Hq = Hkv * int(rs.choice([1, 2, 4, 8]))
@@ -120,10 +123,15 @@ def _run_dense(dev, rs, case):
         # A gradient entry is a sum of N products whose 16-bit factors (P, dS) carry a relative rounding error of
         # 2^-9 / sqrt(3) each: the absolute error of the SUM is about 1.1e-3 x rms(entry) per sigma, whatever the entry's own
         # value -- an entry near a zero crossing of a tensor whose entries are ~20 (1000+ rows per key, ten keys: P is not
-        # small) misses `atol + rtol |want|` by 2x in the 8-wave AND the 64-row kernels alike (kbench bwd 2 1191 10 8 2 128:
-        # dk 7.8e-2 / 9.5e-2).  So the absolute part of the bound never drops below ~7 sigma of that noise.
+        # small) misses `atol + rtol |want|` by 2x in the 8-wave AND the 64-row kernels alike.  So for LONG sums only
+        # (>= 1000 products per entry: dK / dV sum Sq * G rows, dQ sums Sk keys) the absolute part of the bound does not drop
+        # below ~7 sigma of that noise; every other case keeps the stated tolerance.  Pinned by
+        # tests/test_gpu_row64.py::test_long_sum_gradient_noise_is_that_of_16bit_products (both families miss the
+        # un-floored bound by the same amount on that case and pass it against 16-bit-rounded products).
         atol, rtol = TOL[dt]["grad"]
-        atol = max(atol, 8e-3 * float(np.sqrt(np.mean(np.square(r_, dtype=np.float64)))))
+        n_sum = Sk if n_ == "dq" else Sq * (Hq // Hkv)
+        if n_sum >= 1000:
+            atol = max(atol, 8e-3 * float(np.sqrt(np.mean(np.square(r_, dtype=np.float64)))))
         assert_close(g_, r_, atol, rtol, f"{what} {n_}")
 
 

@@ -88,6 +88,17 @@ def test_block_family_fails_on_nan(dev, target, kind):
     _must_fail(target, kind, P.test_block_forward_backward_vs_oracle, dev, *P.SHAPES[3])      # ragged
 
 
+@pytest.mark.parametrize("kind", ["elem", "row"])
+@pytest.mark.parametrize("target", [FWD, BWD_DQ, BWD_DK, BWD_DV], ids=["out", "dq", "dk", "dv"])
+def test_forced_row64_family_fails_on_nan(dev, target, kind):
+    """The tests that pin the 64-row kernels (tests/test_gpu_row64.py) can fail too."""
+    import test_gpu_row64 as R
+    _must_fail(target, kind, R.test_row64_edge_shapes, dev, *R.EDGE[4])          # ragged, bottom-right causal, GQA
+    _must_fail(target, kind, R.test_row64_edge_shapes, dev, *R.EDGE[-1])         # several items per head
+    if target is FWD:
+        _must_fail(target, kind, R.test_row64_merge_in_and_partial_final_ranges, dev, *R.MERGE[1])
+
+
 @pytest.mark.parametrize("target", [PFWD, PBWD_DQ, PBWD_DV], ids=["out", "dq", "dv"])
 def test_packed_family_fails_on_nan(dev, target):
     _must_fail(target, "elem", P.test_packed_kernels_vs_oracle, dev, *P.PACKED[0])

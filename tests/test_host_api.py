@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libusp_hip.so does not export {name}"
     assert set(_C.EXPORTS) == declared
     L = _C.load()
-    assert L.usp_abi_version() == _C.ABI_VERSION == 5
+    assert L.usp_abi_version() == _C.ABI_VERSION == 6
+    assert L.usp_last_launch_kinds() == 0                        # nothing launched on this thread
     assert b"head_dim" in L.usp_strerror(-2)
 
 
@@ -419,6 +420,25 @@ def test_host_launch_plumbing_without_a_device():
     assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
     a.k_splits, a.workspace = 9, base + 5 * 0x1000000
     assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
+    # ABI v6: kernel-family selectors.  Both at once: invalid.  A forced 64-row call the family does not serve (K split,
+    # head dim 64) is refused BEFORE any launch; one it serves reaches the launch; nothing was launched: kinds == 0.
+    a.k_splits, a.workspace = 0, None
+    a.flags = _C.USP_FORCE_ROW64 | _C.USP_FORCE_WAVE32
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
+    a.flags = _C.USP_FORCE_ROW64
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -3
+    a.k_splits, a.workspace = 2, base + 5 * 0x1000000
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -2                      # USP_EUNSUPPORTED
+    a.k_splits, a.workspace, a.D = 0, None, 64
+    for i, x in enumerate((a.q, a.k, a.v, a.out)):
+        x.stride_b, x.stride_s, x.stride_h = S * H * 64, H * 64, 64
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -2
+    a.flags = _C.USP_FORCE_WAVE32
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -3
+    assert L.usp_last_launch_kinds() == 0 and _C.last_launch_kinds() == ()
+    with pytest.raises(ValueError):
+        _C.set_kernel_family("row32")
+    assert _C.set_kernel_family("wave32") == "auto" and _C.set_kernel_family("auto") == "wave32"
 
 
 def test_link_rate_probe_is_inert_without_rccl(monkeypatch):
