@@ -63,6 +63,12 @@ enum {
  * Both bits at once: USP_EINVAL.  usp_last_launch_kinds() reports what a call actually launched. */
 #define USP_FORCE_ROW64 4
 #define USP_FORCE_WAVE32 8
+/* usp_flash_bwd only (ABI v6): issue only one of the backward's two launches -- the dK/dV launch (+ its head / cut reduce)
+ * or the dQ launch (+ its cut reduce).  The two are independent given (lse, delta); a caller may order them around its
+ * transfers (dK/dV travel the ring, dQ stays), and a bench can time each kernel alone with stream events.  The skipped
+ * launch's outputs are not touched.  Both bits at once: USP_EINVAL. */
+#define USP_BWD_SKIP_DQ 16
+#define USP_BWD_SKIP_DKDV 32
 
 typedef struct usp_tensor {
   void* ptr;
@@ -270,6 +276,17 @@ enum {
   USP_KIND_REDUCE_CUTS = 512    /* reduce_cuts_kernel (dQ key cuts) */
 };
 int usp_last_launch_kinds(void);
+
+/* Diagnostic (ABI v6), not a replacement of any reference call site: what the matrix pipe of THIS part sustains on the
+ * caller's operands -- an MFMA-only loop (v_mfma_f32_32x32x16_bf16, no LDS / VALU / memory traffic inside) on one workgroup
+ * per CU, `waves_per_simd` (1 | 2) waves per SIMD, `iters` passes of 64 MFMAs per wave.  `operands`: >= 64 KiB of device
+ * memory holding bf16 values (N(0,1) as the bench's inputs, or zeros: the part clocks by power and MFMA power depends on
+ * the operand bit patterns).  FLOPs of a launch = CUs * 4 * waves_per_simd * iters * 64 * 32768.  `sink`: >= 512 floats of
+ * device scratch.  `clocks` (optional, 2 x uint64 device): elapsed s_memtime (shader clock) and s_memrealtime (100 MHz)
+ * ticks of one wave's loop -> sustained clock.  bench.py reports a flash kernel's rate against this ceiling beside its
+ * fraction of the nominal 2.5 PFLOP/s. */
+int usp_mfma_probe(const void* operands, int64_t operand_bytes, int32_t iters, int32_t waves_per_simd,
+                   float* sink, uint64_t* clocks, void* stream);
 
 int usp_abi_version(void);
 const char* usp_strerror(int code);

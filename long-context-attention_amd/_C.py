@@ -22,6 +22,8 @@ USP_LAUNCH_INTERLEAVE = 1      # include/usp_hip.h: launch so that collectives o
 USP_ATTN_WINDOW = 2            # the window_left / window_right fields are valid
 USP_FORCE_ROW64 = 4            # ABI v6: the call must be served by the one-wave-per-SIMD (64-row) kernel family ...
 USP_FORCE_WAVE32 = 8           # ... or by the two-waves-per-SIMD (32 rows per wave) family
+USP_BWD_SKIP_DQ = 16           # usp_flash_bwd: only the dK/dV launch ...
+USP_BWD_SKIP_DKDV = 32         # ... only the dQ launch
 ABI_VERSION = 6
 # usp_last_launch_kinds(): bit -> kernel (include/usp_hip.h, USP_KIND_*)
 KINDS = {1: "fwd_row64", 2: "fwd_wave8", 4: "fwd_wave4", 8: "fwd_split_merge", 16: "dkdv_row64", 32: "dkdv_wave8",
@@ -99,7 +101,7 @@ class UspBwdArgs(ctypes.Structure):
 
 
 EXPORTS = ("usp_flash_fwd", "usp_flash_fwd_workspace_bytes", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
-           "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror", "usp_last_launch_kinds")
+           "usp_cast_from_f32", "usp_add_f32", "usp_abi_version", "usp_strerror", "usp_last_launch_kinds", "usp_mfma_probe")
 
 
 def lib_path() -> str:
@@ -140,6 +142,8 @@ def load():
     L.usp_copy_rows.argtypes = [vp, vp] + [i64] * 13 + [vp]
     L.usp_cast_from_f32.argtypes = [i32, vp, i64, vp, i64, i64, i64, vp]
     L.usp_add_f32.argtypes = [vp, i64, vp, i64, vp, i64, i64, i64, vp]
+    L.usp_mfma_probe.argtypes = [vp, i64, i32, i32, vp, vp, vp]
+    L.usp_mfma_probe.restype = ctypes.c_int
     for name in ("usp_flash_fwd", "usp_flash_bwd", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
                  "usp_cast_from_f32", "usp_add_f32"):
         getattr(L, name).restype = ctypes.c_int
@@ -462,11 +466,12 @@ def bwd_delta(dout, out, delta):
 
 def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causal: bool,
               accum_dq=False, accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None,
-              interleave: bool = False, splits=None, window=None, family=None):
+              interleave: bool = False, splits=None, window=None, family=None, only=None):
     """usp_flash_bwd.  dq/dk/dv are fp32 (B,S,H,D) views, written or accumulated; a 16-bit
     dq16/dk16/dv16 receives the FINAL rounded result instead (the fp32 tensor may then be None
     unless it is accumulated from).  `splits` = (dq_splits, dkdv_splits), None: bwd_splits decides.  `window` =
-    flash-attn's window_size (left, right), None / (-1, -1) = none.  `family`: as flash_fwd."""
+    flash-attn's window_size (left, right), None / (-1, -1) = none.  `family`: as flash_fwd.  `only`: "dkdv" | "dq" issues
+    just that launch of the two (ABI v6: USP_BWD_SKIP_DQ / USP_BWD_SKIP_DKDV)."""
     _require_cuda(dout, q, k, v, lse, delta, dq, dk, dv, dq16, dk16, dv16)
     B, Sq, Hq, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
@@ -485,7 +490,7 @@ def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causa
     a.dq16, a.dk16, a.dv16 = _t4(dq16), _t4(dk16), _t4(dv16)
     a.accum_dq, a.accum_dk, a.accum_dv = int(bool(accum_dq)), int(bool(accum_dk)), int(bool(accum_dv))
     ff = _family_flag(family)
-    a.flags = (USP_LAUNCH_INTERLEAVE if interleave else 0) | ff
+    a.flags = (USP_LAUNCH_INTERLEAVE if interleave else 0) | ff | {None: 0, "dkdv": USP_BWD_SKIP_DQ, "dq": USP_BWD_SKIP_DKDV}[only]
     a.dq_splits, a.dkdv_splits = bwd_splits(B, Sq, Sk, Hq, bool(causal)) if splits is None else splits
     if ff == USP_FORCE_ROW64 and splits is None:
         a.dq_splits = 0                            # the 64-row dQ kernel has no key cut; the policy's cut is optional
@@ -556,3 +561,19 @@ def add_f32(dst, a, b):
         sd, sa, sb_ = dst.stride(0), a.stride(0), b.stride(0)
     _check(load().usp_add_f32(ctypes.c_void_p(dst.data_ptr()), sd, ctypes.c_void_p(a.data_ptr()), sa,
                               ctypes.c_void_p(b.data_ptr()), sb_, rows, n, _stream()), "usp_add_f32")
+
+
+def mfma_probe(operands: torch.Tensor, iters: int, waves_per_simd: int = 1, clocks: Optional[torch.Tensor] = None):
+    """usp_mfma_probe: one launch of the MFMA-only loop on `operands` (a bf16 device tensor of >= 32768 elements).
+    Returns the FLOPs of the launch; `clocks`: optional int64[2] device tensor (shader-clock and 100 MHz ticks)."""
+    _require_cuda(operands, clocks)
+    assert operands.dtype == torch.bfloat16 and operands.is_contiguous() and operands.numel() >= 32768
+    key = ("probe_sink", operands.device.index)
+    sink = _SCHED.get(key)
+    if sink is None:
+        sink = _SCHED[key] = torch.zeros(512, dtype=torch.float32, device=operands.device)
+    _check(load().usp_mfma_probe(ctypes.c_void_p(operands.data_ptr()), operands.numel() * 2, int(iters), int(waves_per_simd),
+                                 ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(clocks.data_ptr() if clocks is not None else None),
+                                 _stream()), "usp_mfma_probe")
+    cus = torch.cuda.get_device_properties(operands.device).multi_processor_count
+    return cus * 4 * waves_per_simd * iters * 64 * 32768.0

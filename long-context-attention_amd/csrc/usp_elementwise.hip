@@ -259,6 +259,59 @@ extern "C" int usp_add_f32(float* dst, int64_t d_rs, const float* a, int64_t a_r
   return launched();
 }
 
+// ---- diagnostic: what the matrix pipe sustains on THIS part, on THESE operands -----------------------------------------
+// An MFMA-only loop of the flash kernels' instruction (v_mfma_f32_32x32x16_{bf16}) on operands the caller provides
+// (N(0,1) bf16 as the bench's inputs, or zeros): no LDS, no VALU, no memory traffic in the loop, eight independent
+// accumulators, eight A and eight B fragments in rotation (64 distinct products per pass).  One or two waves per SIMD.
+// The part clocks by power, and MFMA power depends on the operands' bit patterns: the rate this loop sustains on random
+// operands is the ceiling a flash kernel can approach on the same box in the same run.
+// Lane 0 of every wave records s_memtime (shader clock) and s_memrealtime (100 MHz) around the loop: sustained clock.
+namespace usp {
+__global__ __launch_bounds__(512, 1) void mfma_probe_kernel(const u32x4* ops, int n_frag, int iters, float* sink,
+                                                            unsigned long long* clocks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u32x4 a[8], b[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {            // every wave of the launch draws its own fragments from the operand buffer
+    const unsigned w = (blockIdx.x * (blockDim.x >> 6) + wave) * 16 + i;
+    a[i] = ops[((w * 64 + lane) * 2) % n_frag];
+    b[i] = ops[((w * 64 + lane) * 2 + 1 + 128 * i) % n_frag];
+  }
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int m = 0; m < 64; ++m)
+      acc[m & 7] = Elem<0>::mfma(a[m & 7], b[(m >> 3) & 7], acc[m & 7]);
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 123.456f) sink[threadIdx.x] = s;            // keeps the loop alive; practically never true
+  if (clocks && lane == 0 && wave == 0 && blockIdx.x == 0) { clocks[0] = t1 - t0; clocks[1] = r1 - r0; }
+}
+}  // namespace usp
+
+extern "C" int usp_mfma_probe(const void* operands, int64_t operand_bytes, int32_t iters, int32_t waves_per_simd,
+                              float* sink, uint64_t* clocks, void* stream) {
+  using namespace usp;
+  if (!operands || operand_bytes < 16 * 4096 || iters <= 0 || !sink || (waves_per_simd != 1 && waves_per_simd != 2)) return USP_EINVAL;
+  if (!al16(operands)) return USP_EUNSUPPORTED;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+    cus = 256;
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(256 * waves_per_simd), 0, (hipStream_t)stream,
+                     (const u32x4*)operands, (int)(operand_bytes / 16), (int)iters, sink, (unsigned long long*)clocks);
+  return launched();
+}
+
 extern "C" int usp_abi_version(void) { return USP_ABI_VERSION; }
 
 // What the calling thread's last flash call launched (include/usp_hip.h: usp_last_launch_kinds).  Thread-local: the entry

@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void reduce_cuts_kernel(const BwdParams p) {
 }
 
 template <int D, int DT>
-static int launch_bwd(BwdParams p, bool causal, hipStream_t st, int force) {
+static int launch_bwd(BwdParams p, bool causal, hipStream_t st, int force, int skip) {
   constexpr size_t lds0 = 2 * (2 * kTile * D * 2);
   // dK,dV
   // persistent launches: one workgroup per CU (both kernels fit once per CU), each walks n_items / grid items
@@ -858,8 +858,8 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st, int force) {
   static const int forced_env = [] { const char* e = getenv("USP_BWD_WAVES"); return e ? atoi(e) : 0; }();
   const int forced_waves = (force & USP_FORCE_WAVE32) ? 8 : ((force & USP_FORCE_ROW64) ? 0 : forced_env);
   if ((force & USP_FORCE_ROW64) && !(D == 128 && dkdv64_serves(p, DT) && dq64_serves(p))) return USP_EUNSUPPORTED;
-  bool dkdv_done = false;
-  if (D == 128 && forced_waves != 8) {
+  bool dkdv_done = (skip & USP_BWD_SKIP_DKDV) != 0;
+  if (!dkdv_done && D == 128 && forced_waves != 8) {
     int rc64 = USP_ELAUNCH;
     if (launch_dkdv64(p, DT, causal, st, &rc64)) {
       if (rc64 != USP_OK) return rc64;
@@ -881,7 +881,7 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st, int force) {
   }
   }
   if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
-  if (p.split) {
+  if (p.split && !(skip & USP_BWD_SKIP_DKDV)) {
     const int64_t items = (int64_t)p.B * p.Sk * p.Hkv * (D / 4);
     int64_t rg = (items + 255) / 256;
     rg = rg > 2048 ? 2048 : rg;
@@ -889,6 +889,7 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st, int force) {
     if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
     launch_kinds_note(USP_KIND_REDUCE_HEADS);
   }
+  if (skip & USP_BWD_SKIP_DQ) return USP_OK;
   // dQ: the one-wave-per-SIMD kernel (4 waves x 64 query rows, usp_flash_bwd_dq64.hip) where it applies
   static const int forced_dq_env = [] { const char* e = getenv("USP_BWD_DQ_WAVES"); return e ? atoi(e) : 0; }();
   const int forced_dq = force ? 0 : forced_dq_env;
@@ -952,6 +953,8 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   if (!a || !a->lse || !a->delta) return USP_EINVAL;
   const int force = a->flags & (USP_FORCE_ROW64 | USP_FORCE_WAVE32);
   if (force == (USP_FORCE_ROW64 | USP_FORCE_WAVE32)) return USP_EINVAL;
+  const int skip = a->flags & (USP_BWD_SKIP_DQ | USP_BWD_SKIP_DKDV);
+  if (skip == (USP_BWD_SKIP_DQ | USP_BWD_SKIP_DKDV)) return USP_EINVAL;
   if (a->dtype != USP_BF16 && a->dtype != USP_FP16) return USP_EINVAL;
   if (a->B <= 0 || a->Sq <= 0 || a->Sk <= 0 || a->Hq <= 0 || a->Hkv <= 0) return USP_EINVAL;
   if (!(a->softmax_scale > 0.f)) return USP_EINVAL;
@@ -962,8 +965,9 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   if (packed && !(a->seq_q && a->seq_k && a->total_k > 0)) return USP_EINVAL;
   // an fp32 tensor may be absent only if its 16-bit final output is given and nothing is accumulated
   auto need32 = [](const usp_tensor& t32, const usp_tensor& t16, int accum) { return !t16.ptr || accum; };
-  if ((need32(a->dq, a->dq16, a->accum_dq) && !a->dq.ptr) || (need32(a->dk, a->dk16, a->accum_dk) && !a->dk.ptr) ||
-      (need32(a->dv, a->dv16, a->accum_dv) && !a->dv.ptr))
+  const bool want_dq = !(a->flags & USP_BWD_SKIP_DQ), want_dkdv = !(a->flags & USP_BWD_SKIP_DKDV);   // (a skipped launch needs no outputs)
+  if ((want_dq && need32(a->dq, a->dq16, a->accum_dq) && !a->dq.ptr) || (want_dkdv && need32(a->dk, a->dk16, a->accum_dk) && !a->dk.ptr) ||
+      (want_dkdv && need32(a->dv, a->dv16, a->accum_dv) && !a->dv.ptr))
     return USP_EINVAL;
   auto ok32 = [](const usp_tensor& t) { return !t.ptr || ok16(t, 4); };
   auto okh = [](const usp_tensor& t) {
@@ -1037,12 +1041,12 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   const bool causal = wr >= 0;                    // (a->causal, or a right window bound)
   switch (a->D * 2 + a->dtype) {
-    case 64: return launch_bwd<32, 0>(p, causal, st, force);
-    case 65: return launch_bwd<32, 1>(p, causal, st, force);
-    case 128: return launch_bwd<64, 0>(p, causal, st, force);
-    case 129: return launch_bwd<64, 1>(p, causal, st, force);
-    case 256: return launch_bwd<128, 0>(p, causal, st, force);
-    case 257: return launch_bwd<128, 1>(p, causal, st, force);
+    case 64: return launch_bwd<32, 0>(p, causal, st, force, skip);
+    case 65: return launch_bwd<32, 1>(p, causal, st, force, skip);
+    case 128: return launch_bwd<64, 0>(p, causal, st, force, skip);
+    case 129: return launch_bwd<64, 1>(p, causal, st, force, skip);
+    case 256: return launch_bwd<128, 0>(p, causal, st, force, skip);
+    case 257: return launch_bwd<128, 1>(p, causal, st, force, skip);
   }
   return USP_EUNSUPPORTED;
 }

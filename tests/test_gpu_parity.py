@@ -964,7 +964,8 @@ def _load_bench():
 
 def test_seq64k_sampled_parity_through_bench(dev):
     """The metric's own size on one GPU (B1 S65536 H32/Hkv4 D128 causal, forward + backward kernels) against exact fp64
-    attention on sampled rows and key columns -- the check bench.py attaches to `roofline.seq64k_single_gpu`."""
+    attention on sampled rows and key columns -- the check bench.py attaches to `roofline.sampled_parity` (round 5: the N = 1
+    workload itself)."""
     b = _load_bench()
     c5 = b.WORKLOADS[8]
     t = b._fwd_bwd_kernels(c5["B"], c5["S"], c5["Hq"], c5["Hkv"], c5["D"], dev, 1, keep=True)

@@ -18,7 +18,7 @@ import sys
 import tempfile
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-ROOFLINE_KERNEL = r"flash_fwd64_kernel<0, true>"      # the 4 x 64-row forward, bf16, causal (the N=1 roofline kernel)
+ROOFLINE_KERNEL = r"flash_bwd_dkdv64_kernel<0, true>"  # the 4 x 64-key dK/dV kernel, bf16, causal: the dominant kernel of the N=1 step
 
 
 def _disassemble(lib):

@@ -31,9 +31,12 @@ def main():
         Y.set_seq_parallel_pg(1, 1, 0, 1)
         ms = bench._layer_fwd_bwd(2, 8192, 16, 16, 128, dev, iters or 20)
         print(f"layer fwd+bwd C2: {ms:.4f} ms per step")
+        w = bench.WORKLOADS[1]
+        ms = bench._layer_fwd_bwd(w["B"], w["S"], w["Hq"], w["Hkv"], w["D"], dev, 3, warm=1)
+        print(f"layer fwd+bwd at the N=1 workload (B1 S65536 H32/Hkv4): {ms:.3f} ms per step")
         dist.destroy_process_group()
         return
-    c = bench.WORKLOADS[1] if what == "c2" else bench.WORKLOADS[8]
+    c = bench.C2 if what == "c2" else bench.WORKLOADS[1]
     n = iters or (40 if what == "c2" else 3)
     if what == "c2":
         bench._fwd_bwd_kernels(c["B"], c["S"], c["Hq"], c["Hkv"], c["D"], dev, 200)      # sustained clocks first

@@ -79,7 +79,7 @@ def main():
     fake = FakeDist()
     for mod in (A, AL, HL, RB, RS, U, RZ):
         mod.dist = fake
-    cfg = bench.WORKLOADS[args.gpus]
+    cfg = (bench.CONFIG_WORKLOADS if os.environ.get("USP_BENCH_WORKLOAD") == "configs" else bench.WORKLOADS)[args.gpus]
     ud, rd = cfg["ud"], cfg["rd"]
     u_rank, r_rank = args.rank % ud, args.rank // ud
     Y.PROCESS_GROUP.ULYSSES_PG, Y.PROCESS_GROUP.RING_PG = Group(ud, u_rank), Group(rd, r_rank)
