@@ -68,24 +68,40 @@ def applicable(send: torch.Tensor, group) -> bool:
     return plan is not None and stripe_rows(send.shape[1], len(plan[1]))[1] > 0
 
 
-_AGREED = set()          # (shape, dtype) signatures every rank of the world group has confirmed
+_AGREED = set()          # (shape, dtype) signatures every rank of THIS sequence-parallel block has confirmed
+
+
+def forget_agreements():
+    """set_seq_parallel_pg: a re-initialised grid starts without confirmed signatures (another block, other peers)."""
+    _AGREED.clear()
 
 
 def _agree_once(send: torch.Tensor):
-    """First use of a buffer signature: ONE all-reduce over the world group confirms that every rank entered the relayed
-    exchange with the same shape and dtype (the two grouped phases below would otherwise pair up buffers of different sizes,
-    or leave a rank waiting for a peer that took the direct path).  Raises on every rank when they disagree."""
+    """First use of a buffer signature: every rank of the SEQUENCE-PARALLEL BLOCK (the ranks the two grouped phases below
+    couple: base .. base + ud * rd -- not the world: data-parallel replicas may legitimately exchange other shapes, or reach
+    a new shape at another step) tells every other one its signature, point to point, in ONE grouped send/recv, and raises
+    when they differ (the phases would otherwise pair up buffers of different sizes).  A rank of the block that took the
+    direct path instead leaves the others waiting here -- as it would in phase 1 -- which is why USP_EXCHANGE_RELAY must be
+    set for the whole block or not at all."""
     sig = (tuple(send.shape), str(send.dtype))
     if sig in _AGREED:
         return
     h = 0
     for x in (*send.shape, send.element_size()):
         h = (h * 1000003 + int(x)) % (1 << 40)
-    t = torch.tensor([float(h), -float(h)], dtype=torch.float64, device=send.device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    if float(t[0].item()) != float(h) or -float(t[1].item()) != float(h):
-        raise RuntimeError(f"relayed pair exchange: ranks disagree on the exchanged buffer (here {sig}); "
-                           "USP_EXCHANGE_RELAY needs every rank of the block in the same exchange with the same shape")
+    me = dist.get_rank()
+    peer, helpers = pair_and_helpers(me)
+    block = sorted(helpers + [peer])
+    mine = torch.tensor([float(h)], dtype=torch.float64, device=send.device)
+    theirs = torch.zeros((len(block), 1), dtype=torch.float64, device=send.device)
+    ops = []
+    for j, w in enumerate(block):
+        ops += [dist.P2POp(dist.isend, mine, w), dist.P2POp(dist.irecv, theirs[j], w)]
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    if not bool((theirs == float(h)).all().item()):
+        raise RuntimeError(f"relayed pair exchange: the ranks of this sequence-parallel block disagree on the exchanged buffer "
+                           f"(here {sig}); USP_EXCHANGE_RELAY needs every rank of the block in the same exchange with the same shape")
     _AGREED.add(sig)
 
 

@@ -63,6 +63,7 @@ def set_seq_parallel_pg(sp_ulysses_degree, sp_ring_degree, rank, world_size, use
     PROCESS_GROUP.RING_PG = ring_pg
     from .comm import relay_exchange
     relay_exchange.GRID = (sp_ulysses_degree, sp_ring_degree, world_size, bool(use_ulysses_low))      # who is whose peer
+    relay_exchange.forget_agreements()             # buffer signatures confirmed on the previous grid mean nothing on this one
     # every rank is here by contract: the one collective moment to measure what the schedules size themselves by --
     # opt-in (USP_LINK_PROBE=1, comm/link.py): a reference-style script must not meet a hidden collective here
     from .comm.link import probe_link_rate

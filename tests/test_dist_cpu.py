@@ -673,3 +673,38 @@ def _relay_worker(rank, ws, ud, rd, low):
 @pytest.mark.parametrize("ws,ud,rd,low", [(4, 2, 2, True), (8, 2, 4, True), (8, 2, 4, False)])
 def test_relayed_pair_exchange_is_bit_identical(ws, ud, rd, low):
     assert all(run_distributed(_relay_worker, ws, ud, rd, low))
+
+
+def _relay_dp_worker(rank, ws):
+    """Data-parallel x sequence-parallel (world 8 = 2 replicas of ulysses 2 x ring 2): the relayed exchange couples the
+    ranks of ONE sequence-parallel block only.  The two replicas exchange buffers of DIFFERENT shapes (another batch /
+    sequence length per replica is legitimate) and replica 1 makes one exchange more than replica 0: the shape agreement
+    must neither raise "ranks disagree" nor wait for the other block (round 4 ran it over the world group: ADVICE.md).
+    A re-initialised grid forgets the confirmed signatures."""
+    import yunchang_amd as Y
+    import yunchang_amd.comm.all_to_all as A
+    import yunchang_amd.comm.relay_exchange as RX
+    ud, rd = 2, 2
+    Y.set_seq_parallel_pg(ud, rd, rank, ws)
+    upg = Y.PROCESS_GROUP.ULYSSES_PG
+    replica = rank // (ud * rd)
+    ok = True
+    RX._OVERRIDE["relay"] = True
+    try:
+        for n in range(2 + replica):                           # replica 1: three exchanges, replica 0: two
+            rows = 16 + 8 * replica + 4 * n                    # shapes differ between the replicas and from call to call
+            torch.manual_seed(rank * 10 + n)
+            send = torch.randn(2, rows, 2, 8)
+            RX._OVERRIDE["relay"] = False
+            want = A._exchange(send, upg, False)
+            RX._OVERRIDE["relay"] = True
+            ok = ok and RX.applicable(send, upg) and torch.equal(A._exchange(send, upg, False), want)
+        ok = ok and len(RX._AGREED) == 2 + replica
+    finally:
+        RX._OVERRIDE.clear()
+    Y.set_seq_parallel_pg(ud, rd, rank, ws)
+    return ok and len(RX._AGREED) == 0
+
+
+def test_relayed_exchange_agrees_inside_its_sequence_parallel_block_only():
+    assert all(run_distributed(_relay_dp_worker, 8))

@@ -77,3 +77,63 @@ def test_the_checker_sees_a_planted_hazard(tmp_path):
         "\ts_endpgm",
         ".Lfunc_end0:", ""]))
     assert H.check(str(clean), "_Z1cv", out=found.append) == 0
+
+
+def test_the_checker_follows_loop_back_edges(tmp_path):
+    """Round 4's scan ran in layout order and never followed a branch: an MFMA at the END of a loop body whose result the
+    loop HEAD reads was invisible to it, and so was a producer at the loop's end feeding an MFMA at
+    its head.  Both planted here; the same loop with the wait states in place is clean."""
+    import mfma_hazards as H
+    s = tmp_path / "loop.s"
+    s.write_text("\n".join([
+        "_Z1lv:",
+        ".LBB0_1:",
+        "\tv_add_f32_e32 v50, v0, v52",                                      # reads D of the MFMA at the loop's end
+        "\ts_nop 7",
+        "\ts_nop 7",
+        "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[40:43], v[44:47], v[0:15]",
+        "\ts_cbranch_scc1 .LBB0_1",
+        "\ts_nop 15",
+        "\ts_endpgm",
+        ".Lfunc_end0:", ""]))
+    found = []
+    assert H.check(str(s), "_Z1lv", out=found.append) == 1 and found[0].startswith("B:"), found
+    s2 = tmp_path / "loop2.s"
+    s2.write_text("\n".join([
+        "_Z1mv:",
+        ".LBB0_1:",
+        "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[40:43], v[44:47], v[0:15]",   # its A operand is written at the loop's end
+        "\ts_nop 15",
+        "\tv_cvt_pk_bf16_f32 v40, v1, v2",
+        "\ts_cbranch_scc1 .LBB0_1",
+        "\ts_endpgm",
+        ".Lfunc_end0:", ""]))
+    found = []
+    assert H.check(str(s2), "_Z1mv", out=found.append) == 1 and found[0].startswith("A:"), found
+    ok = tmp_path / "ok.s"
+    ok.write_text("\n".join([
+        "_Z1ov:",
+        ".LBB0_1:",
+        "\tv_mfma_f32_32x32x16_bf16 v[0:15], v[40:43], v[44:47], v[0:15]",
+        "\ts_nop 15",
+        "\tv_cvt_pk_bf16_f32 v40, v1, v2",
+        "\ts_nop 1",
+        "\ts_cbranch_scc1 .LBB0_1",
+        "\ts_nop 15",
+        "\tv_add_f32_e32 v50, v0, v52",
+        "\ts_endpgm",
+        ".Lfunc_end0:", ""]))
+    assert H.check(str(ok), "_Z1ov", out=found.append) == 0
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"), reason="no llvm-objdump")
+def test_no_hazard_in_the_shipped_library():
+    """The same check on the DISASSEMBLY of libusp_hip.so as it ships (what __graft_entry__.build() runs): a rebuild with
+    another hipcc is guarded by the library it produced, not by a fresh -S compile next to it."""
+    import mfma_hazards as H
+    lib = os.path.join(ROOT, "long-context-attention_amd", "libusp_hip.so")
+    if not os.path.exists(lib):
+        pytest.skip("libusp_hip.so not built")
+    found = []
+    n, bad = H.check_library(lib, out=found.append)
+    assert n >= 12 and bad == 0, found[:10]
