@@ -499,8 +499,9 @@ def pmc_traffic():
             return None
         res = {"kernel": ROOFLINE_KERNEL, "read_MB": rd, "write_MB": wr, "algorithmic_MB": ROOFLINE_ALGORITHMIC_MB,
                "kernel_src_sha16": sha,
-               "note": "the GQA head split writes one fp32 dK / dV partial per query head (8 x 2 x 128 MiB) that reduce_heads_kernel "
-                       "sums: traffic above the algorithmic bytes by design, at 1 % of the HBM roof",
+               "note": "above the algorithmic bytes by the flash tiling: every 128-key item re-streams its head's Q / dO tiles (served "
+                       "by L2 / MALL, the misses are the HBM reads), and the GQA head split writes one fp32 dK / dV partial per query "
+                       "head that reduce_heads_kernel sums -- 3-4 % of the HBM roof over the launch: the kernel is MFMA-bound by 25x",
                "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources)"}
         if sha == kernel_source_sha16():
             return res
