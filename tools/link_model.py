@@ -27,6 +27,51 @@ def pipeline(t_in, t_comp, t_out, ng, eff=1.0):
     return lane, lane - t_comp / eff
 
 
+def round5(ms):
+    """Round 5: what `bench.py --gpus N` runs -- the metric's configuration (B1 S65536 H32/Hkv4 D128 bf16 causal fwd+bwd, 123.15
+    TFLOP per iteration) on the grids 1x1, 2x1, 1x4, 2x4 -- from the compute-only iteration of one rank measured on one MI355X
+    with round 5's kernels (profiles/r05_rank_emulation.txt; N = 1: the driver's own line, profiles/r05_bench_driver_cmd_*.json)
+    and the bytes each schedule puts on a link.  fwd : bwd = 0.235 : 0.765 (28.4 : 92.7 ms on one GPU)."""
+    F = 123.15
+    print("\nround 5 bench workloads (B1 S65536 H32/Hkv4 fwd+bwd at every N; compute-only per rank: profiles/r05_rank_emulation.txt)")
+    print("   N=1  1x1: 121.4 ms per iteration = %5.0f TFLOP/s (measured: the driver's command on one box)" % (F / 121.4 * 1e3))
+    # N = 2, ulysses 2: per rank q 256 MiB, k / v 32 MiB each before the exchange; half of everything goes to the peer
+    comp = 60.09
+    ex = dict(fi=ms((128 + 32) * MiB), fo=ms(128 * MiB), bi=ms(128 * MiB), bo=ms((128 + 32) * MiB))
+    for ng, c in ((1, 59.83), (2, comp)):
+        tf, _ = pipeline(ex["fi"], c * 0.235, ex["fo"], ng)
+        tb, _ = pipeline(ex["bi"], c * 0.765, ex["bo"], ng)
+        tot = tf + tb
+        print("   N=2  2x1, %d head group(s): exchanges %.2f + %.2f + %.2f + %.2f ms over ONE link, compute %.1f ms -> %.1f ms per iteration = %5.0f "
+              "TFLOP/s on 2 GPUs, overlap %.2f" % (ng, ex["fi"], ex["fo"], ex["bi"], ex["bo"], c, tot, F / tot * 1e3,
+                                                 1 - (tot - c) / sum(ex.values())))
+    # N = 4, ring 4 zigzag: K / V of a peer 2 x 16 MiB (forward and again in the backward: three links in parallel); the travelling
+    # fp32 dK + dV 64 MiB per hop, every hop but the last beside a step's kernels (5.6 ms), the last one rounded (32 MiB)
+    comp, kv, hop = 29.54, ms(32 * MiB), ms(64 * MiB)
+    step_b = comp * 0.765 / 4
+    tot = comp + max(0.0, kv - comp * 0.235 / 4) + max(0.0, hop - step_b) * 3 + hop / 2
+    comm = 2 * kv + 3 * hop + hop / 2
+    print("   N=4  1x4 zigzag: K/V fetch %.2f ms x 2 (3 links in parallel), dK/dV hop %.2f ms against %.1f ms of kernels per step, last hop "
+          "rounded %.2f ms exposed -> %.1f ms per iteration = %5.0f TFLOP/s on 4 GPUs, overlap %.2f"
+          % (kv, hop, step_b, hop / 2, tot, F / tot * 1e3, 1 - (tot - comp) / comm))
+    # N = 8: the section above with round 5's compute-only iteration (16.36 ms pipelined, 16.19 ms one exchange; round 2: 16.7)
+    fwd, bwd = 16.19 * 0.235, 16.19 * 0.765
+    e8 = dict(fi=ms(40 * MiB), fo=ms(32 * MiB), bi=ms(32 * MiB), bo=ms(40 * MiB))
+    hop8, kv8 = ms(32 * MiB), ms(16 * MiB)
+    for label, ng, eff, relay in (("one exchange (USP_SAFE_COMM=1)", 1, 1.0, 1.0), ("2 head groups pipelined (default)", 2, 16.19 / 16.36, 1.0),
+                                  ("default + pair exchanges striped over 6 helpers (USP_EXCHANGE_RELAY=1)", 2, 16.19 / 16.36, 3 / 8)):
+        e = {n: t * relay for n, t in e8.items()}
+        tf, _ = pipeline(e["fi"], fwd, e["fo"], ng, eff)
+        tb, _ = pipeline(e["bi"], bwd, e["bo"], ng, eff)
+        last = hop8 / ng / 2
+        tot = tf + tb + last
+        comm = sum(e.values()) + 3 * hop8 + ng * last + 2 * kv8
+        print("   N=8  2x4, %-74s %.1f ms per iteration = %5.0f TFLOP/s on 8 GPUs, overlap %.2f"
+              % (label + ":", tot, F / tot * 1e3, 1 - (tot - (fwd + bwd) / eff) / comm))
+    print("   (overlap >= 0.90 at N=8 needs < 0.46 ms exposed of 4.6 ms: the first-in / last-out exchange of each pass alone is 1.18 ms at 64 GB/s;"
+          "\n    self-chunk starts + row-chunked tails would reach 0.88 by this model, 0.92 with the relay on top -- DESIGN.md 5: not built)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--link-gbs", type=float, default=64.0, help="one xGMI link, one direction, GB/s")
@@ -135,6 +180,8 @@ def main():
     comm = sum(ex.values()) + 3 * hop + 2 * hop / 4 + 2 * kv
     print("   with self-chunk starts + row-chunked tails (3-4 launches instead of 1 at four places, ~0.2 ms of kernel time): %.2f ms exposed -> overlap %.2f"
           % (sum(cut.values()), 1 - sum(cut.values()) / comm))
+
+    round5(ms)
 
     # Ring backward: the travelling dK/dV (relay, the reference's order) against USP_DKDV_RETURN=direct (every block
     # straight to its owner over its own link, front-half blocks at half size).  Per ring rank; t_c = kernels of one step.
