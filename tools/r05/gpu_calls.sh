@@ -1,0 +1,104 @@
+#!/bin/bash
+# Round 5's GPU calls, one function per call (bodies as they ran; outputs merged back under gpurun_out/r05/, the ones that are
+# evidence copied to profiles/ -- profiles/r05_INDEX.md).   usage:  gpurun -- 'bash tools/r05/gpu_calls.sh run10_prof_and_tests'
+
+run01_row64_tests() {
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+( time timeout 1500 python -m pytest tests/test_gpu_row64.py tests/test_gpu_mutation.py -q -x 2>&1 | tail -40 ) > gpurun_out/r05/01_row64.log 2>&1
+tail -30 gpurun_out/r05/01_row64.log
+}
+
+run02_bench() {
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r05
+( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/r05/02_bench.log 2>&1
+grep -E "^\{" gpurun_out/r05/02_bench.log > gpurun_out/r05/02_bench_line.json
+tail -5 gpurun_out/r05/02_bench.log | cut -c1-3000
+( time timeout 900 python -m pytest tests/test_gpu_rccl_order.py -q -x -k "bench_" 2>&1 | tail -15 ) > gpurun_out/r05/02_grid.log 2>&1
+tail -12 gpurun_out/r05/02_grid.log
+}
+
+# round 5: per-tile anatomy of the dK/dV kernel's two roles (s_memtime build abl/b_tm), GQA rank-block shape
+run04_dkdv_anatomy() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench
+mkdir -p $R/gpurun_out/r05
+export USP_KBENCH_FLAGS=16        # USP_BWD_SKIP_DQ: the dK/dV launch alone
+LD_LIBRARY_PATH=$R/abl/b_tm timeout 120 $K bwd 1 16384 16384 16 2 128 1 0 0 1 2>&1 | grep "^TM" | awk '{k=$3" "$5; if (c[k]++ < 2) print}' | sort -k3n -k5n | head -40
+}
+
+# round 5: per-item anatomy of the forward and the dQ kernel (s_memtime builds abl/f_tm, abl/q_tm) at the 64K rank-block shape
+run05_fwd_dq_anatomy() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench
+LD_LIBRARY_PATH=$R/abl/f_tm timeout 120 $K fwd 1 16384 16384 16 2 128 1 0 0 1 2>&1 | grep "^TF" | awk '{k=$3" "$7; if (c[k]++ < 1) print}' | sort -k3n -k7n | head -24
+export USP_KBENCH_FLAGS=32        # USP_BWD_SKIP_DKDV: the dQ launch alone
+LD_LIBRARY_PATH=$R/abl/q_tm timeout 120 $K bwd 1 16384 16384 16 2 128 1 0 0 1 2>&1 | grep "^TQ" | awk '{k=$3" "$7; if (c[k]++ < 1) print}' | sort -k3n -k7n | head -24
+timeout 120 $K bwd 1 16384 16384 16 2 128 1 0 0 5 2>&1 | grep TIME
+unset USP_KBENCH_FLAGS
+timeout 120 $K fwd 1 16384 16384 16 2 128 1 0 0 5 2>&1 | grep TIME
+}
+
+# round 5: (1) MFMA-only ceiling + clock / power telemetry beside the product kernels, one box, one process;
+#          (2) one rank of the bench workloads of N = 2, 4, 8 with the wire replaced by local copies (compute-only ceilings)
+run06_ceiling_emulation() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05
+timeout 300 python tools/r05/ceiling.py > gpurun_out/r05/06_ceiling.txt 2>&1
+tail -30 gpurun_out/r05/06_ceiling.txt
+for n in 8 4 2; do
+  timeout 200 python tools/rank_emulation.py --gpus $n --iters 4 2>&1 | grep -A1 "^configs" 
+  timeout 200 python tools/rank_emulation.py --gpus $n --iters 4 --env USP_PIPELINE_ULYSSES=0 2>&1 | grep -A1 "^configs" | tail -1
+done > gpurun_out/r05/06_rank_emulation.txt 2>&1
+cat gpurun_out/r05/06_rank_emulation.txt
+}
+
+# round 5: dK/dV kernel with the statistics two tiles ahead (store at the head of the stream) + fixed-register resident fragments
+run07_dkdv_early_stats() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench
+timeout 600 $K suite bwd 2>&1 | grep -E "FAIL|SUITE|TIME  bwd"
+export USP_KBENCH_FLAGS=16        # USP_BWD_SKIP_DQ: the dK/dV launch alone
+for i in 1 2; do
+timeout 120 $K bwd 1 16384 16384 16 2 128 1 0 0 10 2>&1 | grep TIME
+timeout 120 $K bwd 2 8192 8192 16 16 128 1 0 0 20 2>&1 | grep TIME
+done
+LD_LIBRARY_PATH=$R/abl/b_tm timeout 120 $K bwd 1 16384 16384 16 2 128 1 0 0 1 2>&1 | grep "^TM" | awk '{k=$3" "$5; if (c[k]++ < 1) print}' | sort -k3n -k5n | head -12
+}
+
+# round 5: dK/dV kernel variants -- correctness (native suite, NaN tails) + timing at C2, the 8-GPU rank block and the N = 1 workload
+run08_dkdv() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench
+timeout 600 $K suite bwd 2>&1 | grep -E "FAIL|SUITE"
+export USP_KBENCH_FLAGS=16        # USP_BWD_SKIP_DQ: the dK/dV launch alone
+for i in 1 2; do
+timeout 120 $K bwd 2 8192 8192 16 16 128 1 0 0 20 2>&1 | grep TIME
+timeout 120 $K bwd 1 16384 16384 16 2 128 1 0 0 10 2>&1 | grep TIME
+timeout 120 $K bwd 1 65536 65536 32 4 128 1 0 0 2 2>&1 | grep TIME
+done
+LD_LIBRARY_PATH=$R/abl/b_tm timeout 120 $K bwd 1 16384 16384 16 2 128 1 0 0 1 2>&1 | grep "^TM" | awk '{k=$3" "$5; if (c[k]++ < 1) print}' | sort -k3n -k5n | head -8
+LD_LIBRARY_PATH=$R/abl/b_tm timeout 120 $K bwd 2 8192 8192 16 16 128 1 0 0 1 2>&1 | grep "^TI" | awk '{k=$3" "$7; if (c[k]++ < 1) print}' | sort -k3n -k7n | head -8
+}
+
+# round 5: same-box A/B of the dK/dV kernel: abl/b_old (round 4's) against the in-tree library, alternating
+run09_dkdv_ab() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench
+export USP_KBENCH_FLAGS=16        # USP_BWD_SKIP_DQ: the dK/dV launch alone
+for i in 1 2 3; do
+for lib in $R/abl/b_old $R/long-context-attention_amd; do
+echo "== $(basename $lib)"
+LD_LIBRARY_PATH=$lib timeout 120 $K bwd 2 8192 8192 16 16 128 1 0 0 30 2>&1 | grep TIME
+LD_LIBRARY_PATH=$lib timeout 120 $K bwd 1 16384 16384 16 2 128 1 0 0 15 2>&1 | grep TIME
+LD_LIBRARY_PATH=$lib timeout 120 $K bwd 1 65536 65536 32 4 128 1 0 0 2 2>&1 | grep TIME
+done; done
+}
+
+run10_prof_and_tests() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05
+( time bash tools/prof_round.sh r05 ) > gpurun_out/r05/10_prof_round.log 2>&1
+tail -5 gpurun_out/r05/10_prof_round.log
+( time timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -25 ) > gpurun_out/r05/10_pytest_gpu.log 2>&1
+tail -12 gpurun_out/r05/10_pytest_gpu.log
+}
+
+case "$1" in
+  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests) "$1" ;;
+  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests}"; exit 64 ;;
+esac
