@@ -57,7 +57,7 @@ enum {
  * per process -- which is what lets a parity test pin the kernel it means to test, and a bench time both families on
  * the same box:
  *   USP_FORCE_ROW64   every flash kernel of the call must come from the 64-row family; a call that family does not
- *                     serve (head dim != 128, packed batch, window, forward K split, GQA without the head-split
+ *                     serve (head dim != 128, packed batch, window, forward K split, GQA backward without the head-split
  *                     workspace) returns USP_EUNSUPPORTED and launches nothing;
  *   USP_FORCE_WAVE32  every flash kernel of the call comes from the 32-rows-per-wave family.
  * Both bits at once: USP_EINVAL.  usp_last_launch_kinds() reports what a call actually launched. */

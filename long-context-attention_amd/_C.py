@@ -492,8 +492,6 @@ def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causa
     ff = _family_flag(family)
     a.flags = (USP_LAUNCH_INTERLEAVE if interleave else 0) | ff | {None: 0, "dkdv": USP_BWD_SKIP_DQ, "dq": USP_BWD_SKIP_DKDV}[only]
     a.dq_splits, a.dkdv_splits = bwd_splits(B, Sq, Sk, Hq, bool(causal)) if splits is None else splits
-    if ff == USP_FORCE_ROW64 and splits is None:
-        a.dq_splits = 0                            # the 64-row dQ kernel has no key cut; the policy's cut is optional
     win = _window(window)
     if win is not None:
         a.flags |= USP_ATTN_WINDOW

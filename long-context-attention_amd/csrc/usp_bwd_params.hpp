@@ -85,7 +85,8 @@ template <int D> USP_DEV int tile_swz(int row) {
 // one it serves (the caller then takes the 8-wave kernel).
 bool launch_dkdv64(const BwdParams& p, int dtype, bool causal, hipStream_t st, int* rc);
 bool dkdv64_serves(const BwdParams& p, int dtype);     // ... whether it would (no launch)
-// The one-wave-per-SIMD dQ launch (usp_flash_bwd_dq64.hip): dense launches of D = 128 (bf16 / fp16) without a window or a key cut.
+// The one-wave-per-SIMD dQ launch (usp_flash_bwd_dq64.hip): dense launches of D = 128 (bf16 / fp16) without a window; key cuts
+// (ksplit > 1: partials to ws_dq, the caller launches reduce_cuts_kernel behind it) since round 5.
 bool launch_dq64(const BwdParams& p, int dtype, bool causal, hipStream_t st, int* rc);
 bool dq64_serves(const BwdParams& p);
 

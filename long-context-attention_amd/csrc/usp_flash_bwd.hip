@@ -896,8 +896,16 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st, int force, int s
   if (D == 128 && forced_waves != 8 && forced_dq != 8) {
     int rc64 = USP_ELAUNCH;
     if (launch_dq64(p, DT, causal, st, &rc64)) {
-      if (rc64 == USP_OK) launch_kinds_note(USP_KIND_DQ_ROW64);
-      return rc64;
+      if (rc64 != USP_OK) return rc64;
+      launch_kinds_note(USP_KIND_DQ_ROW64);
+      if (p.ksplit > 1) {          // same stream: the cuts' partials are complete when this starts
+        const int64_t items = (int64_t)p.B * p.Sq * p.Hq * (D / 4);
+        int64_t rg = (items + 255) / 256;
+        rg = rg > 2048 ? 2048 : rg;
+        hipLaunchKernelGGL((reduce_cuts_kernel<D, DT>), dim3((int)rg), dim3(256), 0, st, p);
+        launch_kinds_note(USP_KIND_REDUCE_CUTS);
+      }
+      return hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
     }
   }
   p.nblk = (p.Sq + 255) / 256;

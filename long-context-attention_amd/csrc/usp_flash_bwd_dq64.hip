@@ -98,8 +98,10 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
   USP_TM(const uint64_t tm_item = __builtin_amdgcn_s_memtime();)
   w = walk.dealt(w, p->nblk);
   const int qt_r = w % p->nblk;
-  const int rest = w / p->nblk;
+  int rest = w / p->nblk;
   const int qt = CAUSAL ? (p->nblk - 1 - qt_r) : qt_r;    // heavy (late) tiles first
+  int cut = 0;                                            // key cut of a few-item launch (ABI v5 dq_splits): this item's run of
+  if (p->ksplit > 1) { cut = rest % p->ksplit; rest /= p->ksplit; }     // the key tiles, partial to the workspace
   const int h = rest % p->Hq, b = rest / p->Hq;
   const int hkv = h / p->G;
   const int q0 = qt * kBM;
@@ -124,6 +126,15 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
   }
   const int n_w = wave_kv_end > 0 ? (wave_kv_end + kTile - 1) / kTile : 0;  // tiles this wave works on
   if (n_full > n_w) n_full = n_w;
+  // key cut: the workgroup streams tiles [tb, te) of its [0, nt) -- equal runs, as the 8-wave kernel cuts them
+  int tb = 0, te = nt;
+  if (p->ksplit > 1) {
+    const int per = (nt + p->ksplit - 1) / p->ksplit;
+    tb = cut * per < nt ? cut * per : nt;
+    te = tb + per < nt ? tb + per : nt;
+  }
+  const int e_full = n_full < tb ? tb : (n_full > te ? te : n_full);        // [tb, e_full) plain, [e_full, e_own) masked,
+  const int e_own = n_w < tb ? tb : (n_w > te ? te : n_w);                  // [e_own, te) other waves' tiles
 
   // ---- resident B operands: Q and dO fragments of the wave's 64 rows, loaded straight into the accumulator file (asm
   // loads + wait: usp_flash_bwd64.hip explains why hipcc must not see them) ------------------------------------------------
@@ -163,9 +174,9 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
   const int64_t k_tb = (int64_t)kTile * k_rowb, v_tb = (int64_t)kTile * v_rowb;         // bytes per tile step
   int k_step = 4 * k_rowb - 1024, v_step = 4 * v_rowb - 1024;
   int lds_w = wave * 4096;
-  const char* k_cur = p->k + 2 * (b * p->k_sb + hkv * p->k_sh) + (int64_t)wave * 16 * k_rowb;
-  const char* v_cur = p->v + 2 * (b * p->v_sb + hkv * p->v_sh) + (int64_t)wave * 16 * v_rowb;
-  int rows_kv = p->Sk - 16 * wave;               // valid rows from the cursors on (<= 0: nothing left, lanes read 0)
+  const char* k_cur = p->k + 2 * (b * p->k_sb + hkv * p->k_sh) + (int64_t)wave * 16 * k_rowb + tb * k_tb;
+  const char* v_cur = p->v + 2 * (b * p->v_sb + hkv * p->v_sh) + (int64_t)wave * 16 * v_rowb + tb * v_tb;
+  int rows_kv = p->Sk - 16 * wave - tb * kTile;  // valid rows from the cursors on (<= 0: nothing left, lanes read 0)
   u32x4 k_rs, v_rs;
   int dma_buf = 0;
   auto dma_open = [&](int buf) {                 // scalar work only, no branch: it runs inside the MFMA stream
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
       pin_agpr(dq[qb][dj]);
     }
 
-  dma_open(0);
+  dma_open(tb & 1);                              // (iteration t reads buffer t & 1)
 #pragma unroll
   for (int n = 0; n < 8; ++n) dma_piece(n);
   dma_drain();
@@ -328,21 +339,21 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
   };
   const std::integral_constant<bool, false> plain;
   const std::integral_constant<bool, true> masked;
-  int t = 0;
+  int t = tb;
   USP_TM(const uint64_t tm_loop = __builtin_amdgcn_s_memtime();)
   __builtin_amdgcn_s_waitcnt(0x0f70);            // (usp_flash_bwd64.hip: nothing may still count as pending at a loop header)
-  for (; t < n_full; ++t) iter(plain, t, true);
+  for (; t < e_full; ++t) iter(plain, t, true);
   __builtin_amdgcn_s_waitcnt(0x0f70);
-  for (; t < n_w; ++t) iter(masked, t, true);
+  for (; t < e_own; ++t) iter(masked, t, true);
   mfma_settle(dq);
   USP_TM(const uint64_t tm_own = __builtin_amdgcn_s_memtime(); const uint64_t tm_plain_n = n_full;)
-  for (; t < nt; ++t) iter(plain, t, false);     // tiles other waves of the workgroup still work on: keep the cadence
+  for (; t < te; ++t) iter(plain, t, false);     // tiles other waves of the workgroup still work on: keep the cadence
   USP_TM(const uint64_t tm_epi = __builtin_amdgcn_s_memtime();)
 
   // ---- epilogue: fp32 store / accumulate, or final 16-bit store (dQ^T: a lane holds 4-dim pieces of ONE query row) --------
   mfma_settle(dq);
   asm volatile("" : "+s"(p));
-  const bool wide = (p->wide16 & 1) != 0;         // 16-bit final output, rows 16-byte aligned, nothing accumulated
+  const bool wide = (p->wide16 & 1) != 0;         // 16-bit final output, rows 16-byte aligned, nothing accumulated (never with a cut)
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const int row = qw + 32 * qb + l31;
@@ -353,7 +364,12 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
     } else if (row < p->Sq) {
       float* o1 = p->dq + b * p->dq_sb + (int64_t)row * p->dq_ss + h * p->dq_sh;
       char* h1 = p->dq16 ? p->dq16 + 2 * (b * p->dq16_sb + (int64_t)row * p->dq16_ss + h * p->dq16_sh) : nullptr;
-      const int acc_f = p->accum_dq;
+      int acc_f = p->accum_dq;
+      if (p->ksplit > 1) {       // the partial of this cut, combined (deterministically) with the others and with an accumulated
+        o1 = p->ws_dq + ((((int64_t)cut * p->B + b) * p->Sq + row) * p->Hq + h) * D;      // dq by reduce_cuts_kernel
+        h1 = nullptr;
+        acc_f = 0;
+      }
       const float sc = p->scale;
 #pragma unroll
       for (int dj = 0; dj < NDJ; ++dj)
@@ -380,9 +396,9 @@ USP_TM(
 }
 
 bool dq64_serves(const BwdParams& p_in) {
-  // dense launches (bf16 / fp16) without a window, a cut of the key range or the dynamic item queue; the pieces' swizzle is XORed
-  // into the per-lane byte offset (rows a multiple of 256 bytes apart), 64 rows of K / V span less than 2^31 bytes
-  if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on || p_in.ksplit > 1) return false;
+  // dense launches (bf16 / fp16) without a window or the dynamic item queue; the pieces' swizzle is XORed into the per-lane byte
+  // offset (rows a multiple of 256 bytes apart), 64 rows of K / V span less than 2^31 bytes
+  if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on) return false;
   if ((p_in.k_ss * 2) % 256 != 0 || (p_in.v_ss * 2) % 256 != 0 || p_in.k_ss * 128 >= (1LL << 31) || p_in.v_ss * 128 >= (1LL << 31))
     return false;
   return true;
@@ -399,8 +415,8 @@ bool launch_dq64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st, 
   if (!dq64_serves(p_in)) return false;
   BwdParams p = p_in;
   p.nblk = (p.Sq + 255) / 256;
-  p.n_items = p.B * p.Hq * p.nblk;
-  p.wide16 = (p.dq16 && !p.accum_dq && rows16_aligned(p.dq16, p.dq16_sb, p.dq16_ss, p.dq16_sh)) ? 1 : 0;
+  p.n_items = p.B * p.Hq * p.nblk * p.ksplit;
+  p.wide16 = (p.ksplit <= 1 && p.dq16 && !p.accum_dq && rows16_aligned(p.dq16, p.dq16_sb, p.dq16_ss, p.dq16_sh)) ? 1 : 0;
   const int grid = (!p.interleave && p.n_items > cus) ? cus : p.n_items;      // persistent: one workgroup per CU
   const size_t lds = 4 * kTile * 128 * 2;
   if (dtype == USP_BF16) {

@@ -247,6 +247,48 @@ def test_row64_merge_in_and_partial_final_ranges(dev, Sq, Sk, Sa, causal2, fb, f
     assert ar.guards_intact()
 
 
+@pytest.mark.parametrize("B,Sq,Sk,Hq,Hkv,causal,cuts", [(1, 1024, 1024, 2, 2, True, (2, 2)), (1, 333, 200, 2, 1, True, (3, 4)),
+                                                        (2, 300, 712, 4, 2, False, (8, 2)), (1, 2048, 2048, 2, 1, True, (4, 1)),
+                                                        (1, 1500, 1500, 1, 1, True, (5, 0))])
+def test_row64_backward_cuts(dev, B, Sq, Sk, Hq, Hkv, causal, cuts):
+    """The cuts of few-item backward launches (ABI v5 dq_splits / dkdv_splits) through the 64-row kernels: the dQ kernel
+    takes the key cut since round 5 (`flash_bwd_dq64_kernel` + `reduce_cuts_kernel`; round 4 fell back to the 8-wave dQ
+    kernel), the dK/dV kernel the query cut.  Every cut against the uncut forced launch (same sums in another order: tight)
+    and against the oracle; fp32-accumulated dQ on top of a previous value as a ring step does it."""
+    from yunchang_amd import _C
+    dt, D = "bfloat16", 128
+    rs = np.random.RandomState(31)
+    q, k, v, do = _inputs(rs, B, Sq, Sk, Hq, Hkv, D, dt)
+    scale = D ** -0.5
+    ro, rl = O.attention_ref(q, k, v, causal, scale)
+    o16 = round_to(ro.astype(np.float32), dt)
+    rdq, rdk, rdv = O.block_bwd(do, q, k, v, o16, rl, scale, causal)
+    tq, tk, tv, tdo, to16 = (torch.from_numpy(x).to(torch.bfloat16).to(dev) for x in (q, k, v, do, o16))
+    lse_t = torch.from_numpy(np.ascontiguousarray(rl, dtype=np.float32)).to(dev)
+    delta = torch.empty((B, Hq, Sq), dtype=torch.float32, device=dev)
+    _C.bwd_delta(tdo, to16, delta)
+    res = {}
+    for name, sp in (("uncut", (0, 0)), ("cut", cuts)):
+        dq, dk, dv = (torch.full_like(t, float("nan")) for t in (tq, tk, tv))
+        _C.flash_bwd(tdo, tq, tk, tv, lse_t, delta, None, None, None, scale, causal, dq16=dq, dk16=dk, dv16=dv, family="row64", splits=sp)
+        kinds = set(_C.last_launch_kinds())
+        assert {"dkdv_row64", "dq_row64"} <= kinds and not ({"dkdv_wave8", "dq_wave8"} & kinds), (name, kinds)
+        if name == "cut":
+            assert ("reduce_cuts" in kinds) == (cuts[0] > 1) and ("reduce_heads" in kinds) == (cuts[1] > 1 or Hq > Hkv), kinds
+        res[name] = [_f(x) for x in (dq, dk, dv)]
+    for a_, b_, r_, n_ in zip(res["cut"], res["uncut"], (rdq, rdk, rdv), ("dq", "dk", "dv")):
+        assert_close(a_, b_, 2e-2, 2e-2, f"{n_}: cut {cuts} against the uncut launch")          # (one 16-bit rounding apart)
+        assert_close(a_, r_, *TOL[dt]["grad"], f"{n_}: cut {cuts} against the oracle")
+    # fp32 accumulation on top of a previous value (accum_dq: what a ring step asks for), cut along the keys
+    if cuts[0] > 1:
+        base = torch.randn(B, Sq, Hq, D, device=dev, dtype=torch.float32)
+        acc = base.clone()
+        dk32, dv32 = (torch.empty(B, Sk, Hkv, D, device=dev, dtype=torch.float32) for _ in range(2))
+        _C.flash_bwd(tdo, tq, tk, tv, lse_t, delta, acc, dk32, dv32, scale, causal, accum_dq=True, family="row64", splits=cuts)
+        assert "reduce_cuts" in _C.last_launch_kinds()
+        assert_close(_f(acc) - _f(base), rdq, *TOL[dt]["grad"], "accumulated dq with a key cut")
+
+
 def test_forced_family_refuses_what_it_does_not_serve(dev):
     """USP_FORCE_ROW64 on a call the family does not serve returns USP_EUNSUPPORTED (RuntimeError in the binding) and
     launches nothing -- a test that pins the family can never silently run on the other one."""

@@ -98,7 +98,22 @@ tail -5 gpurun_out/r05/10_prof_round.log
 tail -12 gpurun_out/r05/10_pytest_gpu.log
 }
 
+# round 5: the dQ kernel's key cuts (ksplit > 1 served by flash_bwd_dq64_kernel): native suite (every backward shape x five cut pairs,
+# NaN tails), few-head timing with and without cuts, the new pytest cases
+run11_dq64_cuts() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench
+cd $R; mkdir -p gpurun_out/r05
+timeout 900 $K suite bwd 2>&1 | grep -E "FAIL|SUITE|TIME  bwd"
+for cuts in "0,0" "4,2" "2,1"; do
+  echo "== cuts $cuts"
+  USP_KBENCH_BWD_SPLITS=$cuts timeout 120 $K bwd 1 16384 16384 2 1 128 1 0 0 5 2>&1 | grep TIME
+  USP_KBENCH_BWD_SPLITS=$cuts timeout 120 $K bwd 1 16384 16384 4 4 128 1 0 0 5 2>&1 | grep TIME
+done
+timeout 900 python -m pytest tests/test_gpu_row64.py -q -x -k "cuts or refuses or dispatch" 2>&1 | tail -5
+timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "cuts" 2>&1 | tail -3
+}
+
 case "$1" in
-  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests) "$1" ;;
-  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests}"; exit 64 ;;
+  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts) "$1" ;;
+  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts}"; exit 64 ;;
 esac
