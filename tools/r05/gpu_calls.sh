@@ -113,7 +113,22 @@ timeout 900 python -m pytest tests/test_gpu_row64.py -q -x -k "cuts or refuses o
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -x -k "cuts" 2>&1 | tail -3
 }
 
+# round 5: the dQ kernel with the barrier between the dP and the dQ blocks + a K ring of three: native suite, then a same-box A/B
+# of the dQ launch alone against abl/q_base (the kernel without it), alternating
+run12_dq64_midbarrier() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench
+timeout 900 $K suite bwd 2>&1 | grep -E "FAIL|SUITE"
+export USP_KBENCH_FLAGS=32        # USP_BWD_SKIP_DKDV: the dQ launch alone
+for i in 1 2 3; do
+for lib in $R/abl/q_base $R/long-context-attention_amd; do
+echo "== $(basename $lib)"
+LD_LIBRARY_PATH=$lib timeout 120 $K bwd 2 8192 8192 16 16 128 1 0 0 30 2>&1 | grep TIME
+LD_LIBRARY_PATH=$lib timeout 120 $K bwd 1 16384 16384 16 2 128 1 0 0 15 2>&1 | grep TIME
+LD_LIBRARY_PATH=$lib timeout 120 $K bwd 1 65536 65536 32 4 128 1 0 0 2 2>&1 | grep TIME
+done; done
+}
+
 case "$1" in
-  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts) "$1" ;;
-  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts}"; exit 64 ;;
+  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier) "$1" ;;
+  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier}"; exit 64 ;;
 esac
