@@ -116,6 +116,94 @@ def pipeline_mode(ring_degree: int) -> bool:
     return _PIPELINE_BESIDE_RING_DEFAULT
 
 
+def self_chunk_mode(P: int, ring: int, causal, impl: str, rows_local: int) -> bool:
+    """Does the FIRST head group start on the rows this rank already holds (USP_SELF_CHUNK=1; round 5, opt-in)?
+
+    At ulysses degree 2 half of every exchanged tensor is the self chunk: a rank's own rows of the heads it will own never
+    cross a link.  Causal attention over those rows alone is a complete sub-block of the group's work -- rank 0 (rows [0, c)):
+    q[0:c] x k[0:c] causal = all of those rows; rank 1 (rows [c, 2c)): the diagonal block q[c:2c] x k[c:2c] -- so the first
+    group's kernels start AT ONCE, on views of the send buffer's self chunk, and only the rest of the group waits for the
+    exchange (forward: 1/4 resp. 1/4 of the group's work in front of the wait; backward, where K and V are already there and
+    only dO travels: 1/4 resp. 3/4).  That hides the one exchange of each pass nothing else can hide -- the first.
+    Built for ring degree 1 (the 2-GPU grid: the ring function there is ONE causal block, split here into two or three
+    launches joined by the kernel's fused LSE merge / fp32 accumulation); beside a ring the same split applies to step 0
+    but the K/V relay then has to start behind the exchange instead of behind the compute stream -- not built.
+    Results equal the unsplit launch up to fp32 summation order (the merge is the ring's own)."""
+    mode = _COMM_OVERRIDE.get("self_chunk", os.environ.get("USP_SELF_CHUNK", "0"))
+    if str(mode) not in ("1", "True"):
+        return False
+    return P == 2 and ring == 1 and bool(causal) and impl in ("basic", "zigzag") and rows_local >= 1
+
+
+def _self_views(send, u, splits):
+    """The self chunk of a packed send buffer (P, S/P, B, Ht, D) as (B, S/P, h_j, D) strided views, heads cut at `splits`."""
+    full = send[u].transpose(0, 1)
+    out, h0 = [], 0
+    for h in splits:
+        out.append(full[:, :, h0:h0 + h])
+        h0 += h
+    return out
+
+
+def _split_first_forward(be, u, selfs, full, wait, scale):
+    """The first head group's causal block at ring degree 1, ulysses degree 2, started on the self chunk (self_chunk_mode).
+    `selfs` = (q, k, v) of this rank's own rows (views of the send buffer), `full` = (q, k, v) over all 2c rows (views of the
+    receive buffer, valid behind `wait()`).  Returns (out, lse) as the ring forward would."""
+    qs, ks, vs = selfs
+    q, k, v = full
+    B, S, hq, D = q.shape
+    c = S // 2
+    out = torch.empty((B, S, hq, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, hq, S), dtype=torch.float32, device=q.device)
+    if u == 0:       # own rows [0, c): they see own keys only -- complete and final at once
+        be.fwd(qs, ks, vs, scale, True, lse[:, :, :c], out[:, :c])
+        wait()
+        be.fwd(q[:, c:], k, v, scale, True, lse[:, :, c:], out[:, c:])          # c rows x 2c keys, bottom-right causal
+    else:            # own rows [c, 2c): the diagonal block now, the peer's keys merged in behind the exchange
+        acc = torch.empty((B, c, hq, D), dtype=torch.float32, device=q.device)
+        be.fwd(qs, ks, vs, scale, True, lse[:, :, c:], None, acc, False, 0, 0)
+        wait()
+        be.fwd(q[:, c:], k[:, :c], v[:, :c], scale, False, lse[:, :, c:], out[:, c:], acc, True, 0, c)
+        be.fwd(q[:, :c], k[:, :c], v[:, :c], scale, True, lse[:, :, :c], out[:, :c])
+    return out, lse
+
+
+def _split_first_backward(be, u, do_self, do_full, wait, q, k, v, o, lse, scale):
+    """The backward of the same block: K, V, out and the LSE are there (saved), only dO travels -- the rows this rank owns
+    start at once, the peer's rows follow behind the exchange; dK / dV accumulate in fp32 across the two launches and are
+    rounded by the last one that touches a row.  Returns (dq, dk, dv) in q.dtype."""
+    B, S, hq, D = q.shape
+    kvh = k.shape[2]
+    c = S // 2
+    dev = q.device
+    delta = torch.empty((B, hq, S), dtype=torch.float32, device=dev)
+    dq = torch.empty((B, S, hq, D), dtype=q.dtype, device=dev)
+    dk = torch.empty((B, S, kvh, D), dtype=k.dtype, device=dev)
+    dv = torch.empty_like(dk)
+    dk32 = torch.empty((B, S, kvh, D), dtype=torch.float32, device=dev)
+    dv32 = torch.empty_like(dk32)
+    if u == 0:       # rows [0, c) x keys [0, c) first; then rows [c, 2c) x all keys on top
+        be.delta(do_self, o[:, :c], delta[:, :, :c])
+        dk32[:, c:].zero_()
+        dv32[:, c:].zero_()
+        be.bwd(do_self, q[:, :c], k[:, :c], v[:, :c], lse[:, :, :c], delta[:, :, :c], None, dk32[:, :c], dv32[:, :c], scale, True,
+               dq16=dq[:, :c])
+        wait()
+        be.delta(do_full[:, c:], o[:, c:], delta[:, :, c:])
+        be.bwd(do_full[:, c:], q[:, c:], k, v, lse[:, :, c:], delta[:, :, c:], None, dk32, dv32, scale, True,
+               accum_dk=True, accum_dv=True, dq16=dq[:, c:], dk16=dk, dv16=dv)
+    else:            # rows [c, 2c) x all keys first (3/4 of the block); then rows [0, c) x keys [0, c) on top
+        be.delta(do_self, o[:, c:], delta[:, :, c:])
+        be.bwd(do_self, q[:, c:], k, v, lse[:, :, c:], delta[:, :, c:], None, dk32, dv32, scale, True, dq16=dq[:, c:])
+        wait()
+        be.delta(do_full[:, :c], o[:, :c], delta[:, :, :c])
+        be.bwd(do_full[:, :c], q[:, :c], k[:, :c], v[:, :c], lse[:, :, :c], delta[:, :, :c], None, dk32[:, :c], dv32[:, :c], scale,
+               True, accum_dk=True, accum_dv=True, dq16=dq[:, :c], dk16=dk[:, :c], dv16=dv[:, :c])
+        be.cast(dk[:, c:], dk32[:, c:])              # keys [c, 2c) got gradients from the first launch only
+        be.cast(dv[:, c:], dv32[:, c:])
+    return dq, dk, dv
+
+
 # The default beside a ring.  Round 2 turned it on without any run through RCCL (ADVICE.md, round 2); round 3 first
 # built tests/test_gpu_rccl_order.py::test_pipelined_exchange_beside_a_ring_through_rccl -- BASELINE's 8-GPU grid
 # (ulysses 2 x ring 4, GQA, zigzag, forward + backward) and the 2 x 2 grids as virtual ranks whose every exchange and
@@ -205,7 +293,7 @@ def _qkv_to_seq(lane, q, k, v, P, ng, kvh, g, i, group):
     (P, S/P, B, kvh*g + 2*kvh, D) = [q heads | k heads | v heads] of (destination rank, group i) -- the
     GQA-capable form of the reference's packed exchange (async_attn_layer.py:100-128 stacks q|k|v of one head
     per rank, which needs Hkv == Hq).  Returns ((q, k, v) as (B, S, h, D) strided views of the receive buffer,
-    event)."""
+    event, the send buffer)."""
     hq = kvh * g
     send = None
     for x, h, h0 in ((q, hq, 0), (k, kvh, hq), (v, kvh, hq + kvh)):
@@ -217,17 +305,18 @@ def _qkv_to_seq(lane, q, k, v, P, ng, kvh, g, i, group):
         A.pack_head_group(x.view(B, Sl, P, ng, h, D)[:, :, :, i], send, h0)    # heads p*(ng*h) + i*h + (0..h)
     recv, ev = lane.exchange(send, group)
     full = A.view_seq(recv)                                        # (B, S, hq + 2 kvh, D)
-    return (full[:, :, :hq], full[:, :, hq:hq + kvh], full[:, :, hq + kvh:]), ev
+    return (full[:, :, :hq], full[:, :, hq:hq + kvh], full[:, :, hq + kvh:]), ev, send
 
 
 def _to_seq(lane, x, P, ng, h, i, group):
-    """Exchange head group i of x (B, S/P, H, D): returns ((B, S, h, D) view, event)."""
+    """Exchange head group i of x (B, S/P, H, D): returns ((B, S, h, D) view, event, the send buffer)."""
     B, Sl, H, D = x.shape
     if x.stride(3) != 1 or x.stride(2) != D:
         x = x.contiguous()
     x5 = x.view(B, Sl, P, ng, h, D)[:, :, :, i]                   # heads p*(ng*h) + i*h + (0..h)
-    recv, ev = lane.exchange(A.pack_head_group(x5), group)
-    return A.view_seq(recv), ev
+    send = A.pack_head_group(x5)
+    recv, ev = lane.exchange(send, group)
+    return A.view_seq(recv), ev, send
 
 
 def _to_heads_issue(lane, xs, P, group):
@@ -287,12 +376,22 @@ class _AsyncUSPFunc(torch.autograd.Function):
         if softmax_scale is None:
             softmax_scale = D ** (-0.5)
         overlap = ng > 1                # kernels run beside later groups' exchanges
+        split0 = self_chunk_mode(P, ring, causal, impl, Sl)          # the first group starts on this rank's own rows
+        u = dist.get_rank(ulysses_pg) if split0 else 0
         saved, outs = [], []
         with _Lane(q) as lane:
             # every input exchange is queued before any attention runs
             ins = [_qkv_to_seq(lane, q, k, v, P, ng, kvh, g, i, ulysses_pg) for i in range(ng)]
             for i in range(ng):
-                (qi, ki, vi), ev = ins[i]
+                (qi, ki, vi), ev, send_i = ins[i]
+                if split0 and i == 0:
+                    from ..kernels.attention import get_block_backend
+                    oi, lse_i = _split_first_forward(get_block_backend(beside_transfers=True), u,
+                                                     _self_views(send_i, u, (kvh * g, kvh, kvh)), (qi, ki, vi),
+                                                     lambda ev=ev: lane.wait(ev), softmax_scale)
+                    saved += [qi, ki, vi, oi, lse_i]
+                    outs.append(_to_heads_issue(lane, [oi], P, ulysses_pg))
+                    continue
                 lane.wait(ev)
                 oi, lse_i = fwd(ring_pg, qi, ki, vi, softmax_scale=softmax_scale, causal=causal, overlap=overlap)
                 saved += [qi, ki, vi, oi, lse_i]
@@ -304,6 +403,7 @@ class _AsyncUSPFunc(torch.autograd.Function):
                 A.unpack_head_group(recv, o5[:, :, :, i])
         ctx.save_for_backward(*saved)
         ctx.meta = (softmax_scale, causal, ulysses_pg, ring_pg, impl, P, ng, kvh, g, Hq, Hkv)
+        ctx.split0 = (split0, u)
         return out
 
     @staticmethod
@@ -316,9 +416,17 @@ class _AsyncUSPFunc(torch.autograd.Function):
         with _Lane(dout) as lane:
             douts = [_to_seq(lane, dout, P, ng, kvh * g, i, ulysses_pg) for i in range(ng)]
             pend = []
+            split0, u = getattr(ctx, "split0", (False, 0))
             for i in range(ng):
                 qi, ki, vi, oi, lse_i = saved[5 * i:5 * i + 5]
-                doi, ev = douts[i]
+                doi, ev, send_i = douts[i]
+                if split0 and i == 0:
+                    from ..kernels.attention import get_block_backend
+                    dqi, dki, dvi = _split_first_backward(get_block_backend(beside_transfers=True), u,
+                                                          _self_views(send_i, u, (kvh * g,))[0], doi, lambda ev=ev: lane.wait(ev),
+                                                          qi, ki, vi, oi, lse_i, softmax_scale)
+                    pend.append(_grads_to_heads_issue(lane, dqi, dki, dvi, [], P, ulysses_pg))
+                    continue
                 lane.wait(ev)
                 tail = []                      # the ring backward's last dK/dV hop, left pending (ring/utils.py:travel_dkdv)
                 dqi, dki, dvi = bwd(ring_pg, doi, qi, ki, vi, oi, lse_i, softmax_scale=softmax_scale,

@@ -187,6 +187,9 @@ def _main_worker(rank, ws):
         assert set(line["comm_modes_ms_per_step"]) == {"safe", "overlapped", "relayed"}
         assert line["config"]["comm_mode"].startswith(("safe", "overlapped"))
         assert line["ms_per_step"] == min(line["comm_modes_ms_per_step"].values())
+    elif ws == 2:     # ulysses 2, ring degree 1: the default, then the self-chunk start under a deadline; the faster is the line
+        assert set(line["comm_modes_ms_per_step"]) == {"default", "self_chunk_start"}
+        assert line["ms_per_step"] == min(line["comm_modes_ms_per_step"].values())
     else:
         assert "comm_modes_ms_per_step" not in line
     return True

@@ -189,6 +189,65 @@ def _async_worker(rank, ws, ud, rd, impl, Hq, Hkv):
     return same and right
 
 
+def _self_chunk_worker(rank, ws, impl, Hq, Hkv, B, S):
+    """USP_SELF_CHUNK=1 (hybrid/async_attn_layer.py:self_chunk_mode): on the 2-GPU grid (ulysses 2, ring degree 1) the first
+    head group starts on the rows the rank already holds -- two or three launches joined by the fused LSE merge / fp32 dK, dV
+    accumulation instead of one causal block.  Against the unsplit schedule (same sums in another order: tight) and against
+    exact attention and its gradients; the launches the test backend sees must START before the exchange is waited for."""
+    import yunchang_amd as Y
+    import yunchang_amd.hybrid.async_attn_layer as AL
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    from oracle import usp_oracle as O
+    set_block_backend(OracleBlockBackend())
+    Y.set_seq_parallel_pg(2, 1, rank, ws)
+    AL._FILL_ITEMS = 1
+    torch.manual_seed(1)
+    D = 32
+    q, k, v, do = (torch.randn(B, S, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
+    ext = Y.EXTRACT_FUNC_DICT[impl]
+    qn, kn, vn, don = (t.float().numpy().astype(np.float64) for t in (q, k, v, do))
+    ro, rl = O.attention_ref(qn, kn, vn, causal=True)
+    truth = [ext(torch.from_numpy(np.ascontiguousarray(t)), rank, world_size=ws, rd=1, ud=2).float()
+             for t in (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, True))]
+    res, order = [], []
+    real_wait = AL._Lane.wait
+    real_split = AL._split_first_forward
+    AL._Lane.wait = lambda self, ev: (order.append("wait"), real_wait(self, ev))[1]
+
+    def spy(be, u, selfs, full, wait, scale):
+        order.append("split-forward")
+        return real_split(be, u, selfs, full, wait, scale)
+    AL._split_first_forward = spy
+    try:
+        for on in (False, True):
+            AL._COMM_OVERRIDE["self_chunk"] = "1" if on else "0"
+            lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=1, ud=2).detach().clone() for t in (q, k, v, do))
+            for t in (lq, lk, lv):
+                t.requires_grad_(True)
+            order.clear()
+            out = Y.LongContextAttention(ring_impl_type=impl)(lq, lk, lv, causal=True)
+            fwd_order = list(order)
+            out.backward(ldo)
+            res.append([t.detach().float() for t in (out, lq.grad, lk.grad, lv.grad)])
+            if on:      # the split forward is entered BEFORE the first wait for an exchange
+                assert fwd_order and fwd_order[0] == "split-forward" and "wait" in fwd_order[1:], fwd_order
+            else:
+                assert "split-forward" not in fwd_order
+    finally:
+        AL._COMM_OVERRIDE.pop("self_chunk", None)
+        AL._Lane.wait = real_wait
+        AL._split_first_forward = real_split
+    close = all(torch.allclose(a, b, atol=tol, rtol=tol) for a, b, tol in zip(res[0], res[1], (8e-3, 3e-2, 3e-2, 3e-2)))
+    right = all(torch.allclose(a, t, atol=tol, rtol=tol) for a, t, tol in zip(res[1], truth, (2e-2, 5e-2, 5e-2, 5e-2)))
+    return close and right
+
+
+@pytest.mark.parametrize("impl,Hq,Hkv,B,S", [("basic", 4, 4, 1, 64), ("basic", 8, 2, 2, 96), ("zigzag", 4, 2, 1, 128)])
+def test_self_chunk_start_on_the_two_gpu_grid(impl, Hq, Hkv, B, S):
+    assert all(run_distributed(_self_chunk_worker, 2, impl, Hq, Hkv, B, S))
+
+
 @pytest.mark.parametrize("ws,ud,rd,impl,Hq,Hkv", [(4, 2, 2, "zigzag", 8, 4), (2, 2, 1, "basic", 4, 4),
                                                   (4, 4, 1, "basic", 16, 8), (4, 2, 2, "basic", 4, 4),
                                                   (4, 1, 4, "zigzag", 4, 2),      # ring 4: two-wave mesh fetch, B = 2

@@ -84,7 +84,7 @@ def _usp_gpu_worker(rank, ws, path, pipelined=False):
     return res
 
 
-def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D):
+def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D, self_chunk=False):
     """No fixture has batch > 1 on a ulysses x ring grid: exact attention (fp64 oracle) on the unsharded
     tensors is the reference here.  Batch 2 is what gives the seq-major views the exchange hands the ring a
     real batch stride (the P > 1 gradient cast used to reject them)."""
@@ -93,11 +93,17 @@ def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D):
     from oracle import usp_oracle as O
     _order_p2p_like_rccl()
     AL._FILL_ITEMS = 1
+    calls = []
+    if self_chunk:
+        AL._COMM_OVERRIDE["self_chunk"] = "1"
+        real_f, real_b = AL._split_first_forward, AL._split_first_backward
+        AL._split_first_forward = lambda *a: (calls.append("f"), real_f(*a))[1]
+        AL._split_first_backward = lambda *a: (calls.append("b"), real_b(*a))[1]
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     Y.set_seq_parallel_pg(ud, rd, rank, ws)
     torch.manual_seed(0)
-    B, S = 2, 64 * ws
+    B, S = 2, (64 if not self_chunk else 333 * 2) * ws
     q, k, v, do = (torch.randn(B, S, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
     ext = Y.EXTRACT_FUNC_DICT[impl]
     qn, kn, vn, don = (t.float().numpy().astype(np.float64) for t in (q, k, v, do))
@@ -111,6 +117,7 @@ def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D):
     out.backward(ldo)
     torch.cuda.synchronize()
     got = [t.detach().float().cpu().numpy() for t in (out, lq.grad, lk.grad, lv.grad)]
+    assert calls == (["f", "b"] if self_chunk else []), calls          # the split path ran (forward and backward), or did not
     return got, truth
 
 
@@ -175,6 +182,17 @@ def test_batch2_on_a_ulysses_x_ring_grid(gloo_cuda, ws, ud, rd, impl, Hq, Hkv, D
     for got, truth in run_distributed(_batch2_worker, ws, ud, rd, impl, Hq, Hkv, D):
         for a, t, key in zip(got, truth, ("out", "dq", "dk", "dv")):
             assert_close(a, t, *TOL["bfloat16"]["out" if key == "out" else "grad"], f"B=2 {impl} {key}")
+
+
+@pytest.mark.parametrize("impl,Hq,Hkv,D", [("basic", 8, 2, 128), ("zigzag", 4, 4, 128), ("basic", 4, 4, 64)])
+def test_self_chunk_start_two_processes_one_gpu(gloo_cuda, impl, Hq, Hkv, D):
+    """USP_SELF_CHUNK=1 on the 2-GPU grid with the HIP kernels (two processes sharing the GPU): the first head group's block as
+    two / three launches on views of the send and receive buffers (odd row counts: 666 rows per rank, the split at 666; merge-in
+    with a partial final range on rank 1; fp32 dK / dV accumulated across the launches; GQA workspace path), batch 2, against
+    exact attention and its gradients."""
+    for got, truth in run_distributed(_batch2_worker, 2, 2, 1, impl, Hq, Hkv, D, True):
+        for a, t, key in zip(got, truth, ("out", "dq", "dk", "dv")):
+            assert_close(a, t, *TOL["bfloat16"]["out" if key == "out" else "grad"], f"self-chunk {impl} {key}")
 
 
 def _varlen_gpu_worker(rank, ws, path):

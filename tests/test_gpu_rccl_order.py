@@ -255,10 +255,10 @@ def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch,
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize("n_gpus,relay,harness", [(8, False, "barrier"), (4, False, "barrier"), (2, False, "barrier"),
                                                   (8, True, "barrier"), (8, False, "pairwise"), (4, False, "pairwise"),
-                                                  (-4, False, "barrier"), (-2, False, "barrier")],
+                                                  (-4, False, "barrier"), (-2, False, "barrier"), (-2, False, "barrier-selfchunk")],
                          ids=["configs4_8gpu_u2r4_gqa_fwd_bwd", "configs3_4gpu_r4_fwd", "configs2_2gpu_u2_fwd",
                               "configs4_8gpu_relayed_pair_exchange", "configs4_8gpu_drifting_ranks", "configs3_4gpu_drifting_ranks",
-                              "bench_4gpu_r4_64k_gqa_fwd_bwd", "bench_2gpu_u2_64k_gqa_fwd_bwd"])
+                              "bench_4gpu_r4_64k_gqa_fwd_bwd", "bench_2gpu_u2_64k_gqa_fwd_bwd", "bench_2gpu_u2_64k_self_chunk_start"])
 def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatch, n_gpus, relay, harness):
     """BASELINE's multi-GPU configs AT THEIR OWN SIZE with the ranks as virtual ranks of one GPU -- configs[4]: 8 ranks,
     ulysses 2 x ring 4, zigzag, B1 S65536 H32/Hkv4 D128 bf16 causal, forward + backward; configs[3]: 4 ranks, ring 4
@@ -299,8 +299,14 @@ def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatc
     loc = [[ext(t, r).contiguous() for t in (q, k, v, do)] for r in range(ws)]
     from virtual_grid import VirtualGridPairwise
     # "pairwise": no host rendezvous of a group at its collectives, random host delays -- the ranks drift apart (virtual_grid.py)
-    grid = _VirtualGrid(ud, rd, nccl_single) if harness == "barrier" else VirtualGridPairwise(ud, rd, nccl_single, jitter=(5, 0.004))
+    grid = _VirtualGrid(ud, rd, nccl_single) if harness.startswith("barrier") else VirtualGridPairwise(ud, rd, nccl_single, jitter=(5, 0.004))
     AL = patch_dist(monkeypatch, grid)
+    split_calls = []
+    if harness.endswith("selfchunk"):            # USP_SELF_CHUNK=1: the first head group starts on the rank's own rows
+        monkeypatch.setitem(AL._COMM_OVERRIDE, "self_chunk", "1")
+        real_f, real_b = AL._split_first_forward, AL._split_first_backward
+        monkeypatch.setattr(AL, "_split_first_forward", lambda *a: (split_calls.append("f"), real_f(*a))[1])
+        monkeypatch.setattr(AL, "_split_first_backward", lambda *a: (split_calls.append("b"), real_b(*a))[1])
     import yunchang_amd.comm.relay_exchange as RX
     monkeypatch.setitem(RX._OVERRIDE, "relay", relay)         # (8 ranks: every pair exchange striped over the 6 other ranks)
     streams = [torch.cuda.Stream(device=dev) for _ in range(ws)]
@@ -325,6 +331,8 @@ def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatc
 
     res = run_grid(grid, ws, rank_fn)
     torch.cuda.synchronize()
+    if harness.endswith("selfchunk"):
+        assert sorted(split_calls) == ["b"] * ws + ["f"] * ws, split_calls            # every rank took the split path, both passes
     if not metric:
         assert {n for _, n in res} == {{8: 2, 4: 1, 2: 4}[n_gpus]}        # head groups per rank: the default pipeline
     kinds = {"ulysses", "ring"} - ({"ulysses"} if ud == 1 else set()) - ({"ring"} if rd == 1 else set())

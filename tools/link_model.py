@@ -45,6 +45,11 @@ def round5(ms):
         print("   N=2  2x1, %d head group(s): exchanges %.2f + %.2f + %.2f + %.2f ms over ONE link, compute %.1f ms -> %.1f ms per iteration = %5.0f "
               "TFLOP/s on 2 GPUs, overlap %.2f" % (ng, ex["fi"], ex["fo"], ex["bi"], ex["bo"], c, tot, F / tot * 1e3,
                                                  1 - (tot - c) / sum(ex.values())))
+    # ... with the self-chunk start (USP_SELF_CHUNK=1, built in round 5 for this grid: the first group's kernels start on the rank's
+    # own rows, the first exchange of each pass runs beside them; compute-only cost of the split: none, profiles/r05_self_chunk.txt)
+    tot = comp + ex["fo"] / 2 + ex["bo"] / 2
+    print("   N=2  2x1, 2 head groups + self-chunk start: first-in exchanges hidden, last-out %.2f + %.2f ms exposed -> %.1f ms per iteration = %5.0f "
+          "TFLOP/s on 2 GPUs, overlap %.2f" % (ex["fo"] / 2, ex["bo"] / 2, tot, F / tot * 1e3, 1 - (tot - comp) / sum(ex.values())))
     # N = 4, ring 4 zigzag: K / V of a peer 2 x 16 MiB (forward and again in the backward: three links in parallel); the travelling
     # fp32 dK + dV 64 MiB per hop, every hop but the last beside a step's kernels (5.6 ms), the last one rounded (32 MiB)
     comp, kv, hop = 29.54, ms(32 * MiB), ms(64 * MiB)

@@ -128,7 +128,18 @@ LD_LIBRARY_PATH=$lib timeout 120 $K bwd 1 65536 65536 32 4 128 1 0 0 2 2>&1 | gr
 done; done
 }
 
+# round 5: the self-chunk start of the first head group on the 2-GPU grid: two processes sharing the GPU (HIP kernels), the N = 2
+# bench workload at full size on the virtual grid through real RCCL, and the compute-only cost of the split (rank emulation)
+run13_self_chunk() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05
+timeout 900 python -m pytest tests/test_gpu_multiproc.py -q -x -k "self_chunk" 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_rccl_order.py -q -x -k "bench_2gpu" -rP 2>&1 | grep -E "passed|failed|max abs errors|Error" | tail -6
+for env in USP_SELF_CHUNK=0 USP_SELF_CHUNK=1; do
+  timeout 200 python tools/rank_emulation.py --gpus 2 --iters 4 --env $env 2>&1 | grep -A1 "^configs" | tail -1
+done
+}
+
 case "$1" in
-  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier) "$1" ;;
-  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier}"; exit 64 ;;
+  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk) "$1" ;;
+  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk}"; exit 64 ;;
 esac
