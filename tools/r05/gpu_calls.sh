@@ -139,7 +139,21 @@ for env in USP_SELF_CHUNK=0 USP_SELF_CHUNK=1; do
 done
 }
 
+# round 5, final tree: the whole GPU suite, larger seeded sweeps (forced 4x64 forward 600 seeds, dense 300, packed 100, backward
+# family 200), and the driver's N = 1 command twice
+run14_final() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05
+( time timeout 2400 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 ) > gpurun_out/r05/14_pytest_gpu.log 2>&1
+tail -6 gpurun_out/r05/14_pytest_gpu.log
+( time USP_FUZZ_ROW64_FWD=600 USP_FUZZ_DENSE=300 USP_FUZZ_PACKED=100 USP_FUZZ_ROW64=200 timeout 2400 python -m pytest tests/test_gpu_row64.py tests/test_gpu_fuzz.py -q -x -n 4 2>&1 | tail -6 ) > gpurun_out/r05/14_fuzz.log 2>&1
+tail -5 gpurun_out/r05/14_fuzz.log
+for i in 1 2; do
+  python bench.py --gpus 1 --steps 20 --warmup 5 2> gpurun_out/r05/14_bench_$i.err | grep -E "^\{" > gpurun_out/r05/14_bench_$i.json
+  python -c "import json; d=json.load(open('gpurun_out/r05/14_bench_$i.json')); r=d['roofline']; print(d['value'], d['ms_per_step'], r['frac'], r['step']['fwd_ms'], r['step']['dkdv_ms'], r['step']['dq_ms'], r['layer_step_ms_by_kernel_family'], r['mfma_ceiling']['sustained_ceiling_TFLOPs'], (r['traffic'] or {}).get('read_MB'))"
+done
+}
+
 case "$1" in
-  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk) "$1" ;;
-  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk}"; exit 64 ;;
+  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final) "$1" ;;
+  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final}"; exit 64 ;;
 esac
