@@ -705,10 +705,13 @@ static int launch_fwd(const FwdArgsT<true>& p, bool causal, hipStream_t st, int 
     const int64_t grid8 = (int64_t)p.B * p.Hq * ((p.Sq + 255) / 256) * p.ksplit;
     // short causal sequences: less diagonal waste (dense only: in packed mode twice the items cost more to fetch)
     // beside a transfer (interleave) RCCL's resident workgroups take a few CUs: with ONE 256-row item per CU a lost
-    // CU costs a whole extra round, so halve the granularity there (kbench overlap, 8 resident copy workgroups:
-    // 256 items 0.695 vs 0.718 ms).  From two items per CU on the 256-row shape wins again, alone (+4...8 %) and
-    // beside the copies (512 items: 2.054 vs 2.084 ms) -- profiles/r02_rank_emulation.txt
-    waves = (grid8 < 256 || (p.interleave && grid8 < 512) || (!p.seq_q && causal && p.Sq <= 1024)) ? 4 : 8;
+    // CU costs a whole extra round, so the 8-wave kernel halves its granularity there (kbench overlap, 8 resident copy
+    // workgroups: 256 items 0.695 vs 0.718 ms; from two items per CU on the 256-row shape wins again, profiles/
+    // r02_rank_emulation.txt).  That rule predates the 4 x 64 kernel, which beats the 128-row shape at one item per CU too,
+    // alone and beside the copies (round 5, same harness, four launches + 3 x 16 MiB on 8 workgroups: 8192 x 16384 rows x
+    // keys, 8 heads = 256 items 1.985 vs 2.081 ms; 8192 x 49152: 5.413 vs 5.773 ms; profiles/r05_fwd_small_interleave.txt):
+    // where the 4 x 64 kernel serves the launch the rule no longer applies.
+    waves = (grid8 < 256 || (p.interleave && grid8 < 512 && !fwd64_ok) || (!p.seq_q && causal && p.Sq <= 1024)) ? 4 : 8;
     // where the 256-row item wins, the one-wave-per-SIMD kernel (4 waves x 64 rows, usp_flash_fwd64.hip) serves it
     if (waves == 8 && fwd64_ok && !(force & USP_FORCE_WAVE32)) waves = 64;
   }

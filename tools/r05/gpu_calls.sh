@@ -153,7 +153,38 @@ for i in 1 2; do
 done
 }
 
+# round 5: where one rank's compute-only iteration of the 8-GPU config goes (kernel trace of tools/rank_emulation.py)
+run15_rank_trace() {
+export TMPDIR=/tmp; cd /tmp; R=$GRAFT_REPO_ROOT
+for mode in auto 0; do
+  rocprofv3 --kernel-trace --stats -d /tmp/emu_$mode -o x -- python $R/tools/rank_emulation.py --gpus 8 --iters 5 --env USP_PIPELINE_ULYSSES=$mode > /tmp/emu_$mode.log 2>&1
+  grep "per iteration" /tmp/emu_$mode.log | cut -c1-140
+  python3 - <<PY
+import sqlite3,glob
+db=glob.glob('/tmp/emu_$mode/**/*_results.db',recursive=True)[0]
+c=sqlite3.connect(db)
+rows=c.execute("select name,total_calls,total_duration,average from top_kernels").fetchall()
+tot=sum(r[2] for r in rows)
+print("mode $mode: total kernel time %.1f ms over 8 iterations (3 warm + 5) = %.2f ms per iteration" % (tot/1e3, tot/8e3))
+for n,calls,t,avg in rows[:16]:
+    print("   %-70s calls %5d  total %9.1f us  avg %8.1f  (%.2f ms / iteration)" % (n.replace('void ','')[:70], calls, t, avg, t/8e3))
+PY
+done
+}
+
+# round 5: 256-item interleavable forward launches (the q[c:] half-row steps of a head group at the 8-GPU config) beside resident
+# copy workgroups: the 4-wave 128-row kernel (round 2's heuristic, taken against the 8-wave kernel) against the 4 x 64 kernel
+run16_fwd_small_interleave() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench
+for shape in "8192 16384 8 1" "8192 49152 8 1" "16384 8192 8 1"; do
+  for w in 4 64 8; do
+    echo "== shape (Sq Sk Hq Hkv) $shape   USP_FWD_WAVES=$w"
+    USP_OVL_SHAPE="$shape" USP_FWD_WAVES=$w timeout 120 $K overlap 4 16 8 2>&1 | grep "OVERLAP USP_LAUNCH"
+  done
+done
+}
+
 case "$1" in
-  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final) "$1" ;;
-  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final}"; exit 64 ;;
+  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final|run15_rank_trace|run16_fwd_small_interleave) "$1" ;;
+  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final|run15_rank_trace|run16_fwd_small_interleave}"; exit 64 ;;
 esac
