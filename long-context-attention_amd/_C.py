@@ -337,13 +337,11 @@ def flash_fwd(q, k, v, softmax_scale: float, causal: bool, lse, out=None, acc=No
     out 16-bit / acc fp32 (B,Sq,Hq,D).  All may be strided views (unit dim stride).  `k_splits`: cut the keys of
     every query tile into that many work items (None: fwd_k_splits decides; 0 / 1: off).  `window` = flash-attn's
     window_size (left, right), None / (-1, -1) = none.  `family`: "row64" | "wave32" pins the kernel family of this call
-    (ABI v6; None: set_kernel_family's default, normally "auto"); a forced 64-row call takes no K split."""
+    (ABI v6; None: set_kernel_family's default, normally "auto"); both families serve a K split."""
     _require_cuda(q, k, v, lse, out, acc)
     B, Sq, Hq, D = q.shape
     ff = _family_flag(family)
     n = fwd_k_splits(B, Sq, Hq, causal) if k_splits is None else int(k_splits)
-    if ff == USP_FORCE_ROW64 and k_splits is None:
-        n = 0                                      # the policy's cut is an optimisation; the forced family has none
     a = _fwd_args(q, k, v, softmax_scale, bool(causal), lse, out, acc, bool(merge_in), final_begin, final_end,
                   bool(interleave), n, _window(window), ff)
     L = load()

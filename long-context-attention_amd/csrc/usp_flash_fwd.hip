@@ -644,6 +644,16 @@ __global__ __launch_bounds__(256) void split_merge_kernel(const FwdArgsT<true> p
   }
 }
 
+int launch_split_merge(const FwdArgsT<true>& p, int dtype, int D, hipStream_t st) {
+  // same stream as the cuts: the partials are complete when this starts
+  if (64 % (D / 4) != 0) return USP_EUNSUPPORTED;           // (the D/4 lanes of a row must share a wavefront: D = 64, 128)
+  const int64_t work = (int64_t)p.B * p.Sq * p.Hq * (D / 4);
+  const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+  if (dtype == USP_BF16) hipLaunchKernelGGL((split_merge_kernel<0>), dim3(blocks), dim3(256), 0, st, p, D);
+  else hipLaunchKernelGGL((split_merge_kernel<1>), dim3(blocks), dim3(256), 0, st, p, D);
+  return hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
+}
+
 template <int D, int DT, int NWAVES>
 static int launch_fwd_w(FwdArgsT<true> p, bool causal, hipStream_t st) {
   p.nq = (p.Sq + 32 * NWAVES - 1) / (32 * NWAVES);
@@ -673,13 +683,12 @@ static int launch_fwd_w(FwdArgsT<true> p, bool causal, hipStream_t st) {
     else
       hipLaunchKernelGGL((flash_fwd_kernel<D, DT, false, NWAVES>), dim3(grid), dim3(64 * NWAVES), lds, st, plain);
   }
-  if (p.ksplit > 1) {          // same stream: the partials are complete when this starts
+  if (hipGetLastError() != hipSuccess) return USP_ELAUNCH;
+  if (p.ksplit > 1) {
     static_assert(64 % (D / 4) == 0 && 256 % (D / 4) == 0, "split_merge_kernel: the D/4 lanes of a row must share a wavefront");
-    const int64_t work = (int64_t)p.B * p.Sq * p.Hq * (D / 4);
-    const int blocks = (int)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
-    hipLaunchKernelGGL((split_merge_kernel<DT>), dim3(blocks), dim3(256), 0, st, p, D);
+    return launch_split_merge(p, DT, D, st);
   }
-  return hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
+  return USP_OK;
 }
 
 template <int D, int DT>
@@ -691,11 +700,12 @@ static int launch_fwd(const FwdArgsT<true>& p, bool causal, hipStream_t st, int 
   // include/usp_hip.h) picks the family; per process, USP_FWD_WAVES=4|8|64 forces a shape for A/B runs (64 = the
   // 4 x 64-row kernel of usp_flash_fwd64.hip, where it applies).
   static const int forced_env = [] { const char* e = getenv("USP_FWD_WAVES"); return e ? atoi(e) : 0; }();
-  const bool fwd64_ok = D == 128 && !p.seq_q && p.ksplit <= 1 && !p.win_on;   // what usp_flash_fwd64.hip serves
+  const bool fwd64_ok = D == 128 && !p.seq_q && !p.win_on;   // what usp_flash_fwd64.hip serves (plain and K-split launches)
+  const int split_kind = p.ksplit > 1 ? USP_KIND_FWD_SPLIT_MERGE : 0;
   if (force & USP_FORCE_ROW64) {
     int rc = USP_ELAUNCH;
     if (fwd64_ok && launch_fwd64(p, DT, causal, st, &rc)) {
-      if (rc == USP_OK) launch_kinds_note(USP_KIND_FWD_ROW64);
+      if (rc == USP_OK) launch_kinds_note(USP_KIND_FWD_ROW64 | split_kind);
       return rc;
     }
     return USP_EUNSUPPORTED;
@@ -712,19 +722,25 @@ static int launch_fwd(const FwdArgsT<true>& p, bool causal, hipStream_t st, int 
     // keys, 8 heads = 256 items 1.985 vs 2.081 ms; 8192 x 49152: 5.413 vs 5.773 ms; profiles/r05_fwd_small_interleave.txt):
     // where the 4 x 64 kernel serves the launch the rule no longer applies.
     waves = (grid8 < 256 || (p.interleave && grid8 < 512 && !fwd64_ok) || (!p.seq_q && causal && p.Sq <= 1024)) ? 4 : 8;
-    // where the 256-row item wins, the one-wave-per-SIMD kernel (4 waves x 64 rows, usp_flash_fwd64.hip) serves it
-    if (waves == 8 && fwd64_ok && !(force & USP_FORCE_WAVE32)) waves = 64;
+    // where the 256-row item wins, the one-wave-per-SIMD kernel (4 waves x 64 rows, usp_flash_fwd64.hip) serves it.  Cut
+    // launches: a 64-row item costs more to open and close (64 Q fragments parked, 128 accumulators written as partials),
+    // which pays from ~96 tiles per cut on (kbench ksplit, 8-wave split -> 4 x 64 split, merge launch included, round 5:
+    // S = 65536 1 head n = 2 1174 -> 1216 TFLOP/s, 32768 2 heads n = 2 1136 -> 1162 and n = 3 1051 -> 1064, 16384 4 heads
+    // n = 2 1049 -> 1057; below: 16384 4 heads n = 3 963 -> 945, n = 4 984 -> 957, 8192 6 heads n = 2 799 -> 780;
+    // profiles/r05_fwd64_ksplit.txt)
+    const bool long_cuts = p.ksplit <= 1 || (int64_t)p.Sk >= (int64_t)96 * kBN * p.ksplit;
+    if (waves == 8 && fwd64_ok && long_cuts && !(force & USP_FORCE_WAVE32)) waves = 64;
   }
   if (waves == 64) {
     int rc = USP_ELAUNCH;
     if (fwd64_ok && launch_fwd64(p, DT, causal, st, &rc)) {
-      if (rc == USP_OK) launch_kinds_note(USP_KIND_FWD_ROW64);
+      if (rc == USP_OK) launch_kinds_note(USP_KIND_FWD_ROW64 | split_kind);
       return rc;
     }
     waves = 8;
   }
   const int rc = waves == 4 ? launch_fwd_w<D, DT, 4>(p, causal, st) : launch_fwd_w<D, DT, 8>(p, causal, st);
-  if (rc == USP_OK) launch_kinds_note((waves == 4 ? USP_KIND_FWD_WAVE4 : USP_KIND_FWD_WAVE8) | (p.ksplit > 1 ? USP_KIND_FWD_SPLIT_MERGE : 0));
+  if (rc == USP_OK) launch_kinds_note((waves == 4 ? USP_KIND_FWD_WAVE4 : USP_KIND_FWD_WAVE8) | split_kind);
   return rc;
 }
 

@@ -1,8 +1,8 @@
 // Blockwise flash-attention forward for gfx950, ONE WAVE PER SIMD: a workgroup is 4 waves x 64 query rows (256 rows of
 // one (batch, head), KV tile = 64 keys), every wave owns its SIMD's whole 512-entry register file.
 // Same C ABI entry (usp_flash_fwd, include/usp_hip.h), same LDS images, same numerics, same epilogue (fused ring LSE
-// merge) as the 8-wave kernel of usp_flash_fwd.hip, which stays the kernel of the packed / K-split / windowed / small
-// launches.  Replaces the reference's `fwd-only` block kernel (yunchang/kernels/attention.py:44-136) and
+// merge) as the 8-wave kernel of usp_flash_fwd.hip, which stays the kernel of the packed / windowed / small launches and of
+// K splits with short cuts (round 5: long cuts run here, see SPLIT below).  Replaces the reference's `fwd-only` block kernel (yunchang/kernels/attention.py:44-136) and
 // update_out_and_lse (yunchang/ring/utils.py:10-51).
 //
 // Why this shape (profiles/r03_bwd_ablations.txt, tools/issue_bench.hip): with two 32-row waves per SIMD every MFMA
@@ -47,8 +47,13 @@ constexpr int kF64_DMAS = 6;    // goes out, and the distance to the next one
 #define USP_TM(...)
 #endif
 
-template <int DT, bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<false> /* read through the kernarg segment */) {
+// SPLIT: the K-split form (usp_fwd_args.k_splits > 1) is its own instantiation with its own argument block (FwdParams +
+// FwdSplit), as in usp_flash_fwd.hip: the plain kernels keep the machine code they were profiled with.  A work item is then
+// one CUT of a query tile's keys, bound by rebasing the K / V cursors, the key count and the causal offset (the tile loops
+// are untouched); it writes its normalised fp32 partial and its LSE to the workspace through the not-final epilogue, and
+// split_merge_kernel (usp_flash_fwd.hip) combines the cuts, the running result and the 16-bit emission afterwards.
+template <int DT, bool CAUSAL, bool SPLIT = false>
+__global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<SPLIT> /* read through the kernarg segment */) {
   using E = Elem<DT>;
   using M = M64<DT>;
   constexpr int D = 128;
@@ -72,7 +77,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   // register only around its uses.  Held in SGPRs for the whole persistent loop the block alone fills the scalar file,
   // and the pipelined loop then reloads its loop invariants from spill lanes (v_readlane + 5 wait states in front of
   // every LDS-DMA that takes one as its scalar offset).
-  typedef const __attribute__((address_space(4))) FwdParams* KArgs;
+  typedef const __attribute__((address_space(4))) FwdArgsT<SPLIT>* KArgs;
   KArgs p = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(p));
 
@@ -99,7 +104,13 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
   int w = walk.at(pass);
   if (w < 0) break;
   asm volatile("" : "+s"(p));
-  w = walk.dealt(w, p->nq);
+  int ks = 0;                                             // (split form) the cut of the query tile's keys this item is
+  if constexpr (SPLIT) {
+    w = walk.dealt(w, p->nq * p->ksplit);                 // the cuts of a tile are dealt like tiles
+    ks = w % p->ksplit; w /= p->ksplit;
+  } else {
+    w = walk.dealt(w, p->nq);
+  }
   const int qt_r = w % p->nq;
   int rest = w / p->nq;
   const int qt = CAUSAL ? (p->nq - 1 - qt_r) : qt_r;      // heavy (late) tiles first
@@ -111,19 +122,35 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<fals
 
   const int q0 = qt * kBM;
   const int qw = q0 + wave * 64;                          // first row of this wave
-  const int off = p->causal_off;
+  int off = p->causal_off;
+  // (split form) first key of the cut and the number of keys in it: the item sees keys [kb, kb + sk_cut) as keys [0, sk_cut)
+  int kb = 0, sk_cut = 0;
+  if constexpr (SPLIT) {
+    int e = p->Sk;                                        // keys any row of the 256-row tile sees
+    if (CAUSAL) {
+      const int lim = (q0 + kBM < p->Sq ? q0 + kBM : p->Sq) + off;
+      e = lim < e ? lim : e;
+    }
+    const int nt_all = e > 0 ? (e + kBN - 1) / kBN : 0;
+    kb = (ks * nt_all / p->ksplit) * kBN;
+    int ke = (ks == p->ksplit - 1) ? p->Sk : ((ks + 1) * nt_all / p->ksplit) * kBN;
+    ke = ke < p->Sk ? ke : p->Sk;
+    sk_cut = ke > kb ? ke - kb : 0;
+    off -= kb;
+  }
+  auto n_keys = [&]() { if constexpr (SPLIT) return sk_cut; else return p->Sk; };
 
   // ---- KV range -------------------------------------------------------------------------------------------------------
-  int blk_kv_end = p->Sk, wave_kv_end = p->Sk;
+  int blk_kv_end = n_keys(), wave_kv_end = n_keys();
   if (CAUSAL) {
     const int blk_last = (q0 + kBM < p->Sq ? q0 + kBM : p->Sq) - 1;
     const int wav_last = (qw + 64 < p->Sq ? qw + 64 : p->Sq) - 1;
-    blk_kv_end = blk_last + off + 1 < p->Sk ? blk_last + off + 1 : p->Sk;
-    wave_kv_end = wav_last + off + 1 < p->Sk ? wav_last + off + 1 : p->Sk;
+    blk_kv_end = blk_last + off + 1 < n_keys() ? blk_last + off + 1 : n_keys();
+    wave_kv_end = wav_last + off + 1 < n_keys() ? wav_last + off + 1 : n_keys();
   }
   if (qw >= p->Sq) wave_kv_end = 0;
   const int nt = blk_kv_end > 0 ? (blk_kv_end + kBN - 1) / kBN : 0;
-  int n_full = p->Sk / kBN;                                 // leading tiles that need no mask for this wave
+  int n_full = n_keys() / kBN;                              // leading tiles that need no mask for this wave
   if (CAUSAL) {
     const int lim = qw + off + 1;                          // keys < lim are visible to EVERY row of the wave
     const int nf = lim > 0 ? lim / kBN : 0;
@@ -158,7 +185,8 @@ USP_TM(
   const int64_t k_tb = (int64_t)kBN * p->k_ss * 2, v_tb = (int64_t)kBN * p->v_ss * 2;   // bytes per tile step
   const char* k_cur = p->k + 2 * (b * p->k_sb + hkv * p->k_sh);
   const char* v_cur = p->v + 2 * (b * p->v_sb + hkv * p->v_sh);
-  int rows_kv = p->Sk;                                       // valid rows from the cursors on (<= 0: lanes read 0)
+  if constexpr (SPLIT) { k_cur += 2 * (int64_t)kb * p->k_ss; v_cur += 2 * (int64_t)kb * p->v_ss; }
+  int rows_kv = n_keys();                                    // valid rows from the cursors on (<= 0: lanes read 0)
   const int k_rowb = (int)p->k_ss * 2, v_rowb = (int)p->v_ss * 2;
   // (lds_w / k_step / v_step pass through an opaque asm at every use: hipcc otherwise hoists the sixteen M0 values and the
   // six scalar offsets of the pieces out of the loops as invariants and then SPILLS them -- a v_readlane plus five wait
@@ -227,7 +255,7 @@ USP_TM(
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
       const int row = qw + 32 * qb + l31;
-      int klim = p->Sk - 1;
+      int klim = n_keys() - 1;
       if (CAUSAL) klim = row + off < klim ? row + off : klim;
       const int kb0 = kt0 + 4 * hi;
 #pragma unroll
@@ -484,6 +512,9 @@ USP_TM(
     const float blk_lse = empty ? USP_NEG_INF : (m_run[qb] * c + log2f(l_tot)) * kLn2;
     float w_blk = inv, w_old = 0.f, new_lse = blk_lse;
     float* lse_p = p->lse + b * p->lse_sb + h * p->lse_sh + row;
+    // (split form) launch_fwd64 has pointed acc / lse at cut 0 of the workspace ([ksplit][B,Sq,Hq,D] fp32 rows and
+    // [ksplit][B,Hq,Sq] LSEs), never final, never merged here -- split_merge_kernel does both
+    if constexpr (SPLIT) lse_p += (int64_t)ks * p->B * p->Hq * p->Sq;
     const bool valid = row < p->Sq;
     const bool fin = row >= p->final_begin && row < p->final_end;
     // single-pass call whose 32 rows are all final and 16-byte aligned: straight-line widened stores
@@ -504,7 +535,8 @@ USP_TM(
         }
       }
       if (hi == 0) *lse_p = new_lse;
-      const int64_t arow = b * p->a_sb + (int64_t)row * p->a_ss + h * p->a_sh;
+      int64_t arow = b * p->a_sb + (int64_t)row * p->a_ss + h * p->a_sh;
+      if constexpr (SPLIT) arow += (int64_t)ks * p->B * p->Sq * p->Hq * D;
       const int64_t orow = b * p->o_sb + (int64_t)row * p->o_ss + h * p->o_sh;
       if (wide) {
         // each row is split across the two half-waves in 8-byte pieces; one v_permlane32_swap per dword regroups two
@@ -559,7 +591,18 @@ USP_TM(
   }  // next item
 }
 
-bool launch_fwd64(const FwdParams& p_in, int dtype, bool causal, hipStream_t st, int* rc) {
+template <bool SPLIT>
+static void launch64(const FwdArgsT<SPLIT>& p, int grid, size_t lds, int dtype, bool causal, hipStream_t st) {
+  if (dtype == USP_BF16) {
+    if (causal) hipLaunchKernelGGL((flash_fwd64_kernel<0, true, SPLIT>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((flash_fwd64_kernel<0, false, SPLIT>), dim3(grid), dim3(256), lds, st, p);
+  } else {
+    if (causal) hipLaunchKernelGGL((flash_fwd64_kernel<1, true, SPLIT>), dim3(grid), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((flash_fwd64_kernel<1, false, SPLIT>), dim3(grid), dim3(256), lds, st, p);
+  }
+}
+
+bool launch_fwd64(const FwdArgsT<true>& p_in, int dtype, bool causal, hipStream_t st, int* rc) {
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -570,19 +613,29 @@ bool launch_fwd64(const FwdParams& p_in, int dtype, bool causal, hipStream_t st,
   // the K pieces' swizzle is XORed into the per-lane byte offset (row part a multiple of 256 bytes); per-lane offsets and the
   // pieces' scalar offsets are 32-bit: 64 rows of K / V must span less than 2^31 bytes
   if ((p_in.k_ss * 2) % 256 != 0 || p_in.k_ss * 128 >= (1LL << 31) || p_in.v_ss * 128 >= (1LL << 31)) return false;
+  if (p_in.win_on || p_in.seq_q) return false;
+  const size_t lds = 2 * 2 * kBN * 128 * 2;
+  if (p_in.ksplit > 1) {
+    FwdArgsT<true> p = p_in;
+    p.nq = (p.Sq + 255) / 256;
+    p.n_items = p.B * p.Hq * p.nq * p.ksplit;
+    const int grid = (!p.interleave && p.n_items > cus) ? cus : p.n_items;
+    // the cuts write partials: the epilogue's fp32 destination is cut 0 of the workspace (the kernel adds the cut)
+    p.acc = p.ws_o;
+    p.a_sb = (int64_t)p.Sq * p.Hq * 128; p.a_ss = (int64_t)p.Hq * 128; p.a_sh = 128;
+    p.lse = p.ws_lse;
+    p.lse_sb = (int64_t)p.Hq * p.Sq; p.lse_sh = p.Sq;
+    p.merge_in = 0; p.final_begin = 0; p.final_end = 0; p.out_wide = 0;
+    launch64<true>(p, grid, lds, dtype, causal, st);
+    *rc = hipGetLastError() == hipSuccess ? launch_split_merge(p_in, dtype, 128, st) : USP_ELAUNCH;
+    return true;
+  }
   FwdArgsT<false> p;
   static_cast<FwdParams&>(p) = p_in;
   p.nq = (p.Sq + 255) / 256;
   p.n_items = p.B * p.Hq * p.nq;
   const int grid = (!p.interleave && p.n_items > cus) ? cus : p.n_items;      // persistent: one workgroup per CU
-  const size_t lds = 2 * 2 * kBN * 128 * 2;
-  if (dtype == USP_BF16) {
-    if (causal) hipLaunchKernelGGL((flash_fwd64_kernel<0, true>), dim3(grid), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((flash_fwd64_kernel<0, false>), dim3(grid), dim3(256), lds, st, p);
-  } else {
-    if (causal) hipLaunchKernelGGL((flash_fwd64_kernel<1, true>), dim3(grid), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((flash_fwd64_kernel<1, false>), dim3(grid), dim3(256), lds, st, p);
-  }
+  launch64<false>(p, grid, lds, dtype, causal, st);
   *rc = hipGetLastError() == hipSuccess ? USP_OK : USP_ELAUNCH;
   return true;
 }

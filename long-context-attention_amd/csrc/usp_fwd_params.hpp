@@ -48,8 +48,10 @@ template <int D> struct KSwz {
   static USP_DEV int of(int row) { return (row / RPB) & (SPR - 1); }
 };
 
-// The 64-rows-per-wave forward (usp_flash_fwd64.hip): dense, plain launches of D = 128 (no K split, no window, no packed
+// The 64-rows-per-wave forward (usp_flash_fwd64.hip): dense launches of D = 128, plain or K-split (no window, no packed
 // batch).  Returns false when the launch is not one it serves (the caller then takes the 8-wave kernel).
-bool launch_fwd64(const FwdParams& p, int dtype, bool causal, hipStream_t st, int* rc);
+bool launch_fwd64(const FwdArgsT<true>& p, int dtype, bool causal, hipStream_t st, int* rc);
+// The merge launch behind a K-split forward (usp_flash_fwd.hip: split_merge_kernel), same stream.
+int launch_split_merge(const FwdArgsT<true>& p, int dtype, int D, hipStream_t st);
 
 }  // namespace usp

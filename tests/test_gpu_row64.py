@@ -83,7 +83,7 @@ def _forward_forced(dev, case, rs, check_wave32=True):
     D = 128
     what = f"row64 fwd B{B} Sq{Sq} Sk{Sk} Hq{Hq} Hkv{Hkv} causal={causal} {dt}"
     q, k, v, do = _inputs(rs, B, Sq, Sk, Hq, Hkv, D, dt)
-    ar = _Arena(dt, dev, [q.shape, k.shape, v.shape, q.shape, q.shape])
+    ar = _Arena(dt, dev, [q.shape, k.shape, v.shape, q.shape, q.shape, q.shape])
     tq, tk, tv = ar.put(q), ar.put(k), ar.put(v)
     scale = D ** -0.5
     ro, rl = O.attention_ref(q, k, v, causal, scale)
@@ -91,7 +91,7 @@ def _forward_forced(dev, case, rs, check_wave32=True):
     for i in range(2):
         out = ar.out((B, Sq, Hq, D))
         lse = torch.full((B, Hq, Sq), float("nan"), dtype=torch.float32, device=dev)
-        _C.flash_fwd(tq, tk, tv, scale, causal, lse, out=out, interleave=i == 1, family="row64")
+        _C.flash_fwd(tq, tk, tv, scale, causal, lse, out=out, interleave=i == 1, family="row64", k_splits=0)
         assert _C.last_launch_kinds() == ("fwd_row64",), (what, _C.last_launch_kinds())
         runs.append((_f(out), _f(lse)))
     assert np.array_equal(runs[0][0], runs[1][0], equal_nan=True) and np.array_equal(runs[0][1], runs[1][1], equal_nan=True), \
@@ -103,6 +103,18 @@ def _forward_forced(dev, case, rs, check_wave32=True):
     assert_close(got_l[fin], rl[fin], 2e-3, 1e-4, what + " lse")
     assert (np.abs(got_o)[~np.broadcast_to(fin.transpose(0, 2, 1)[..., None], ro.shape)] == 0).all(), what + ": empty rows must be 0"
     assert ar.guards_intact(), what + ": a launch wrote outside its tensors"
+    # the same shape with every query tile's keys cut into n work items (the split instantiation + the merge launch)
+    n = int(rs.choice([2, 3, 4, 8]))
+    out = ar.out((B, Sq, Hq, D))
+    lse = torch.full((B, Hq, Sq), float("nan"), dtype=torch.float32, device=dev)
+    _C.flash_fwd(tq, tk, tv, scale, causal, lse, out=out, interleave=bool(rs.randint(2)), family="row64", k_splits=n)
+    assert _C.last_launch_kinds() == ("fwd_row64", "fwd_split_merge"), (what, n, _C.last_launch_kinds())
+    cut_o, cut_l = _f(out), _f(lse)
+    assert (np.isfinite(cut_l) == fin).all(), what + f" k_splits={n}: rows without a visible key must give lse = -inf"
+    assert_close(cut_o, ro, *TOL[dt]["out"], what + f" out, k_splits={n}")
+    assert_close(cut_l[fin], rl[fin], 2e-3, 1e-4, what + f" lse, k_splits={n}")
+    assert (np.abs(cut_o)[~np.broadcast_to(fin.transpose(0, 2, 1)[..., None], ro.shape)] == 0).all(), what + f" k_splits={n}: empty rows must be 0"
+    assert ar.guards_intact(), what + f" k_splits={n}: a launch wrote outside its tensors"
     if check_wave32:
         out8 = torch.empty((B, Sq, Hq, D), dtype=tq.dtype, device=dev)
         lse8 = torch.empty((B, Hq, Sq), dtype=torch.float32, device=dev)
@@ -245,6 +257,22 @@ def test_row64_merge_in_and_partial_final_ranges(dev, Sq, Sk, Sa, causal2, fb, f
     assert_close(a[:, ~fin], ro[:, ~fin], 2e-3, 2e-3, what + " running rows (fp32)")
     assert np.array_equal(a[:, fin], _f(acc1)[:, fin]), what + ": accumulator rows of the final range must not be rewritten"
     assert ar.guards_intact()
+    # the same second call with its keys cut into 3 work items: the cuts go to the workspace, split_merge_kernel merges them
+    # with the running result and emits the same final / running rows
+    out2 = torch.full_like(out, float("nan"))
+    acc2, lse2 = acc1.clone(), torch.full_like(lse, float("nan"))
+    _C.flash_fwd(tq, tk[:, :Sa], tv[:, :Sa], scale, False, lse2, out=None, acc=acc2, final_begin=0, final_end=0, family="row64",
+                 k_splits=0)
+    _C.flash_fwd(tq, tk[:, Sa:], tv[:, Sa:], scale, causal2, lse2, out=out2, acc=acc2, merge_in=True, final_begin=fb, final_end=fe,
+                 family="row64", k_splits=3)
+    assert _C.last_launch_kinds() == ("fwd_row64", "fwd_split_merge")
+    assert_close(_f(lse2), rl, 2e-3, 1e-4, what + " lse (3 cuts)")
+    o2, a2 = _f(out2), _f(acc2)
+    assert_close(o2[:, fin], ro[:, fin], *TOL[dt]["out"], what + " final rows (3 cuts)")
+    assert np.isnan(o2[:, ~fin]).all(), what + " (3 cuts): rows outside the final range must not be written to `out`"
+    assert_close(a2[:, ~fin], ro[:, ~fin], 2e-3, 2e-3, what + " running rows (fp32, 3 cuts)")
+    assert np.array_equal(a2[:, fin], _f(acc1)[:, fin]), what + " (3 cuts): accumulator rows of the final range must not be rewritten"
+    assert ar.guards_intact()
 
 
 @pytest.mark.parametrize("B,Sq,Sk,Hq,Hkv,causal,cuts", [(1, 1024, 1024, 2, 2, True, (2, 2)), (1, 333, 200, 2, 1, True, (3, 4)),
@@ -303,9 +331,10 @@ def test_forced_family_refuses_what_it_does_not_serve(dev):
     out = torch.full_like(q, float("nan"))
     with pytest.raises(RuntimeError, match="unsupported"):
         _C.flash_fwd(q, q, q, 0.09, True, lse, out=out, family="row64", window=(17, 0))
-    with pytest.raises(RuntimeError, match="unsupported"):
-        _C.flash_fwd(q, q, q, 0.09, True, lse, out=out, family="row64", k_splits=2)
     assert torch.isnan(out).all()
+    _C.flash_fwd(q, q, q, 0.09, True, lse, out=out, family="row64", k_splits=2)   # (round 5: the family serves K splits)
+    assert _C.last_launch_kinds() == ("fwd_row64", "fwd_split_merge") and torch.isfinite(out).all()
+    out.fill_(float("nan"))
     _C.flash_fwd(q, q, q, 0.09, True, lse, out=out, family="wave32")
     assert _C.last_launch_kinds() == ("fwd_wave4",) and torch.isfinite(out).all()
     # the in-process default (what bench.py's same-box A/B uses)

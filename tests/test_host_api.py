@@ -420,15 +420,16 @@ def test_host_launch_plumbing_without_a_device():
     assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
     a.k_splits, a.workspace = 9, base + 5 * 0x1000000
     assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
-    # ABI v6: kernel-family selectors.  Both at once: invalid.  A forced 64-row call the family does not serve (K split,
-    # head dim 64) is refused BEFORE any launch; one it serves reaches the launch; nothing was launched: kinds == 0.
+    # ABI v6: kernel-family selectors.  Both at once: invalid.  A forced 64-row call the family does not serve (head dim
+    # 64) is refused BEFORE any launch; one it serves -- since round 5 also a K split -- reaches the launch; nothing was
+    # launched: kinds == 0.
     a.k_splits, a.workspace = 0, None
     a.flags = _C.USP_FORCE_ROW64 | _C.USP_FORCE_WAVE32
     assert L.usp_flash_fwd(ctypes.byref(a), None) == -1
     a.flags = _C.USP_FORCE_ROW64
     assert L.usp_flash_fwd(ctypes.byref(a), None) == -3
     a.k_splits, a.workspace = 2, base + 5 * 0x1000000
-    assert L.usp_flash_fwd(ctypes.byref(a), None) == -2                      # USP_EUNSUPPORTED
+    assert L.usp_flash_fwd(ctypes.byref(a), None) == -3                      # the split instantiation of the 64-row kernel
     a.k_splits, a.workspace, a.D = 0, None, 64
     for i, x in enumerate((a.q, a.k, a.v, a.out)):
         x.stride_b, x.stride_s, x.stride_h = S * H * 64, H * 64, 64

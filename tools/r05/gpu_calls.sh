@@ -184,7 +184,21 @@ for shape in "8192 16384 8 1" "8192 49152 8 1" "16384 8192 8 1"; do
 done
 }
 
+# round 5: the K split through the 4 x 64 forward (split instantiation of flash_fwd64_kernel + split_merge_kernel): parity first,
+# then the same few-head causal launches timed with the 8-wave split kernel (USP_FWD_WAVES=8) and with the library's choice
+run17_fwd64_ksplit() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05; K=$GRAFT_REPO_ROOT/long-context-attention_amd/kbench
+( time USP_FUZZ_ROW64_FWD=300 timeout 1500 python -m pytest tests/test_gpu_row64.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_mutation.py -q -x -n 4 2>&1 | tail -8 ) 2>&1 | tail -12
+timeout 300 $K suite 2>&1 | grep -c "ok$\|OK" ; timeout 300 $K suite 2>&1 | grep -i "fail\|bad [1-9]" | head
+for shape in "1 16384 16384 2 2" "1 16384 16384 4 4" "1 16384 16384 4 1" "1 32768 32768 2 2" "1 8192 8192 6 6" "1 65536 65536 1 1"; do
+  for w in 8 64 0; do
+    echo "== B Sq Sk Hq Hkv $shape  USP_FWD_WAVES=$w (8: the 8-wave split kernel; 64: the 4 x 64 one wherever n x items >= 256; 0: the library's choice)"
+    USP_FWD_WAVES=$w timeout 200 $K ksplit $shape 128 1 0 0 10 2>&1 | grep "^TIME"
+  done
+done
+}
+
 case "$1" in
-  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final|run15_rank_trace|run16_fwd_small_interleave) "$1" ;;
-  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final|run15_rank_trace|run16_fwd_small_interleave}"; exit 64 ;;
+  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final|run15_rank_trace|run16_fwd_small_interleave|run17_fwd64_ksplit) "$1" ;;
+  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final|run15_rank_trace|run16_fwd_small_interleave|run17_fwd64_ksplit}"; exit 64 ;;
 esac
