@@ -990,11 +990,13 @@ def main(argv=None, dev=None):
                 RX._OVERRIDE.clear()
         if line is not None:
             line["comm_modes_ms_per_step"] = modes
-    # The 2-GPU grid (ulysses 2, ring degree 1): the first head group can start on the rows the rank already holds
-    # (USP_SELF_CHUNK=1, hybrid/async_attn_layer.py:self_chunk_mode -- hides the first exchange of each pass; opt-in in the
-    # library because it has never met two devices).  Measured as a second, deadline-guarded mode; the faster one is reported.
-    if cfg["ud"] == 2 and cfg["rd"] == 1 and ws == 2 and "USP_SELF_CHUNK" not in os.environ and not args.async_ulysses:
-        modes = {"default": round(ms, 4)}
+    # Ulysses degree 2 (the 2-GPU grid, and the 8-GPU grid 2 x 4 beside its zigzag ring): the first head group can start on
+    # the rows the rank already holds (USP_SELF_CHUNK=1, hybrid/async_attn_layer.py:self_chunk_mode -- hides the first
+    # exchange of each pass; opt-in in the library because it has never met two devices).  Measured as one more
+    # deadline-guarded mode on top of the fastest so far; the faster one is reported.
+    if (cfg["ud"] == 2 and (cfg["rd"] == 1 or cfg["impl"] == "zigzag") and "USP_SELF_CHUNK" not in os.environ
+            and not args.async_ulysses):
+        modes = modes if two_comms else {"default": round(ms, 4)}
         fallback = _LineOnce(None if line is None else
                              {**line, "comm_modes_ms_per_step": modes,
                               "comm_mode_note": "the self-chunk start (USP_SELF_CHUNK=1) did not finish before its deadline; this is "
@@ -1006,7 +1008,8 @@ def main(argv=None, dev=None):
         modes["self_chunk_start"] = round(ms2, 4)
         if ms2 < ms:
             ms, dms = ms2, dms2
-            line = make_line(ms, dms, "library default + first head group started on the rank's own rows (USP_SELF_CHUNK=1)")
+            line = make_line(ms, dms, ((line["config"]["comm_mode"] if line and two_comms else "library default") +
+                                       " + first head group started on the rank's own rows (USP_SELF_CHUNK=1)"))
         else:
             AL._COMM_OVERRIDE.pop("self_chunk", None)
         if line is not None:

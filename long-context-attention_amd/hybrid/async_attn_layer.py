@@ -125,14 +125,18 @@ def self_chunk_mode(P: int, ring: int, causal, impl: str, rows_local: int) -> bo
     group's kernels start AT ONCE, on views of the send buffer's self chunk, and only the rest of the group waits for the
     exchange (forward: 1/4 resp. 1/4 of the group's work in front of the wait; backward, where K and V are already there and
     only dO travels: 1/4 resp. 3/4).  That hides the one exchange of each pass nothing else can hide -- the first.
-    Built for ring degree 1 (the 2-GPU grid: the ring function there is ONE causal block, split here into two or three
-    launches joined by the kernel's fused LSE merge / fp32 accumulation); beside a ring the same split applies to step 0
-    but the K/V relay then has to start behind the exchange instead of behind the compute stream -- not built.
+    At ring degree 1 (the 2-GPU grid) the ring function is ONE causal block, split here into two or three launches joined
+    by the kernel's fused LSE merge / fp32 accumulation (_split_first_forward / _split_first_backward).  Beside a zigzag
+    ring (the 8-GPU grid: ulysses 2 x ring 4) the same split applies to STEP 0 of the ring schedule -- the exchange
+    delivers exactly one zigzag chunk, rank u = 0 owns the front chunk and u = 1 the back one -- and the ring's K/V
+    transfers, which read the exchanged tensors, are posted behind the wait (ring/zigzag_ring_flash_attn.py: `first`).
     Results equal the unsplit launch up to fp32 summation order (the merge is the ring's own)."""
     mode = _COMM_OVERRIDE.get("self_chunk", os.environ.get("USP_SELF_CHUNK", "0"))
     if str(mode) not in ("1", "True"):
         return False
-    return P == 2 and ring == 1 and bool(causal) and impl in ("basic", "zigzag") and rows_local >= 1
+    if not (P == 2 and bool(causal) and rows_local >= 1):
+        return False
+    return impl in ("basic", "zigzag") if ring == 1 else impl == "zigzag"
 
 
 def _self_views(send, u, splits):
@@ -386,9 +390,13 @@ class _AsyncUSPFunc(torch.autograd.Function):
                 (qi, ki, vi), ev, send_i = ins[i]
                 if split0 and i == 0:
                     from ..kernels.attention import get_block_backend
-                    oi, lse_i = _split_first_forward(get_block_backend(beside_transfers=True), u,
-                                                     _self_views(send_i, u, (kvh * g, kvh, kvh)), (qi, ki, vi),
-                                                     lambda ev=ev: lane.wait(ev), softmax_scale)
+                    own = _self_views(send_i, u, (kvh * g, kvh, kvh))
+                    if ring == 1:
+                        oi, lse_i = _split_first_forward(get_block_backend(beside_transfers=True), u, own, (qi, ki, vi),
+                                                         lambda ev=ev: lane.wait(ev), softmax_scale)
+                    else:        # step 0 of the ring schedule starts on the owned chunk
+                        oi, lse_i = fwd(ring_pg, qi, ki, vi, softmax_scale=softmax_scale, causal=causal, overlap=overlap,
+                                        first=(u, own, lambda ev=ev: lane.wait(ev)))
                     saved += [qi, ki, vi, oi, lse_i]
                     outs.append(_to_heads_issue(lane, [oi], P, ulysses_pg))
                     continue
@@ -403,7 +411,7 @@ class _AsyncUSPFunc(torch.autograd.Function):
                 A.unpack_head_group(recv, o5[:, :, :, i])
         ctx.save_for_backward(*saved)
         ctx.meta = (softmax_scale, causal, ulysses_pg, ring_pg, impl, P, ng, kvh, g, Hq, Hkv)
-        ctx.split0 = (split0, u)
+        ctx.split0 = (split0, u, ring)
         return out
 
     @staticmethod
@@ -416,16 +424,21 @@ class _AsyncUSPFunc(torch.autograd.Function):
         with _Lane(dout) as lane:
             douts = [_to_seq(lane, dout, P, ng, kvh * g, i, ulysses_pg) for i in range(ng)]
             pend = []
-            split0, u = getattr(ctx, "split0", (False, 0))
+            split0, u, ring = getattr(ctx, "split0", (False, 0, 1))
             for i in range(ng):
                 qi, ki, vi, oi, lse_i = saved[5 * i:5 * i + 5]
                 doi, ev, send_i = douts[i]
                 if split0 and i == 0:
                     from ..kernels.attention import get_block_backend
-                    dqi, dki, dvi = _split_first_backward(get_block_backend(beside_transfers=True), u,
-                                                          _self_views(send_i, u, (kvh * g,))[0], doi, lambda ev=ev: lane.wait(ev),
-                                                          qi, ki, vi, oi, lse_i, softmax_scale)
-                    pend.append(_grads_to_heads_issue(lane, dqi, dki, dvi, [], P, ulysses_pg))
+                    do_own = _self_views(send_i, u, (kvh * g,))[0]
+                    tail = []
+                    if ring == 1:
+                        dqi, dki, dvi = _split_first_backward(get_block_backend(beside_transfers=True), u, do_own, doi,
+                                                              lambda ev=ev: lane.wait(ev), qi, ki, vi, oi, lse_i, softmax_scale)
+                    else:
+                        dqi, dki, dvi = bwd(ring_pg, doi, qi, ki, vi, oi, lse_i, softmax_scale=softmax_scale, causal=causal,
+                                            overlap=overlap, tail=tail, first=(u, do_own, lambda ev=ev: lane.wait(ev)))
+                    pend.append(_grads_to_heads_issue(lane, dqi, dki, dvi, tail, P, ulysses_pg))
                     continue
                 lane.wait(ev)
                 tail = []                      # the ring backward's last dK/dV hop, left pending (ring/utils.py:travel_dkdv)

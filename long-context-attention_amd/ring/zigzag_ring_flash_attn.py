@@ -45,6 +45,59 @@ def zigzag_fwd_step(be, r, P, step, q, kk, vv, softmax_scale, lse, out, acc):
                0, c if last else 0)
 
 
+def zigzag_fwd_step0_own(be, r, u, own, softmax_scale, lse, out, acc):
+    """Step 0 of the forward started on the rows this rank already holds (hybrid/async_attn_layer.py: self_chunk_mode;
+    ulysses degree 2 beside a ring).  The local block is [front chunk | back chunk] of c rows each and the Ulysses
+    exchange delivers one of them from the peer: rank u = 0 owns the front chunk, u = 1 the back chunk.  Step 0 is
+    causal over the 2c local rows (zigzag_ring_flash_attn.py:51-53), so the owned chunk against its own keys is a
+    complete sub-block of it: u = 0: q[0:c] x k[0:c] causal = everything rows [0,c) get from step 0; u = 1: the
+    diagonal block of rows [c,2c).  `own` = (q, k, v) of the owned chunk (views of the exchange's send buffer)."""
+    qs, ks, vs = own
+    c = qs.shape[1]
+    if u == 0:           # rows [0,c) are final at once on ring rank 0 only (the first chunk of the whole sequence)
+        be.fwd(qs, ks, vs, softmax_scale, True, lse[:, :, :c], out[:, :c], acc[:, :c], False, 0, c if r == 0 else 0)
+    else:
+        be.fwd(qs, ks, vs, softmax_scale, True, lse[:, :, c:], out[:, c:], acc[:, c:], False, 0, 0)
+
+
+def zigzag_fwd_step0_rest(be, r, u, q, k, v, softmax_scale, lse, out, acc):
+    """... and the rest of step 0 behind the exchange: u = 0: rows [c,2c) against all 2c local keys (bottom-right
+    causal); u = 1: the peer's keys [0,c) merged into rows [c,2c) (full block), then rows [0,c) causal."""
+    c = q.shape[1] // 2
+    if u == 0:
+        be.fwd(q[:, c:], k, v, softmax_scale, True, lse[:, :, c:], out[:, c:], acc[:, c:], False, 0, 0)
+    else:
+        be.fwd(q[:, c:], k[:, :c], v[:, :c], softmax_scale, False, lse[:, :, c:], out[:, c:], acc[:, c:], True, 0, 0)
+        be.fwd(q[:, :c], k[:, :c], v[:, :c], softmax_scale, True, lse[:, :, :c], out[:, :c], acc[:, :c], False, 0,
+               c if r == 0 else 0)
+
+
+def zigzag_bwd_step0_split(be, u, do_own, dout, wait, q, kk, vv, out, lse, delta, softmax_scale, dq_acc, dk_dst, dv_dst):
+    """Step 0 of the backward started on the rows whose dO this rank already holds (the owned chunk; K, V, out and the
+    LSE are saved tensors): u = 0: rows [0,c) x keys [0,c) first, rows [c,2c) x all keys on top behind the exchange;
+    u = 1: rows [c,2c) x all keys first (3/4 of the block), rows [0,c) x keys [0,c) on top.  dk_dst / dv_dst are the
+    travelling fp32 accumulators (written by the first launch, accumulated into by the second); the delta of the peer's
+    rows is computed behind the exchange as well."""
+    c = q.shape[1] // 2
+    if u == 0:
+        be.delta(do_own, out[:, :c], delta[:, :, :c])
+        dk_dst[:, c:].zero_()
+        dv_dst[:, c:].zero_()
+        be.bwd(do_own, q[:, :c], kk[:, :c], vv[:, :c], lse[:, :, :c], delta[:, :, :c], dq_acc[:, :c], dk_dst[:, :c], dv_dst[:, :c],
+               softmax_scale, True)
+        wait()
+        be.delta(dout[:, c:], out[:, c:], delta[:, :, c:])
+        be.bwd(dout[:, c:], q[:, c:], kk, vv, lse[:, :, c:], delta[:, :, c:], dq_acc[:, c:], dk_dst, dv_dst, softmax_scale, True,
+               accum_dk=True, accum_dv=True)
+    else:
+        be.delta(do_own, out[:, c:], delta[:, :, c:])
+        be.bwd(do_own, q[:, c:], kk, vv, lse[:, :, c:], delta[:, :, c:], dq_acc[:, c:], dk_dst, dv_dst, softmax_scale, True)
+        wait()
+        be.delta(dout[:, :c], out[:, :c], delta[:, :, :c])
+        be.bwd(dout[:, :c], q[:, :c], kk[:, :c], vv[:, :c], lse[:, :, :c], delta[:, :, :c], dq_acc[:, :c], dk_dst[:, :c],
+               dv_dst[:, :c], softmax_scale, True, accum_dk=True, accum_dv=True)
+
+
 def zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, dk_dst,
                      dv_dst):
     """Block backward of ring step `step`: dq accumulates in place into dq_acc (fp32), the dK/dV
@@ -104,9 +157,13 @@ def zigzag_fetch_plan(P, r, pieces, c, grouped=False):
 
 def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, causal=True,
                                    window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
-                                   deterministic=False, attn_type: AttnType = AttnType.HIP, overlap=False):
+                                   deterministic=False, attn_type: AttnType = AttnType.HIP, overlap=False, first=None):
     """`overlap`: the caller has transfers of its own in flight (pipelined Ulysses exchange), so the kernels are
-    launched so that collectives can run beside them even at ring degree 1."""
+    launched so that collectives can run beside them even at ring degree 1.
+    `first` = (u, (q, k, v) of the owned chunk, wait): q / k / v are still in flight (the caller's Ulysses exchange at degree
+    2; `wait()` orders the calling stream behind it) and step 0 starts on the chunk this rank owns (zigzag_fwd_step0_own).
+    The K/V transfers of the ring are posted BEHIND the wait -- they read the exchanged k / v -- i.e. no later than without
+    the split, where everything waits for the exchange.  Ring degree > 1 only (degree 1: _split_first_forward)."""
     assert causal == True, "zigzag ring is meaningless for causal=False"
     P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
@@ -119,10 +176,21 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
         be.fwd(q, k, v, softmax_scale, True, lse, out)
         return out, lse
     acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev)
+    if first is not None:
+        u, own, wait = first
+        zigzag_fwd_step0_own(be, r, u, own, softmax_scale, lse, out, acc)
+        wait()
+
+    def step0():
+        if first is not None:
+            zigzag_fwd_step0_rest(be, r, first[0], q, k, v, softmax_scale, lse, out, acc)
+        else:
+            zigzag_fwd_step(be, r, P, 0, q, k, v, softmax_scale, lse, out, acc)
+
     if P > 2 and kv_relay_mode(P) == "direct":      # mesh fetch in waves, only the halves the schedule reads
         c = S2 // 2
         with ZigzagKVFetch(process_group, k, v, zigzag_fetch_pieces(k)) as fetch:
-            zigzag_fwd_step(be, r, P, 0, q, k, v, softmax_scale, lse, out, acc)
+            step0()
             for w, lo, hi, all_rows, fe in zigzag_fetch_plan(P, r, fetch.pieces, c, fetch.grouped):
                 kp, vp = fetch.get_range(w, lo, hi) if fetch.grouped else fetch.get(w, lo)
                 if all_rows:
@@ -133,14 +201,19 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
     with KVRelay(process_group, k, v) as relay:
         for step in range(P):
             kk, vv = relay.get(step)
-            zigzag_fwd_step(be, r, P, step, q, kk, vv, softmax_scale, lse, out, acc)
+            if step == 0:
+                step0()
+            else:
+                zigzag_fwd_step(be, r, P, step, q, kk, vv, softmax_scale, lse, out, acc)
     return out, lse
 
 
 def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, softmax_scale,
                                     dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
                                     alibi_slopes=None, deterministic=False,
-                                    attn_type: AttnType = AttnType.HIP, overlap=False, tail=None):
+                                    attn_type: AttnType = AttnType.HIP, overlap=False, tail=None, first=None):
+    """`first` = (u, dO of the owned chunk, wait): dO is still in flight (see the forward); step 0 starts on the owned
+    rows (zigzag_bwd_step0_split).  Ring degree > 1 only."""
     assert causal == True, "zigzag ring is meaningless for causal=False"
     P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
@@ -149,7 +222,9 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
     dev = q.device
     lse = softmax_lse
     delta = torch.empty((B, H, S2), dtype=torch.float32, device=dev)
-    be.delta(dout, out, delta)
+    assert first is None or P > 1
+    if first is None:
+        be.delta(dout, out, delta)
     if P == 1:   # one block: the kernels round the gradients to q.dtype in their epilogues
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         be.bwd(dout, q, k, v, lse, delta, None, None, None, softmax_scale, True, dq16=dq, dk16=dk, dv16=dv)
@@ -157,7 +232,11 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
     dq_acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev)
 
     def block(step, kk, vv, dk_dst, dv_dst):
-        zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, dk_dst, dv_dst)
+        if step == 0 and first is not None:
+            u, do_own, wait = first
+            zigzag_bwd_step0_split(be, u, do_own, dout, wait, q, kk, vv, out, lse, delta, softmax_scale, dq_acc, dk_dst, dv_dst)
+        else:
+            zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, dk_dst, dv_dst)
 
     def fold(step, dk_acc, dv_acc, dk_blk, dv_blk):
         zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk)

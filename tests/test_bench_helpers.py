@@ -183,8 +183,9 @@ def _main_worker(rank, ws):
         assert line["roofline"]["stub"] is True and line["scaling"] == "strong" and line["config"]["pass"] == "fwd+bwd"
     else:
         assert set(line["overlap"]) >= {"value", "ms_iter", "ms_compute_only", "ms_comm_only"}
-    if ws == 8:       # ulysses 2 x ring 4: two communicators -> the safe mode is measured first, then the overlapped one
-        assert set(line["comm_modes_ms_per_step"]) == {"safe", "overlapped", "relayed"}
+    if ws == 8:       # ulysses 2 x ring 4: two communicators -> the safe mode is measured first, then the overlapped one, the relayed
+                      # pair exchange and the self-chunk start beside the ring, each under its deadline on top of the fastest so far
+        assert set(line["comm_modes_ms_per_step"]) == {"safe", "overlapped", "relayed", "self_chunk_start"}
         assert line["config"]["comm_mode"].startswith(("safe", "overlapped"))
         assert line["ms_per_step"] == min(line["comm_modes_ms_per_step"].values())
     elif ws == 2:     # ulysses 2, ring degree 1: the default, then the self-chunk start under a deadline; the faster is the line

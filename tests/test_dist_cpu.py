@@ -189,18 +189,24 @@ def _async_worker(rank, ws, ud, rd, impl, Hq, Hkv):
     return same and right
 
 
-def _self_chunk_worker(rank, ws, impl, Hq, Hkv, B, S):
-    """USP_SELF_CHUNK=1 (hybrid/async_attn_layer.py:self_chunk_mode): on the 2-GPU grid (ulysses 2, ring degree 1) the first
-    head group starts on the rows the rank already holds -- two or three launches joined by the fused LSE merge / fp32 dK, dV
-    accumulation instead of one causal block.  Against the unsplit schedule (same sums in another order: tight) and against
-    exact attention and its gradients; the launches the test backend sees must START before the exchange is waited for."""
+def _self_chunk_worker(rank, ws, impl, Hq, Hkv, B, S, rd=1, env=None):
+    """USP_SELF_CHUNK=1 (hybrid/async_attn_layer.py:self_chunk_mode): at ulysses degree 2 the first head group starts on the
+    rows the rank already holds -- on the 2-GPU grid (ring degree 1) two or three launches joined by the fused LSE merge /
+    fp32 dK, dV accumulation instead of one causal block; beside a zigzag ring (rd > 1: the 8-GPU grid is 2 x 4) the same
+    split of STEP 0 of the ring schedule, the ring's own K/V transfers posted behind the exchange.  Against the unsplit
+    schedule (same sums in another order: tight) and against exact attention and its gradients; the launches the test
+    backend sees must START before the exchange is waited for."""
     import yunchang_amd as Y
     import yunchang_amd.hybrid.async_attn_layer as AL
+    import yunchang_amd.ring.zigzag_ring_flash_attn as ZZ
     from yunchang_amd.kernels import set_block_backend
     from oracle_backend import OracleBlockBackend
     from oracle import usp_oracle as O
+    import os
+    for kv in (env or ()):
+        os.environ.__setitem__(*kv.split("="))
     set_block_backend(OracleBlockBackend())
-    Y.set_seq_parallel_pg(2, 1, rank, ws)
+    Y.set_seq_parallel_pg(2, rd, rank, ws)
     AL._FILL_ITEMS = 1
     torch.manual_seed(1)
     D = 32
@@ -208,36 +214,42 @@ def _self_chunk_worker(rank, ws, impl, Hq, Hkv, B, S):
     ext = Y.EXTRACT_FUNC_DICT[impl]
     qn, kn, vn, don = (t.float().numpy().astype(np.float64) for t in (q, k, v, do))
     ro, rl = O.attention_ref(qn, kn, vn, causal=True)
-    truth = [ext(torch.from_numpy(np.ascontiguousarray(t)), rank, world_size=ws, rd=1, ud=2).float()
+    truth = [ext(torch.from_numpy(np.ascontiguousarray(t)), rank, world_size=ws, rd=rd, ud=2).float()
              for t in (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, True))]
     res, order = [], []
     real_wait = AL._Lane.wait
-    real_split = AL._split_first_forward
+    real = (AL._split_first_forward, AL._split_first_backward, ZZ.zigzag_fwd_step0_own, ZZ.zigzag_bwd_step0_split)
     AL._Lane.wait = lambda self, ev: (order.append("wait"), real_wait(self, ev))[1]
 
-    def spy(be, u, selfs, full, wait, scale):
-        order.append("split-forward")
-        return real_split(be, u, selfs, full, wait, scale)
-    AL._split_first_forward = spy
+    def spy(name, fn):
+        def f(*a, **kw):
+            order.append(name)
+            return fn(*a, **kw)
+        return f
+    AL._split_first_forward, AL._split_first_backward = spy("split-forward", real[0]), spy("split-backward", real[1])
+    ZZ.zigzag_fwd_step0_own, ZZ.zigzag_bwd_step0_split = spy("split-forward", real[2]), spy("split-backward", real[3])
     try:
         for on in (False, True):
             AL._COMM_OVERRIDE["self_chunk"] = "1" if on else "0"
-            lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=1, ud=2).detach().clone() for t in (q, k, v, do))
+            lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=rd, ud=2).detach().clone() for t in (q, k, v, do))
             for t in (lq, lk, lv):
                 t.requires_grad_(True)
             order.clear()
             out = Y.LongContextAttention(ring_impl_type=impl)(lq, lk, lv, causal=True)
             fwd_order = list(order)
+            order.clear()
             out.backward(ldo)
+            bwd_order = list(order)
             res.append([t.detach().float() for t in (out, lq.grad, lk.grad, lv.grad)])
-            if on:      # the split forward is entered BEFORE the first wait for an exchange
+            if on:      # the split step is entered BEFORE the first wait for an exchange, forward and backward
                 assert fwd_order and fwd_order[0] == "split-forward" and "wait" in fwd_order[1:], fwd_order
+                assert bwd_order and bwd_order[0] == "split-backward" and "wait" in bwd_order[1:], bwd_order
             else:
-                assert "split-forward" not in fwd_order
+                assert "split-forward" not in fwd_order and "split-backward" not in bwd_order
     finally:
         AL._COMM_OVERRIDE.pop("self_chunk", None)
         AL._Lane.wait = real_wait
-        AL._split_first_forward = real_split
+        AL._split_first_forward, AL._split_first_backward, ZZ.zigzag_fwd_step0_own, ZZ.zigzag_bwd_step0_split = real
     close = all(torch.allclose(a, b, atol=tol, rtol=tol) for a, b, tol in zip(res[0], res[1], (8e-3, 3e-2, 3e-2, 3e-2)))
     right = all(torch.allclose(a, t, atol=tol, rtol=tol) for a, t, tol in zip(res[1], truth, (2e-2, 5e-2, 5e-2, 5e-2)))
     return close and right
@@ -246,6 +258,16 @@ def _self_chunk_worker(rank, ws, impl, Hq, Hkv, B, S):
 @pytest.mark.parametrize("impl,Hq,Hkv,B,S", [("basic", 4, 4, 1, 64), ("basic", 8, 2, 2, 96), ("zigzag", 4, 2, 1, 128)])
 def test_self_chunk_start_on_the_two_gpu_grid(impl, Hq, Hkv, B, S):
     assert all(run_distributed(_self_chunk_worker, 2, impl, Hq, Hkv, B, S))
+
+
+@pytest.mark.parametrize("rd,Hq,Hkv,B,S,env", [(2, 4, 2, 1, 128, None),                               # chain relay (ring 2)
+                                               (4, 8, 2, 2, 256, None),                               # the 8-GPU grid: mesh fetch in waves
+                                               (4, 4, 4, 1, 128, ("USP_KV_RELAY=chain", "USP_DKDV_RETURN=direct")),
+                                               (4, 4, 2, 1, 128, ("USP_PIPELINE_ULYSSES=0",))])        # one packed exchange
+def test_self_chunk_start_beside_a_zigzag_ring(rd, Hq, Hkv, B, S, env):
+    """The same start at ring degree > 1 (ulysses 2 x ring 2 / 4, zigzag): step 0 of the ring schedule is split, every K/V
+    transport (chain relay, mesh fetch) and both dK/dV return forms behind it."""
+    assert all(run_distributed(_self_chunk_worker, 2 * rd, "zigzag", Hq, Hkv, B, S, rd, env))
 
 
 @pytest.mark.parametrize("ws,ud,rd,impl,Hq,Hkv", [(4, 2, 2, "zigzag", 8, 4), (2, 2, 1, "basic", 4, 4),

@@ -255,10 +255,12 @@ def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch,
 @pytest.mark.timeout(1500)
 @pytest.mark.parametrize("n_gpus,relay,harness", [(8, False, "barrier"), (4, False, "barrier"), (2, False, "barrier"),
                                                   (8, True, "barrier"), (8, False, "pairwise"), (4, False, "pairwise"),
-                                                  (-4, False, "barrier"), (-2, False, "barrier"), (-2, False, "barrier-selfchunk")],
+                                                  (-4, False, "barrier"), (-2, False, "barrier"), (-2, False, "barrier-selfchunk"),
+                                                  (-8, False, "barrier-selfchunk")],
                          ids=["configs4_8gpu_u2r4_gqa_fwd_bwd", "configs3_4gpu_r4_fwd", "configs2_2gpu_u2_fwd",
                               "configs4_8gpu_relayed_pair_exchange", "configs4_8gpu_drifting_ranks", "configs3_4gpu_drifting_ranks",
-                              "bench_4gpu_r4_64k_gqa_fwd_bwd", "bench_2gpu_u2_64k_gqa_fwd_bwd", "bench_2gpu_u2_64k_self_chunk_start"])
+                              "bench_4gpu_r4_64k_gqa_fwd_bwd", "bench_2gpu_u2_64k_gqa_fwd_bwd", "bench_2gpu_u2_64k_self_chunk_start",
+                              "bench_8gpu_u2r4_64k_self_chunk_start"])
 def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatch, n_gpus, relay, harness):
     """BASELINE's multi-GPU configs AT THEIR OWN SIZE with the ranks as virtual ranks of one GPU -- configs[4]: 8 ranks,
     ulysses 2 x ring 4, zigzag, B1 S65536 H32/Hkv4 D128 bf16 causal, forward + backward; configs[3]: 4 ranks, ring 4
@@ -307,6 +309,10 @@ def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatc
         real_f, real_b = AL._split_first_forward, AL._split_first_backward
         monkeypatch.setattr(AL, "_split_first_forward", lambda *a: (split_calls.append("f"), real_f(*a))[1])
         monkeypatch.setattr(AL, "_split_first_backward", lambda *a: (split_calls.append("b"), real_b(*a))[1])
+        import yunchang_amd.ring.zigzag_ring_flash_attn as ZZ           # beside a ring: step 0 of the ring schedule is split
+        real_zf, real_zb = ZZ.zigzag_fwd_step0_own, ZZ.zigzag_bwd_step0_split
+        monkeypatch.setattr(ZZ, "zigzag_fwd_step0_own", lambda *a: (split_calls.append("f"), real_zf(*a))[1])
+        monkeypatch.setattr(ZZ, "zigzag_bwd_step0_split", lambda *a: (split_calls.append("b"), real_zb(*a))[1])
     import yunchang_amd.comm.relay_exchange as RX
     monkeypatch.setitem(RX._OVERRIDE, "relay", relay)         # (8 ranks: every pair exchange striped over the 6 other ranks)
     streams = [torch.cuda.Stream(device=dev) for _ in range(ws)]

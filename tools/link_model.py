@@ -73,8 +73,18 @@ def round5(ms):
         comm = sum(e.values()) + 3 * hop8 + ng * last + 2 * kv8
         print("   N=8  2x4, %-74s %.1f ms per iteration = %5.0f TFLOP/s on 8 GPUs, overlap %.2f"
               % (label + ":", tot, F / tot * 1e3, 1 - (tot - (fwd + bwd) / eff) / comm))
+        if ng == 2:
+            # ... + the self-chunk start beside the ring (USP_SELF_CHUNK=1: step 0 of the first group's ring schedule starts on the
+            # owned zigzag chunk): the first-in exchange of each pass runs beside 1/4 of that step's kernels on the slower rank
+            # (forward: 0.25 x 0.496 ms causal launch of an 8-head group; backward: 0.25 x (0.849 + 0.605) ms -- rank trace,
+            # profiles/r05_rank_emulation.txt); what the exchange takes beyond that stays exposed
+            hid = min(e["fi"] / ng, 0.25 * 0.496) + min(e["bi"] / ng, 0.25 * (0.849 + 0.605))
+            print("   N=8  2x4, %-74s %.1f ms per iteration = %5.0f TFLOP/s on 8 GPUs, overlap %.2f"
+                  % ("  ... + self-chunk start beside the ring (USP_SELF_CHUNK=1):", tot - hid, F / (tot - hid) * 1e3,
+                     1 - (tot - hid - (fwd + bwd) / eff) / comm))
     print("   (overlap >= 0.90 at N=8 needs < 0.46 ms exposed of 4.6 ms: the first-in / last-out exchange of each pass alone is 1.18 ms at 64 GB/s;"
-          "\n    self-chunk starts + row-chunked tails would reach 0.88 by this model, 0.92 with the relay on top -- DESIGN.md 5: not built)")
+          "\n    the self-chunk start hides the first-in part as far as a quarter of step 0 lasts; the last-out part needs row-chunked tails"
+          "\n    -- DESIGN.md 5: not built)")
 
 
 def main():

@@ -198,7 +198,31 @@ for shape in "1 16384 16384 2 2" "1 16384 16384 4 4" "1 16384 16384 4 1" "1 3276
 done
 }
 
+# round 5: the self-chunk start beside the zigzag ring (ulysses 2 x ring 4): the full-size virtual grid through RCCL with the split
+# spied on, then what the split costs in compute on one rank (tools/rank_emulation.py, wire = local copies)
+run18_self_chunk_ring() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r05
+( time timeout 1500 python -m pytest tests/test_gpu_rccl_order.py -q -x -k "self_chunk or configs4_8gpu_u2r4" 2>&1 | tail -5 ) 2>&1 | tail -9
+for e in USP_SELF_CHUNK=0 USP_SELF_CHUNK=1 USP_SELF_CHUNK=0 USP_SELF_CHUNK=1; do
+  timeout 600 python tools/rank_emulation.py --gpus 8 --iters 10 --env $e 2>&1 | grep "per iteration" | cut -c1-200
+done
+for r in 1 4 5; do
+  timeout 600 python tools/rank_emulation.py --gpus 8 --iters 10 --rank $r --env USP_SELF_CHUNK=1 2>&1 | grep "per iteration" | cut -c1-200
+done
+}
+
+# round 5: why a middle ring rank of the 8-GPU grid takes longer than ring rank 0 (kernel traces of tools/rank_emulation.py;
+# 3 warm + 5 timed iterations traced)
+run19_rank_compare() {
+export TMPDIR=/tmp; cd /tmp; R=$GRAFT_REPO_ROOT
+for rank in 0 4 6; do
+  rocprofv3 --kernel-trace --stats -d /tmp/emu_r$rank -o x -- python $R/tools/rank_emulation.py --gpus 8 --iters 5 --rank $rank > /tmp/emu_r$rank.log 2>&1
+  grep "per iteration" /tmp/emu_r$rank.log | cut -c1-140
+  python3 $R/tools/r05/trace_top.py /tmp/emu_r$rank 8 "rank $rank" 14
+done
+}
+
 case "$1" in
-  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final|run15_rank_trace|run16_fwd_small_interleave|run17_fwd64_ksplit) "$1" ;;
-  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final|run15_rank_trace|run16_fwd_small_interleave|run17_fwd64_ksplit}"; exit 64 ;;
+  run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final|run15_rank_trace|run16_fwd_small_interleave|run17_fwd64_ksplit|run18_self_chunk_ring|run19_rank_compare) "$1" ;;
+  *) echo "usage: $0 {run01_row64_tests|run02_bench|run04_dkdv_anatomy|run05_fwd_dq_anatomy|run06_ceiling_emulation|run07_dkdv_early_stats|run08_dkdv|run09_dkdv_ab|run10_prof_and_tests|run11_dq64_cuts|run12_dq64_midbarrier|run13_self_chunk|run14_final|run15_rank_trace|run16_fwd_small_interleave|run17_fwd64_ksplit|run18_self_chunk_ring|run19_rank_compare}"; exit 64 ;;
 esac
