@@ -28,10 +28,24 @@
 
 namespace usp {
 
-constexpr int kB64_STATW = 0;    // the wave that stages a tile's statistics (a role-A wave: see stat_wave below)
-constexpr int kB64_DMA_PH = 0;   // phase whose slots carry the next tile's DMA pieces (0: the first chain)
-constexpr int kB64_E0 = 16;      // first and one-past-last slot of the element stream (64 elements; chain(h0) ends at 16, the
-constexpr int kB64_E1 = 54;      // gradient MFMAs of k-step (h, k2) start at 32 + 16 h + 8 k2)
+#ifndef USP_B64_STATW
+#define USP_B64_STATW 0
+#endif
+constexpr int kB64_STATW = USP_B64_STATW;    // the wave that stages a tile's statistics (a role-A wave: see stat_wave below)
+#ifndef USP_B64_DMA_PH
+#define USP_B64_DMA_PH 0
+#endif
+constexpr int kB64_DMA_PH = USP_B64_DMA_PH;   // phase whose slots carry the next tile's DMA pieces (0: the first chain)
+// (round 5: the element stream opens at slot 20 instead of 16 -- swept at the N = 1 workload's shape on two boxes, -0.7 ... -1.5 %
+// on this kernel, -0.7 % on a 16K group launch, C2 inside the noise; profiles/r05_slot_sweep.txt.  The -D overrides exist for such sweeps only.)
+#ifndef USP_B64_E0
+#define USP_B64_E0 20
+#endif
+constexpr int kB64_E0 = USP_B64_E0;      // first and one-past-last slot of the element stream (64 elements; chain(h0) ends at 16, the
+#ifndef USP_B64_E1
+#define USP_B64_E1 54
+#endif
+constexpr int kB64_E1 = USP_B64_E1;      // gradient MFMAs of k-step (h, k2) start at 32 + 16 h + 8 k2)
 
 // dev build -DUSP_B64_TIMING: where an iteration's time goes (s_memtime stamps summed per wave, printed for a few waves;
 // profiles/r04_run21..23*.log)

@@ -32,8 +32,14 @@
 
 namespace usp {
 
-constexpr int kQ64_PF = 3;     // LDS fragments are read this many fragments ahead of the first MFMA that takes them
-constexpr int kQ64_Y1 = 24;    // gaps over which the last element stream (dS of query block 1) is spread, from B5 on
+#ifndef USP_Q64_PF
+#define USP_Q64_PF 3
+#endif
+constexpr int kQ64_PF = USP_Q64_PF;     // LDS fragments are read this many fragments ahead of the first MFMA that takes them
+#ifndef USP_Q64_Y1
+#define USP_Q64_Y1 24
+#endif
+constexpr int kQ64_Y1 = USP_Q64_Y1;    // gaps over which the last element stream (dS of query block 1) is spread, from B5 on
                                // (neither moves the kernel by more than 0.5 %: profiles/r04_run26*.log)
 
 // dev build -DUSP_Q64_TIMING: where an item's time goes (s_memtime stamps, printed for a few waves)

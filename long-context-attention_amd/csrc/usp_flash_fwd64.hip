@@ -31,14 +31,36 @@
 namespace usp {
 
 // Placement of the element work and of the LDS-DMA pieces among the 64 MFMA slots of a tile (tuned on the C2 shape,
-// profiles/r04_dma_probes.txt; constants, not build options):
-constexpr int kF64_NEA = 42;    // exp elements (of 64 per lane and tile) issued in phase A; the rest opens phase B, one per slot
-constexpr int kF64_LEAD = 2;    // ... of which in front of the first MFMA of phase A (it waits for the first K fragments anyway)
-constexpr int kF64_PFK = 2;     // K fragments read this many fragments (= 2 MFMA slots each) ahead of their first MFMA
-constexpr int kF64_PFV = 2;     // likewise the V fragments
-constexpr int kF64_MAX0 = 22;   // first slot of phase B that carries row-max work of the next tile
-constexpr int kF64_DMA0 = 2;    // slot (0..63 over both phases) behind whose MFMA the first of the iteration's 8 LDS-DMA pieces
-constexpr int kF64_DMAS = 6;    // goes out, and the distance to the next one
+// profiles/r04_dma_probes.txt; swept again at the N = 1 workload's shape in round 5 -- every variant within +-1 % of these,
+// profiles/r05_slot_sweep.txt.  Constants: the -D overrides exist for such sweeps only):
+#ifndef USP_F64_NEA
+#define USP_F64_NEA 42
+#endif
+constexpr int kF64_NEA = USP_F64_NEA;    // exp elements (of 64 per lane and tile) issued in phase A; the rest opens phase B, one per slot
+#ifndef USP_F64_LEAD
+#define USP_F64_LEAD 2
+#endif
+constexpr int kF64_LEAD = USP_F64_LEAD;    // ... of which in front of the first MFMA of phase A (it waits for the first K fragments anyway)
+#ifndef USP_F64_PFK
+#define USP_F64_PFK 2
+#endif
+constexpr int kF64_PFK = USP_F64_PFK;     // K fragments read this many fragments (= 2 MFMA slots each) ahead of their first MFMA
+#ifndef USP_F64_PFV
+#define USP_F64_PFV 2
+#endif
+constexpr int kF64_PFV = USP_F64_PFV;     // likewise the V fragments
+#ifndef USP_F64_MAX0
+#define USP_F64_MAX0 22
+#endif
+constexpr int kF64_MAX0 = USP_F64_MAX0;   // first slot of phase B that carries row-max work of the next tile
+#ifndef USP_F64_DMA0
+#define USP_F64_DMA0 2
+#endif
+constexpr int kF64_DMA0 = USP_F64_DMA0;    // slot (0..63 over both phases) behind whose MFMA the first of the iteration's 8 LDS-DMA pieces
+#ifndef USP_F64_DMAS
+#define USP_F64_DMAS 6
+#endif
+constexpr int kF64_DMAS = USP_F64_DMAS;    // goes out, and the distance to the next one
 
 // dev build -DUSP_F64_TIMING: where an item's time goes (s_memtime stamps, printed for a few waves; profiles/r04_run28*.log)
 #ifdef USP_F64_TIMING
