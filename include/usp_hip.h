@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define USP_ABI_VERSION 6
+#define USP_ABI_VERSION 7
 
 enum { USP_BF16 = 0, USP_FP16 = 1 };
 
@@ -57,8 +57,8 @@ enum {
  * per process -- which is what lets a parity test pin the kernel it means to test, and a bench time both families on
  * the same box:
  *   USP_FORCE_ROW64   every flash kernel of the call must come from the 64-row family; a call that family does not
- *                     serve (head dim != 128, packed batch, window, forward K split, GQA backward without the head-split
- *                     workspace) returns USP_EUNSUPPORTED and launches nothing;
+ *                     serve (head dim != 128, packed batch, window) returns USP_EUNSUPPORTED and launches nothing
+ *                     (unforced, the library picks the 64-row forward K split only for long cuts);
  *   USP_FORCE_WAVE32  every flash kernel of the call comes from the 32-rows-per-wave family.
  * Both bits at once: USP_EINVAL.  usp_last_launch_kinds() reports what a call actually launched. */
 #define USP_FORCE_ROW64 4
@@ -203,22 +203,28 @@ typedef struct usp_bwd_args {
   int32_t dkdv_splits;           /* ... and every (query head, 128-key block) item of the dK/dV launch along the query
                                     rows that see it.  Both need `workspace`, see usp_flash_bwd_workspace_bytes() */
   int32_t window_left, window_right; /* as usp_fwd_args; read only with USP_ATTN_WINDOW in `flags` */
+  int32_t dkdv_heads;            /* GQA, dense or packed (ABI v7): query heads of a KV group that ONE dK/dV work item streams
+                                    into its accumulators -- a divisor of Hq/Hkv (else USP_EINVAL).  Hq/Hkv = the whole group
+                                    inside the workgroup (no per-head partials, no reduce launch); 1 = one item per query
+                                    head; 0 = the library decides (see usp_flash_bwd_workspace_bytes()) */
 } usp_bwd_args;
 
 int usp_flash_bwd(const usp_bwd_args* args, void* stream);
 
 /* Bytes of scratch with which the backward launches get more, smaller work items (fp32 partials + one deterministic,
  * HBM-bound reduce launch each; results identical up to fp32 summation order):
- *   - GQA (Hq > Hkv): the dK/dV launch gives every query head of a KV group its own workgroups instead of looping the
- *     group inside one workgroup -- Hq/Hkv times more parallelism, which is what balances the causal triangle when
- *     B*Hkv*ceil(Sk/128) is small;
+ *   - GQA (Hq > Hkv): a dK/dV work item streams dkdv_heads query heads of its KV group (ABI v7; rounds 1-5: one or all).
+ *     With fewer than Hq/Hkv heads per item there are (Hq/Hkv)/dkdv_heads times more items -- what balances the causal
+ *     triangle when B*Hkv*ceil(Sk/128) is small -- and as many fp32 partial slabs.  dkdv_heads = 0: the largest divisor of
+ *     Hq/Hkv up to 4 that leaves two work items per CU (one for launches without a causal / window triangle) -- measured:
+ *     profiles/r06_gqa_loop.txt; packed batches: 1;
  *   - dkdv_splits = n (ABI v5): every such item is cut into n items over equal runs of the query tiles that see its keys;
  *   - dq_splits = n (ABI v5): every (head, 256-row query block) item of the dQ launch is cut into n items over equal runs
  *     of the key tiles it sees -- for launches with few heads (a small head group, a high Ulysses degree), where a causal
  *     launch otherwise lasts as long as its heaviest item.
- * = 2 * (Hq/Hkv) * max(1, dkdv_splits) * rows_k * Hkv * D * 4  (0 when that is a single slab)
+ * = 2 * ((Hq/Hkv)/dkdv_heads) * max(1, dkdv_splits) * rows_k * Hkv * D * 4  (0 when that is a single slab)
  *   + dq_splits * B * Sq * Hq * D * 4                           (0 when dq_splits <= 1); the cuts are ignored for packed
- * batches.  Passing less (or NULL) is valid and selects the in-workgroup loop without cuts. */
+ * batches.  Passing less (or NULL) is valid and selects the whole group per work item without cuts. */
 int64_t usp_flash_bwd_workspace_bytes(const usp_bwd_args* args);
 
 /* delta[b,h,s] = sum_d dout[b,s,h,d] * out[b,s,h,d]   (fp32; delta is (B,H,S), seq stride 1).

@@ -24,7 +24,7 @@ USP_FORCE_ROW64 = 4            # ABI v6: the call must be served by the one-wave
 USP_FORCE_WAVE32 = 8           # ... or by the two-waves-per-SIMD (32 rows per wave) family
 USP_BWD_SKIP_DQ = 16           # usp_flash_bwd: only the dK/dV launch ...
 USP_BWD_SKIP_DKDV = 32         # ... only the dQ launch
-ABI_VERSION = 6
+ABI_VERSION = 7
 # usp_last_launch_kinds(): bit -> kernel (include/usp_hip.h, USP_KIND_*)
 KINDS = {1: "fwd_row64", 2: "fwd_wave8", 4: "fwd_wave4", 8: "fwd_split_merge", 16: "dkdv_row64", 32: "dkdv_wave8",
          64: "dq_row64", 128: "dq_wave8", 256: "reduce_heads", 512: "reduce_cuts"}
@@ -97,7 +97,8 @@ class UspBwdArgs(ctypes.Structure):
                 ("seq_q", ctypes.c_void_p), ("seq_k", ctypes.c_void_p), ("total_k", ctypes.c_int64),
                 ("sched", ctypes.c_void_p), ("flags", ctypes.c_int32),
                 ("dq_splits", ctypes.c_int32), ("dkdv_splits", ctypes.c_int32),
-                ("window_left", ctypes.c_int32), ("window_right", ctypes.c_int32)]
+                ("window_left", ctypes.c_int32), ("window_right", ctypes.c_int32),
+                ("dkdv_heads", ctypes.c_int32)]
 
 
 EXPORTS = ("usp_flash_fwd", "usp_flash_fwd_workspace_bytes", "usp_flash_bwd", "usp_flash_bwd_workspace_bytes", "usp_bwd_delta", "usp_lse_merge", "usp_copy_rows",
@@ -464,12 +465,13 @@ def bwd_delta(dout, out, delta):
 
 def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causal: bool,
               accum_dq=False, accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None,
-              interleave: bool = False, splits=None, window=None, family=None, only=None):
+              interleave: bool = False, splits=None, window=None, family=None, only=None, dkdv_heads: int = 0):
     """usp_flash_bwd.  dq/dk/dv are fp32 (B,S,H,D) views, written or accumulated; a 16-bit
     dq16/dk16/dv16 receives the FINAL rounded result instead (the fp32 tensor may then be None
     unless it is accumulated from).  `splits` = (dq_splits, dkdv_splits), None: bwd_splits decides.  `window` =
     flash-attn's window_size (left, right), None / (-1, -1) = none.  `family`: as flash_fwd.  `only`: "dkdv" | "dq" issues
-    just that launch of the two (ABI v6: USP_BWD_SKIP_DQ / USP_BWD_SKIP_DKDV)."""
+    just that launch of the two (ABI v6: USP_BWD_SKIP_DQ / USP_BWD_SKIP_DKDV).  `dkdv_heads` (ABI v7): query heads of a KV
+    group one dK/dV work item streams (a divisor of Hq / Hkv; 0 = the library decides)."""
     _require_cuda(dout, q, k, v, lse, delta, dq, dk, dv, dq16, dk16, dv16)
     B, Sq, Hq, D = q.shape
     Sk, Hkv = k.shape[1], k.shape[2]
@@ -490,6 +492,7 @@ def flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale: float, causa
     ff = _family_flag(family)
     a.flags = (USP_LAUNCH_INTERLEAVE if interleave else 0) | ff | {None: 0, "dkdv": USP_BWD_SKIP_DQ, "dq": USP_BWD_SKIP_DKDV}[only]
     a.dq_splits, a.dkdv_splits = bwd_splits(B, Sq, Sk, Hq, bool(causal)) if splits is None else splits
+    a.dkdv_heads = int(dkdv_heads)
     win = _window(window)
     if win is not None:
         a.flags |= USP_ATTN_WINDOW

@@ -432,15 +432,21 @@ static int run_bwd(int B, int Sq, int Sk, int Hq, int Hkv, int D, int causal, in
     int x = 0, y = 0;
     if (sscanf(e, "%d,%d", &x, &y) == 2) { a.dq_splits = x; a.dkdv_splits = y; }
   }
+  if (const char* e = getenv("USP_KBENCH_BWD_HEADS")) {            // query heads per dK/dV work item (ABI v7); not a divisor: the library's choice
+    const int g = atoi(e);
+    if (g > 0 && (Hq / Hkv) % g == 0) a.dkdv_heads = g;
+  }
   const int64_t wsb = getenv("USP_NO_WORKSPACE") ? 0 : usp_flash_bwd_workspace_bytes(&a);
   if (wsb > 0) { a.workspace = dev_alloc<char>((size_t)wsb); a.workspace_bytes = wsb; }
   rc |= usp_flash_bwd(&a, nullptr);
   if (rc) { printf("BWD launch failed: %s\n", usp_strerror(rc)); return 1; }
   HIP_OK(hipDeviceSynchronize());
   char tag[160];
-  snprintf(tag, sizeof tag, "bwd B%d Sq%d Sk%d Hq%d Hkv%d D%d %s %s%s%s", B, Sq, Sk, Hq, Hkv, D,
+  char hd[24] = "";
+  if (a.dkdv_heads) snprintf(hd, sizeof hd, " heads/item %d", a.dkdv_heads);
+  snprintf(tag, sizeof tag, "bwd B%d Sq%d Sk%d Hq%d Hkv%d D%d %s %s%s%s%s", B, Sq, Sk, Hq, Hkv, D,
            causal ? "causal" : "full", dt ? "fp16" : "bf16", getenv("USP_KBENCH_BWD_SPLITS") ? " cuts " : "",
-           getenv("USP_KBENCH_BWD_SPLITS") ? getenv("USP_KBENCH_BWD_SPLITS") : "");
+           getenv("USP_KBENCH_BWD_SPLITS") ? getenv("USP_KBENCH_BWD_SPLITS") : "", hd);
   int fail = 0;
   if (check) {
     std::vector<float> ro(nq), rl(nl), rdq(nq), rdk(nk), rdv(nk);
@@ -504,6 +510,23 @@ static int suite(bool with_bwd) {
       for (const C& c : bs) f += run_bwd(c.B, c.Sq, c.Sk, c.Hq, c.Hkv, c.D, c.causal, c.dt, 1, 0);
     }
     unsetenv("USP_KBENCH_BWD_SPLITS");
+    // the GQA loop inside a dK/dV work item (ABI v7 dkdv_heads): 1, 2, 4 and all heads of a group per item, with and without
+    // cuts of the query rows on top; ragged, Sq != Sk both ways, D < 128 (the 8-wave kernel takes the same field)
+    const C gs[] = {{1, 512, 512, 8, 2, 128, 1, 0}, {2, 333, 200, 8, 1, 128, 1, 0}, {1, 200, 333, 4, 1, 128, 0, 1},
+                    {1, 1024, 1024, 8, 1, 128, 1, 1}, {1, 384, 640, 8, 2, 64, 1, 0}, {2, 130, 130, 6, 2, 128, 1, 0}};
+    for (const char* heads : {"1", "2", "4", "8", "3", "6"}) {
+      setenv("USP_KBENCH_BWD_HEADS", heads, 1);
+      for (const C& c : gs)
+        if ((c.Hq / c.Hkv) % atoi(heads) == 0) f += run_bwd(c.B, c.Sq, c.Sk, c.Hq, c.Hkv, c.D, c.causal, c.dt, 1, 0);
+    }
+    setenv("USP_KBENCH_BWD_SPLITS", "2,3", 1);
+    for (const char* heads : {"2", "4"}) {
+      setenv("USP_KBENCH_BWD_HEADS", heads, 1);
+      for (const C& c : gs)
+        if ((c.Hq / c.Hkv) % atoi(heads) == 0) f += run_bwd(c.B, c.Sq, c.Sk, c.Hq, c.Hkv, c.D, c.causal, c.dt, 1, 0);
+    }
+    unsetenv("USP_KBENCH_BWD_SPLITS");
+    unsetenv("USP_KBENCH_BWD_HEADS");
   }
   printf("SUITE %s (%d failing groups)\n", f ? "FAIL" : "PASS", f);
   // timings at BASELINE shapes (C2 = B2 S8192 H16 D128 bf16 causal) and the C5 per-rank ring blocks

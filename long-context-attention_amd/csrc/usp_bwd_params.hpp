@@ -26,11 +26,14 @@ struct BwdParams {
   int64_t dq16_sb, dq16_ss, dq16_sh, dk16_sb, dk16_ss, dk16_sh, dv16_sb, dv16_ss, dv16_sh;
   float* ws_dk; float* ws_dv;        // head-split partials [G][ws_rows][Hkv][D] fp32 (G > 1)
   int64_t ws_rows;                    // key rows per head-group slab: B*Sk, packed mode: rows of k
-  int split;                          // 1: one workgroup per (query head, key block), partials to the workspace
+  int split;                          // 1: the dK/dV items write fp32 partials to the workspace (nslab > 1), reduce_heads_kernel sums them
+  int gsub, ngrp;                     // dK/dV launch: an item streams `gsub` query heads of its KV group (a divisor of G) into the same
+                                      // accumulators; ngrp = G / gsub items per (KV head, key block).  gsub == G: the whole group inside the
+                                      // workgroup (no partials unless cut); gsub == 1: one item per query head (round 1's "head split")
   int qsplit;                         // dK/dV launch: every (head, key block) item is cut into this many items over equal
                                       // runs of the query tiles it sees (>= 1; > 1 only with `split`)
   int ksplit;                         // dQ launch: every (head, query block) item is cut along the key tiles it sees
-  int nslab;                          // dK/dV partial slabs the reduce sums: (split ? G : 1) * qsplit
+  int nslab;                          // dK/dV partial slabs the reduce sums: ngrp * qsplit
   float* ws_dq;                       // dQ partials [ksplit][B*Sq][Hq][D] fp32 (ksplit > 1)
   int win_on, win_lo;                 // sliding window, left bound (ABI v5): query row i sees key j only if
                                       // j >= i + win_lo (= Sk - Sq - window_left); the right bound is the causal limit

@@ -420,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
 
   const ItemWalk walk(p_in.n_items);             // persistent workgroups (usp_common.hpp)
   ItemQueue queue{p_in.sched, p_in.seq_k, p_in.n_items / p_in.nblk, p_in.nblk,
-                  p_in.Hkv * (p_in.split ? p_in.G : 1), OWN, 0};
+                  p_in.Hkv * p_in.ngrp, OWN, 0};
   int qstate = 0;
   USP_LDS int* qslots = (USP_LDS int*)(smem + p_in.sched_lds);
   for (int pass = 0;; ++pass) {
@@ -432,9 +432,9 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
   int rest = w / p.nblk;
   int g = 0, cut = 0;
   if (p.qsplit > 1) { cut = rest % p.qsplit; rest /= p.qsplit; }
-  if (p.split && p.G > 1) { g = rest % p.G; rest /= p.G; }
+  if (p.ngrp > 1) { g = rest % p.ngrp; rest /= p.ngrp; }
   const int hkv = rest % p.Hkv, b = rest / p.Hkv;
-  const int h0 = hkv * p.G + g;
+  const int h0 = hkv * p.G + g * p.gsub;
   int64_t ws_row0;
   if (!bind_sequence(p, b, &ws_row0)) continue;
   const int own0 = blk * OWN;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(512, 2) void flash_bwd_dkdv_kernel(const BwdParams 
     t_end = t_begin + per < t_end ? t_begin + per : t_end;
   }
   const int per_head = t_end - t_begin;
-  const int heads_here = p.split ? 1 : p.G;
+  const int heads_here = p.gsub;
   const int n_iter = per_head * heads_here;
 
   // ---- LDS-DMA staging of the Q / dO tiles -----------------------------------------------------------------
@@ -848,7 +848,7 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st, int force, int s
   }();
   static const bool persist = [] { const char* e = getenv("USP_BWD_PERSIST"); return !(e && e[0] == '0'); }();
   p.nblk = (p.Sk + 127) / 128;
-  p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1) * p.qsplit;
+  p.n_items = p.B * p.Hkv * p.nblk * p.ngrp * p.qsplit;
   const bool pers = (persist || p.sched) && !p.interleave;
   int grid = (pers && p.n_items > cus) ? cus : p.n_items;
   const size_t qx = p.sched ? 16 : 0;            // LDS for the item queue's two slots
@@ -857,7 +857,8 @@ static int launch_bwd(BwdParams p, bool causal, hipStream_t st, int force, int s
   // (per call: `force` = USP_FORCE_ROW64 / USP_FORCE_WAVE32, include/usp_hip.h)
   static const int forced_env = [] { const char* e = getenv("USP_BWD_WAVES"); return e ? atoi(e) : 0; }();
   const int forced_waves = (force & USP_FORCE_WAVE32) ? 8 : ((force & USP_FORCE_ROW64) ? 0 : forced_env);
-  if ((force & USP_FORCE_ROW64) && !(D == 128 && dkdv64_serves(p, DT) && dq64_serves(p))) return USP_EUNSUPPORTED;
+  if ((force & USP_FORCE_ROW64) && !(D == 128 && ((skip & USP_BWD_SKIP_DKDV) || dkdv64_serves(p, DT)) && ((skip & USP_BWD_SKIP_DQ) || dq64_serves(p))))
+    return USP_EUNSUPPORTED;     // (only the launches that will run have to be served)
   bool dkdv_done = (skip & USP_BWD_SKIP_DKDV) != 0;
   if (!dkdv_done && D == 128 && forced_waves != 8) {
     int rc64 = USP_ELAUNCH;
@@ -942,10 +943,55 @@ static int64_t ws_rows_of(const usp_bwd_args* a) {
 
 static int cuts_of(int32_t n, bool packed) { return (packed || n < 2) ? 1 : (n > 8 ? 8 : n); }
 
-// [dK partials | dV partials | dQ partials]: (G * dkdv_splits) slabs of ws_rows x Hkv x D each for dK and for dV (none when
-// there is one slab: Hq == Hkv and no cut), dq_splits slabs of B x Sq x Hq x D for dQ (none without a cut)
+static int device_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+      n = 256;
+    return n;
+  }();
+  return cus;
+}
+
+// Query heads of a KV group that ONE dK/dV work item streams into its accumulators (ABI v7: usp_bwd_args.dkdv_heads; a divisor
+// of G = Hq / Hkv).  More heads per item: K / V fragments, their pre-scale and the epilogue once per run of heads, fewer fp32
+// partial slabs (none when the item takes the whole group and nothing is cut) and a shorter reduce; fewer heads: more items,
+// which is what balances a causal launch of few (batch, KV head, key block) triangles.  0 = the library decides, from what
+// was measured on MI355X (profiles/r06_gqa_loop.txt; dK/dV launch + reduce alone, G = 8): the largest divisor <= 4 that
+// leaves two items per CU (causal; one when every item is equally long) --
+//   B1 S65536 H32/4 causal   55.1 (1) 54.8 (2) 54.7 (4) 55.2 (8) ms      one KV head of 16384 keys, causal  0.915 (1) 0.896 (2) 1.329 (4) ms
+//   B1 S32768 H32/4 causal   14.07    13.91    13.86    14.05            two KV heads, 16384 keys, causal   1.847 (1) 1.798 (2) 1.776 (4) 2.713 (8)
+//   one KV head, 8192 rows x 16384 keys, full  0.907 (1) 0.883 (2) 0.871 (4) 1.218 (8)
+// (eight heads per item lose to four even where there are plenty of items: the per-item saving halves again while every CU's
+// static list shortens to a handful of long items.)  Packed batches keep 1.  USP_BWD_GSUB=n (read once) overrides the automatic
+// choice for A/B runs.
+static int dkdv_heads_of(const usp_bwd_args* a) {
+  const int G = a->Hq / a->Hkv;
+  if (G <= 1) return 1;
+  if (a->dkdv_heads > 0) return (G % a->dkdv_heads == 0) ? a->dkdv_heads : -1;
+  if (a->seq_q || a->seq_k) return 1;
+  static const int forced = [] { const char* e = getenv("USP_BWD_GSUB"); return e ? atoi(e) : 0; }();
+  if (forced > 0) {
+    int g = forced > G ? G : forced;
+    while (G % g != 0) --g;
+    return g;
+  }
+  const int64_t base = (int64_t)a->B * a->Hkv * ((a->Sk + 127) / 128) * cuts_of(a->dkdv_splits, false);
+  const bool triangles = a->causal || ((a->flags & USP_ATTN_WINDOW) && a->window_right >= 0);
+  const int64_t want = (triangles ? 2LL : 1LL) * device_cus();
+  int best = 1;
+  for (int g = 2; g <= G && g <= 4; ++g)
+    if (G % g == 0 && base * (G / g) >= want) best = g;
+  return best;
+}
+
+// [dK partials | dV partials | dQ partials]: ((G / dkdv_heads) * dkdv_splits) slabs of ws_rows x Hkv x D each for dK and for dV
+// (none when that is one slab: the whole group in one item and no cut), dq_splits slabs of B x Sq x Hq x D for dQ (none without a cut)
 static int64_t dkdv_part_bytes(const usp_bwd_args* a) {
-  const int64_t slabs = (int64_t)(a->Hq / a->Hkv) * cuts_of(a->dkdv_splits, a->seq_q || a->seq_k);
+  const int gsub = dkdv_heads_of(a);
+  if (gsub < 1) return 0;
+  const int64_t slabs = (int64_t)((a->Hq / a->Hkv) / gsub) * cuts_of(a->dkdv_splits, a->seq_q || a->seq_k);
   return slabs > 1 ? 2 * slabs * ws_rows_of(a) * a->Hkv * a->D * 4 : 0;
 }
 
@@ -992,6 +1038,7 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   const int wr = a->causal ? 0 : (has_win ? a->window_right : -1);
   if ((a->seq_q || a->seq_k) && (wl >= 0 || wr > 0)) return USP_EUNSUPPORTED;       // dense launches only
   if (a->dq_splits < 0 || a->dq_splits > 8 || a->dkdv_splits < 0 || a->dkdv_splits > 8) return USP_EINVAL;
+  if (a->dkdv_heads < 0 || dkdv_heads_of(a) < 1) return USP_EINVAL;       // (not a divisor of Hq / Hkv)
   BwdParams p;
   p.dout = (const char*)a->dout.ptr; p.q = (const char*)a->q.ptr;
   p.k = (const char*)a->k.ptr; p.v = (const char*)a->v.ptr;
@@ -1029,17 +1076,21 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
     p.do_sb = p.q_sb = p.k_sb = p.v_sb = p.lse_sb = p.dl_sb = 0;
     p.dq_sb = p.dk_sb = p.dv_sb = p.dq16_sb = p.dk16_sb = p.dv16_sb = 0;
   }
-  // Workspace present and large enough: GQA head split and / or the requested cuts; otherwise neither (the in-workgroup
-  // loop over the group's heads, one item per block) -- results are identical up to fp32 summation order either way.
+  // Workspace present and large enough: the dK/dV items of dkdv_heads_of() query heads each and / or the requested cuts;
+  // otherwise neither (the whole KV group inside one workgroup, one item per key block) -- results are identical up to fp32
+  // summation order either way.
   const int64_t need = usp_flash_bwd_workspace_bytes(a);
   p.split = 0; p.qsplit = 1; p.ksplit = 1; p.nslab = 1; p.ws_dk = nullptr; p.ws_dv = nullptr; p.ws_dq = nullptr;
+  p.gsub = p.G; p.ngrp = 1;
   if (need > 0 && a->workspace && a->workspace_bytes >= need &&
       (reinterpret_cast<uintptr_t>(a->workspace) & 15) == 0) {
     const int64_t part = dkdv_part_bytes(a);
     if (part > 0) {
       p.split = 1;
+      p.gsub = dkdv_heads_of(a);
+      p.ngrp = p.G / p.gsub;
       p.qsplit = cuts_of(a->dkdv_splits, packed);
-      p.nslab = p.G * p.qsplit;
+      p.nslab = p.ngrp * p.qsplit;
       p.ws_dk = (float*)a->workspace;
       p.ws_dv = p.ws_dk + part / 8;
     }

@@ -124,11 +124,12 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   w = walk.dealt(w, p->nblk);
   const int blk = w % p->nblk;                   // early key blocks are seen by most rows: first
   int rest = w / p->nblk;
-  int g = 0, cut = 0;
+  int g = 0, cut = 0;                            // g: which run of `gsub` query heads of the KV group this item streams
   if (p->qsplit > 1) { cut = rest % p->qsplit; rest /= p->qsplit; }
-  if (p->split && p->G > 1) { g = rest % p->G; rest /= p->G; }
+  if (p->ngrp > 1) { g = rest % p->ngrp; rest /= p->ngrp; }
   const int hkv = rest % p->Hkv, b = rest / p->Hkv;
-  const int h0 = hkv * p->G + g;
+  const int gsub = p->gsub;
+  const int h0 = hkv * p->G + g * gsub;
   const int own0 = blk * OWN;
   const int off = p->causal_off;
   const int ow = own0 + slice * 64;              // first key of this wave
@@ -193,8 +194,14 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
     t_begin = t_begin + cut * per < t_end ? t_begin + cut * per : t_end;
     t_end = t_begin + per < t_end ? t_begin + per : t_end;
   }
-  const int n_iter = t_end - t_begin;             // (one query head per item: launch_dkdv64 leaves the in-workgroup loop
-                                                  // over a GQA group's heads to the 8-wave kernel)
+  // The item streams the tiles [t_begin, t_end) of `gsub` query heads of its KV group, one head behind the other, into
+  // the same accumulators (round 6: the GQA loop inside the workgroup -- K / V fragments, their pre-scale and the epilogue
+  // once per KV head instead of once per query head, and with gsub == G no fp32 per-head partials and no reduce launch).
+  // Head by head: the two-stage pipeline (role B one tile behind role A, the DMA one tile ahead) drains and refills between
+  // heads -- about two tile times per head, against >= 64 tiles -- so that the streaming loops carry no head state at all:
+  // a seamless stream (the cursor re-based inside the loop by a uniform branch) cost every loop 40 - 140 instructions per
+  // tile in SGPR spills and accumulator copies (tools/r05/census.sh).
+  const int n_iter = t_end - t_begin;             // tiles per head
 
   // ---- LDS-DMA staging of the Q / dO tiles: running cursors (base pointer + remaining bytes, advanced per tile) -------
   const int64_t tb1 = (int64_t)kTile * p->q_ss * 2, tb2 = (int64_t)kTile * p->do_ss * 2;     // bytes per tile step
@@ -211,8 +218,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
   float st_lse = 0.f, st_delta = 0.f;
   bool st_in = false;
   const bool stat_wave = wave == kB64_STATW;  // the wave that stages the tile's statistics (a role-A wave: the branch around its loads breaks role B's register allocation)
-  {                                              // base the cursors on head h0, tile t_begin
-    const int h = h0;
+  auto pf_head = [&](int h) {                    // base the cursors on query head h, tile t_begin (scalar work only)
     // (the cursors point at this wave's groups: 16 gq / 16 gd rows into the tile)
     q_cur = p->q + 2 * (b * p->q_sb + h * p->q_sh) + t_begin * tb1 + (int64_t)gq * 16 * q_rowb;
     do_cur = p->dout + 2 * (b * p->do_sb + h * p->do_sh) + t_begin * tb2 + (int64_t)gd * 16 * do_rowb;
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
     lse_h = p->lse + b * p->lse_sb + h * p->lse_sh;
     dl_h = p->delta + b * p->dl_sb + h * p->dl_sh;
     st_row = t_begin * kTile;
-  }
+  };
   u32x4 q_rs, do_rs;
   int dma_buf = 0;
   // open the cursor's tile for LDS buffer `buf` (descriptors) and advance the cursor: scalar work only, no branch -- it
@@ -278,18 +284,6 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dkdv64_kernel(const BwdParam
       for (int r = 0; r < 16; ++r) acc[kb][dj][r] = 0.f;
       pin_agpr(acc[kb][dj]);
     }
-
-  stats_fetch();
-  dma_open(0);
-#pragma unroll
-  for (int n = 0; n < 4; ++n) dma_piece(n);
-  if (role == 1) {
-#pragma unroll
-    for (int n = 4; n < 12; ++n) dma_piece(n);
-  }
-  dma_drain();
-  stats_store(0);
-  __syncthreads();
 
   // The streaming loop is instantiated per role, with ROLE a compile-time constant, and the role is chosen by ONE branch
   // around the whole loop: both roles execute the same barrier sequence (n_iter + 1 barriers: role B works one tile
@@ -517,20 +511,42 @@ USP_TM(
   // (the vmcnt(0) in front of every loop: hipcc reloads spilled registers -- VMEM loads -- on the way here, and what it
   // still counts as pending at a loop header it waits for at the first use INSIDE the loop, in every iteration; with the
   // statistics wave's fresh loads in flight that is a memory round trip per tile)
+  // a head's first tile: cursors, descriptors, all of the tile's pieces, the barrier that publishes it (every wave is past the
+  // barrier that ended the head in front: nobody reads a buffer or a P slot any more)
+  auto open_head = [&](int h) {
+    pf_head(h);
+    stats_fetch();
+    dma_open(0);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) dma_piece(n);
+    if (role == 1) {
+#pragma unroll
+      for (int n = 4; n < 12; ++n) dma_piece(n);
+    }
+    dma_drain();
+    stats_store(0);
+    __syncthreads();
+    tile_cur = t_begin; buf_a = 0; buf_b = NBUF - 1;
+  };
   if (role == 0) {
-    int it = 0;
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    for (; it < n_mask; ++it) step(rA, masked, it, true);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    for (; it < n_iter; ++it) step(rA, plain, it, true);
-    mfma_settle(acc);            // (whatever hipcc does with the accumulators behind the loop, it does behind these wait states)
-    step(rA, plain, n_iter, false);
+    for (int hh = 0; hh < gsub; ++hh) {            // head by head: the diagonal tiles first, then the plain ones
+      open_head(h0 + hh);
+      int it = 0;
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      for (; it < n_mask; ++it) step(rA, masked, it, true);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      for (; it < n_iter; ++it) step(rA, plain, it, true);
+      mfma_settle(acc);          // (whatever hipcc does with the accumulators behind the loop, it does behind these wait states)
+      step(rA, plain, n_iter, false);
+    }
   } else {
-    tile_cur = t_begin;
-    step(rB, plain, 0, false);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    for (int it = 1; it <= n_iter; ++it) step(rB, plain, it, true);
-    mfma_settle(acc);
+    for (int hh = 0; hh < gsub; ++hh) {
+      open_head(h0 + hh);
+      step(rB, plain, 0, false);
+      __builtin_amdgcn_s_waitcnt(0x0f70);
+      for (int it = 1; it <= n_iter; ++it) step(rB, plain, it, true);
+      mfma_settle(acc);
+    }
   }
 
   // ---- epilogue -----------------------------------------------------------------------------------------------------------
@@ -559,7 +575,7 @@ USP_TM(
       char* o16 = nullptr;
       int accf;
       const float mul = role == 0 ? 1.f : p->scale;
-      if (p->split) {
+      if (p->split) {                            // partial slab of (head run, cut)
         const int64_t wo = (((int64_t)(g * p->qsplit + cut) * p->ws_rows + (int64_t)b * p->Sk + orow) * p->Hkv + hkv) * D;
         o32 = (role == 0 ? p->ws_dv : p->ws_dk) + wo; accf = 0;
       } else if (role == 0) {
@@ -595,7 +611,6 @@ bool dkdv64_serves(const BwdParams& p_in, int dtype) {
   if (p_in.seq_q || p_in.seq_k || p_in.sched || p_in.win_on) return false;
   // (fp16: round 4's first build of that instantiation copied accumulators between the register files inside the loop; with the
   // chains started from the row constants it compiles like the bf16 one -- tools/mfma_hazards.py: 0 -- and is served here too)
-  if (!p_in.split && p_in.G > 1) return false;   // the in-workgroup loop over a GQA group's heads stays with the 8-wave kernel
   // role A keeps K * scale * log2(e) in the 16-bit type: with fp16 an unusually large softmax scale could overflow it
   if (dtype != USP_BF16 && !(p_in.scale_log2 <= 8.f)) return false;
   // the pieces' swizzle is XORed into the per-lane byte offset (row part a multiple of 256 bytes); per-lane offsets and the
@@ -619,7 +634,7 @@ bool launch_dkdv64(const BwdParams& p_in, int dtype, bool causal, hipStream_t st
   p.wide16 = ((p.dk16 && !p.accum_dk && rows16_aligned(p.dk16, p.dk16_sb, p.dk16_ss, p.dk16_sh)) ? 2 : 0) |
              ((p.dv16 && !p.accum_dv && rows16_aligned(p.dv16, p.dv16_sb, p.dv16_ss, p.dv16_sh)) ? 4 : 0);
   p.nblk = (p.Sk + 127) / 128;
-  p.n_items = p.B * p.Hkv * p.nblk * (p.split ? p.G : 1) * p.qsplit;
+  p.n_items = p.B * p.Hkv * p.nblk * p.ngrp * p.qsplit;
   // persistent: one workgroup per CU; USP_LAUNCH_INTERLEAVE: one workgroup per item (the same kernel: a workgroup's item
   // list then has one entry)
   const int grid = (!p.interleave && p.n_items > cus) ? cus : p.n_items;

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libusp_hip.so does not export {name}"
     assert set(_C.EXPORTS) == declared
     L = _C.load()
-    assert L.usp_abi_version() == _C.ABI_VERSION == 6
+    assert L.usp_abi_version() == _C.ABI_VERSION == 7
     assert L.usp_last_launch_kinds() == 0                        # nothing launched on this thread
     assert b"head_dim" in L.usp_strerror(-2)
 
