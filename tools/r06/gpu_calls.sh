@@ -23,4 +23,23 @@ unset USP_KBENCH_FLAGS
 timeout 300 $K bwd 1 65536 65536 32 4 128 1 0 0 3 2>&1 | grep TIME | tee gpurun_out/r06/01_bwd_64k_default.log
 }
 
+# the driver's command on the tree with the GQA loop + the whole GPU suite with per-file durations
+run02_bench_tests() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
+( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/r06/02_bench.log 2>&1
+grep -E "^\{" gpurun_out/r06/02_bench.log > gpurun_out/r06/02_bench_line.json
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r06/02_bench_line.json"))
+r = d["roofline"]
+print("ms_per_step", d["ms_per_step"], "value", d["value"], "frac", d.get("frac_of_mfma_roofline"))
+print("step", {k: r["step"][k] for k in ("fwd_ms", "delta_ms", "dkdv_ms", "dq_ms", "bwd_frac", "frac")})
+print("kinds", r["kernels_launched"], "ceiling", r["mfma_ceiling"]["sustained_ceiling_TFLOPs"])
+print("family", r["layer_step_ms_by_kernel_family"]["row64"], r["layer_step_ms_by_kernel_family"]["wave32"], "c2", r["c2"]["bwd_ms"], r["c2"]["fwd_kernel_ms"])
+print("parity", r["sampled_parity"]["max_err_over_tolerance"])
+PY
+( time timeout 1500 python -m pytest tests -m gpu -q -x --durations=25 2>&1 | tail -60 ) > gpurun_out/r06/02_pytest_gpu.log 2>&1
+tail -45 gpurun_out/r06/02_pytest_gpu.log
+}
+
 "$@"
