@@ -213,7 +213,12 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
                                     alibi_slopes=None, deterministic=False,
                                     attn_type: AttnType = AttnType.HIP, overlap=False, tail=None, first=None):
     """`first` = (u, dO of the owned chunk, wait): dO is still in flight (see the forward); step 0 starts on the owned
-    rows (zigzag_bwd_step0_split).  Ring degree > 1 only."""
+    rows (zigzag_bwd_step0_split).  Ring degree > 1 only.  Ordering differs from the forward's: k and v are SAVED tensors
+    here, so travel_dkdv enters the K/V relay -- which posts the ring's transfers -- BEFORE block(0) calls `wait()` on the dO
+    exchange; the ring's and the Ulysses communicator therefore have transfers in flight together from step 0 on (in the forward
+    the ring's transfers read exchanged tensors and are posted behind the wait).  Correct either way -- nothing the relay moves
+    depends on dO -- and exercised through RCCL on one-device virtual grids only (tests/test_gpu_rccl_order.py); a first run on
+    real devices that stalls here should set USP_SELF_CHUNK=0."""
     assert causal == True, "zigzag ring is meaningless for causal=False"
     P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
