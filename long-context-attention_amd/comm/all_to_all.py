@@ -120,6 +120,20 @@ def pack_seq_into(send: Tensor, h0: int, x: Tensor) -> None:
     _copy_rows(dst, base, h * D, (P * Sl, B), (B * Ht * D, Ht * D), (x.stride(1), x.stride(0)))
 
 
+def pack_seq_rows(x: Tensor, P: int, lo: int, hi: int) -> Tensor:
+    """Rows [lo, hi) of EVERY destination's chunk of (B, S, h, D) -> a send buffer (P, hi - lo, B, h, D) of its own: one piece
+    of a row-chunked sequence-scatter exchange (hybrid/async_attn_layer.py: tails).  Destination p owns rows [p S/P, (p+1) S/P)."""
+    B, S, h, D = x.shape
+    assert S % P == 0 and 0 <= lo < hi <= S // P
+    Sl, n = S // P, hi - lo
+    if x.stride(3) != 1 or x.stride(2) != D:
+        x = x.contiguous()
+    send = torch.empty((P, n, B, h, D), dtype=x.dtype, device=x.device)
+    base = x.as_strided((1,), (1,), x.storage_offset() + lo * x.stride(1))
+    _copy_rows(send, base, h * D, (P, n, B), (n * B * h * D, B * h * D, h * D), (Sl * x.stride(1), x.stride(1), x.stride(0)))
+    return send
+
+
 def view_seq(recv: Tensor) -> Tensor:
     """receive buffer (P, S/P, B, H/P, D) -> (B, S, H/P, D) strided view (no copy)."""
     P, Sl, B, hp, D = recv.shape

@@ -26,7 +26,7 @@ from ..kernels import AttnType
 from ..ring.ring_flash_attn import ring_flash_attn_backward, ring_flash_attn_forward
 from ..ring.stripe_flash_attn import stripe_flash_attn_backward, stripe_flash_attn_forward
 from ..ring.utils import _side_stream
-from ..ring.zigzag_ring_flash_attn import (_check_hot_path_args, zigzag_ring_flash_attn_backward,
+from ..ring.zigzag_ring_flash_attn import (_check_hot_path_args, zigzag_forward_phases, zigzag_ring_flash_attn_backward,
                                            zigzag_ring_flash_attn_forward)
 
 _RING_FWD_BWD = {
@@ -116,8 +116,15 @@ def pipeline_mode(ring_degree: int) -> bool:
     return _PIPELINE_BESIDE_RING_DEFAULT
 
 
+# Round 5 built the self-chunk start opt-in; round 6 made it the default once it was green through the gloo grids (2 x 1, 2 x 2,
+# 2 x 4), two processes on one GPU and both bench workloads at full size on the RCCL virtual grid -- it costs <= 0.15 ms of
+# kernel time per iteration at the 8-GPU grid and hides the first exchange of each pass (tools/link_model.py).  Like every
+# multi-GPU default of this package it has never met two devices: USP_SELF_CHUNK=0 (or USP_SAFE_COMM=1) is the way back.
+_SELF_CHUNK_DEFAULT = "1"
+
+
 def self_chunk_mode(P: int, ring: int, causal, impl: str, rows_local: int) -> bool:
-    """Does the FIRST head group start on the rows this rank already holds (USP_SELF_CHUNK=1; round 5, opt-in)?
+    """Does a head group start on the rows this rank already holds (USP_SELF_CHUNK; round 5: opt-in, round 6: the default)?
 
     At ulysses degree 2 half of every exchanged tensor is the self chunk: a rank's own rows of the heads it will own never
     cross a link.  Causal attention over those rows alone is a complete sub-block of the group's work -- rank 0 (rows [0, c)):
@@ -131,12 +138,31 @@ def self_chunk_mode(P: int, ring: int, causal, impl: str, rows_local: int) -> bo
     delivers exactly one zigzag chunk, rank u = 0 owns the front chunk and u = 1 the back one -- and the ring's K/V
     transfers, which read the exchanged tensors, are posted behind the wait (ring/zigzag_ring_flash_attn.py: `first`).
     Results equal the unsplit launch up to fp32 summation order (the merge is the ring's own)."""
-    mode = _COMM_OVERRIDE.get("self_chunk", os.environ.get("USP_SELF_CHUNK", "0"))
+    mode = _COMM_OVERRIDE.get("self_chunk", os.environ.get("USP_SELF_CHUNK", _SELF_CHUNK_DEFAULT))
     if str(mode) not in ("1", "True"):
         return False
     if not (P == 2 and bool(causal) and rows_local >= 1):
         return False
     return impl in ("basic", "zigzag") if ring == 1 else impl == "zigzag"
+
+
+def tails_mode(P: int, ring: int, causal, impl: str, rows_local: int, pipelined: bool) -> int:
+    """Row pieces of the LAST head group's output exchange (0: one exchange behind the group's last kernel, rounds 1-5).
+
+    The head-group pipeline hides every exchange but the first input and the last output of a pass.  The last output waits
+    for the last launch of the last group's ring schedule -- and that launch finalises the very rows that travel (a zigzag
+    step s > r updates the back chunk; at ulysses degree 2 the back chunk is what ulysses rank 0 sends).  With tails that
+    launch runs in n row pieces (ring/zigzag_ring_flash_attn.py:_final_rows; every piece cut along K so that it still fills
+    the part) and piece j's rows leave in an exchange of their own while piece j + 1 computes: 1 / n of the exchange stays
+    exposed.  The BACKWARD's counterpart needs no pieces: the last ring step issues its dQ launch first and dq -- 4/5 of the
+    gradient exchange's bytes at G = 8 -- travels beside the step's dK/dV launch (`dq_first`); what stays exposed is the last
+    dK/dV hop and the small dk | dv exchange.  Ulysses degree 2 beside a zigzag ring (the 8-GPU grid), pipelined mode only (in
+    the safe mode a second communicator must not start inside a ring pass); USP_TAILS=0 | n overrides (default 4)."""
+    mode = _COMM_OVERRIDE.get("tails", os.environ.get("USP_TAILS", "4"))
+    n = int(mode)
+    if n <= 0 or not (P == 2 and ring > 1 and bool(causal) and impl == "zigzag" and pipelined) or safe_comm():
+        return 0
+    return max(1, min(n, rows_local // 64)) if "tails" not in _COMM_OVERRIDE else max(1, min(n, rows_local))
 
 
 def _self_views(send, u, splits):
@@ -339,15 +365,17 @@ def _to_heads_issue(lane, xs, P, group):
 
 
 def _grads_to_heads_issue(lane, dq, dk, dv, tail, P, group):
-    """ONE exchange dq | dk | dv of a head group back to sequence sharding, with the ring backward's LAST dK/dV hop
+    """ONE exchange dq | dk | dv of a head group back to sequence sharding (dq None: dk | dv alone -- dq went ahead in an
+    exchange of its own, `dq_first`), with the ring backward's LAST dK/dV hop
     still in flight (`tail`: the pending RingComm of travel_dkdv's `defer`): dq is packed on the compute stream, which
     then goes on to the next group's kernels; the lane waits for the hop, packs dk and dv behind it and runs the
     collective.  What the compute stream used to wait for (16 MiB of fp32 per KV head over one link, 0.26 ms at 64 GB/s
     per group at BASELINE's 8-GPU config) now runs beside the next group's first ring step."""
-    B, S, hq, D = dq.shape
-    kvh = dk.shape[2]
-    send = torch.empty((P, S // P, B, hq + 2 * kvh, D), dtype=dq.dtype, device=dq.device)
-    A.pack_seq_into(send, 0, dq)
+    B, S, kvh, D = dk.shape
+    hq = 0 if dq is None else dq.shape[2]
+    send = torch.empty((P, S // P, B, hq + 2 * kvh, D), dtype=dk.dtype, device=dk.device)
+    if dq is not None:
+        A.pack_seq_into(send, 0, dq)
 
     def before(side):
         for comm in tail:
@@ -380,38 +408,73 @@ class _AsyncUSPFunc(torch.autograd.Function):
         if softmax_scale is None:
             softmax_scale = D ** (-0.5)
         overlap = ng > 1                # kernels run beside later groups' exchanges
-        split0 = self_chunk_mode(P, ring, causal, impl, Sl)          # the first group starts on this rank's own rows
+        split0 = self_chunk_mode(P, ring, causal, impl, Sl)          # groups start on this rank's own rows
         u = dist.get_rank(ulysses_pg) if split0 else 0
+        n_tail = tails_mode(P, ring, causal, impl, Sl, ng_cap is None or ng_cap > 1)
         saved, outs = [], []
         with _Lane(q) as lane:
             # every input exchange is queued before any attention runs
             ins = [_qkv_to_seq(lane, q, k, v, P, ng, kvh, g, i, ulysses_pg) for i in range(ng)]
+            pieces = []                       # the last group's output exchange in row pieces: (recv, event, lo, hi)
+
+            def tail_of(i):
+                if not n_tail or i != ng - 1:
+                    return None
+
+                def emit(j, out_i):           # piece j of both chunks is final on this stream: its exchange starts now
+                    lo, hi = j * Sl // n_tail, (j + 1) * Sl // n_tail
+                    if hi > lo:
+                        pieces.append(lane.exchange(A.pack_seq_rows(out_i, P, lo, hi), ulysses_pg) + (lo, hi))
+                return n_tail, emit
+            # Beside a ring EVERY group's owned chunk is launched before the first wait (round 6; round 5: the first group's):
+            # the first exchange of the pass takes longer than one group's owned chunk (0.33 against 0.12 ms at the 8-GPU
+            # grid and 64 GB/s), and the other groups' owned chunks are the only other work that needs no exchanged byte.
+            gens = {}
+            if split0 and ring > 1:
+                for i in range(ng):
+                    (qi, ki, vi), ev, send_i = ins[i]
+                    own = _self_views(send_i, u, (kvh * g, kvh, kvh))
+                    gens[i] = zigzag_forward_phases(ring_pg, qi, ki, vi, softmax_scale, overlap,
+                                                    (u, own, lambda ev=ev: lane.wait(ev)), tail_of(i))
+                    next(gens[i])             # allocations + the launch on the owned chunk; stops in front of the wait
             for i in range(ng):
                 (qi, ki, vi), ev, send_i = ins[i]
-                if split0 and i == 0:
+                if i in gens:                 # the rest of the ring schedule, behind this group's exchange
+                    try:
+                        next(gens[i])
+                        raise AssertionError("zigzag_forward_phases yields once")
+                    except StopIteration as done:
+                        oi, lse_i = done.value
+                elif split0 and i == 0:       # ring degree 1: the one causal block, split in the layer
                     from ..kernels.attention import get_block_backend
                     own = _self_views(send_i, u, (kvh * g, kvh, kvh))
-                    if ring == 1:
-                        oi, lse_i = _split_first_forward(get_block_backend(beside_transfers=True), u, own, (qi, ki, vi),
-                                                         lambda ev=ev: lane.wait(ev), softmax_scale)
-                    else:        # step 0 of the ring schedule starts on the owned chunk
-                        oi, lse_i = fwd(ring_pg, qi, ki, vi, softmax_scale=softmax_scale, causal=causal, overlap=overlap,
-                                        first=(u, own, lambda ev=ev: lane.wait(ev)))
-                    saved += [qi, ki, vi, oi, lse_i]
-                    outs.append(_to_heads_issue(lane, [oi], P, ulysses_pg))
-                    continue
-                lane.wait(ev)
-                oi, lse_i = fwd(ring_pg, qi, ki, vi, softmax_scale=softmax_scale, causal=causal, overlap=overlap)
+                    oi, lse_i = _split_first_forward(get_block_backend(beside_transfers=True), u, own, (qi, ki, vi),
+                                                     lambda ev=ev: lane.wait(ev), softmax_scale)
+                else:
+                    lane.wait(ev)
+                    t = tail_of(i)
+                    kw = {} if t is None else {"tail": t}
+                    oi, lse_i = fwd(ring_pg, qi, ki, vi, softmax_scale=softmax_scale, causal=causal, overlap=overlap, **kw)
                 saved += [qi, ki, vi, oi, lse_i]
-                outs.append(_to_heads_issue(lane, [oi], P, ulysses_pg))
+                if n_tail and i == ng - 1:
+                    outs.append(None)         # (travelled in `pieces`)
+                else:
+                    outs.append(_to_heads_issue(lane, [oi], P, ulysses_pg))
             out = torch.empty((B, Sl, Hq, D), dtype=q.dtype, device=q.device)
             o5 = out.view(B, Sl, P, ng, kvh * g, D)
-            for i, (recv, ev) in enumerate(outs):
+            for i, pending in enumerate(outs):
+                if pending is None:
+                    for recv, ev, lo, hi in pieces:
+                        lane.wait(ev)
+                        A.unpack_head_group(recv, o5[:, lo:hi, :, i])
+                    continue
+                recv, ev = pending
                 lane.wait(ev)
                 A.unpack_head_group(recv, o5[:, :, :, i])
         ctx.save_for_backward(*saved)
         ctx.meta = (softmax_scale, causal, ulysses_pg, ring_pg, impl, P, ng, kvh, g, Hq, Hkv)
         ctx.split0 = (split0, u, ring)
+        ctx.n_tail = n_tail
         return out
 
     @staticmethod
@@ -425,9 +488,14 @@ class _AsyncUSPFunc(torch.autograd.Function):
             douts = [_to_seq(lane, dout, P, ng, kvh * g, i, ulysses_pg) for i in range(ng)]
             pend = []
             split0, u, ring = getattr(ctx, "split0", (False, 0, 1))
+            n_tail = getattr(ctx, "n_tail", 0)
             for i in range(ng):
                 qi, ki, vi, oi, lse_i = saved[5 * i:5 * i + 5]
                 doi, ev, send_i = douts[i]
+                kw = {}
+                dq_sent = []
+                if n_tail and i == ng - 1:     # the last group: dq leaves between the last step's two launches (tails_mode)
+                    kw["dq_first"] = lambda dq16: dq_sent.append(_to_heads_issue(lane, [dq16], P, ulysses_pg))
                 if split0 and i == 0:
                     from ..kernels.attention import get_block_backend
                     do_own = _self_views(send_i, u, (kvh * g,))[0]
@@ -437,21 +505,32 @@ class _AsyncUSPFunc(torch.autograd.Function):
                                                               lambda ev=ev: lane.wait(ev), qi, ki, vi, oi, lse_i, softmax_scale)
                     else:
                         dqi, dki, dvi = bwd(ring_pg, doi, qi, ki, vi, oi, lse_i, softmax_scale=softmax_scale, causal=causal,
-                                            overlap=overlap, tail=tail, first=(u, do_own, lambda ev=ev: lane.wait(ev)))
-                    pend.append(_grads_to_heads_issue(lane, dqi, dki, dvi, tail, P, ulysses_pg))
-                    continue
-                lane.wait(ev)
-                tail = []                      # the ring backward's last dK/dV hop, left pending (ring/utils.py:travel_dkdv)
-                dqi, dki, dvi = bwd(ring_pg, doi, qi, ki, vi, oi, lse_i, softmax_scale=softmax_scale,
-                                    causal=causal, overlap=overlap, tail=tail)
-                pend.append(_grads_to_heads_issue(lane, dqi, dki, dvi, tail, P, ulysses_pg))   # ONE exchange: dq | dk | dv
+                                            overlap=overlap, tail=tail, first=(u, do_own, lambda ev=ev: lane.wait(ev)), **kw)
+                else:
+                    lane.wait(ev)
+                    tail = []                  # the ring backward's last dK/dV hop, left pending (ring/utils.py:travel_dkdv)
+                    dqi, dki, dvi = bwd(ring_pg, doi, qi, ki, vi, oi, lse_i, softmax_scale=softmax_scale,
+                                        causal=causal, overlap=overlap, tail=tail, **kw)
+                if dq_sent:                    # two exchanges: dq (posted inside the ring backward), then dk | dv
+                    pend.append((dq_sent[0], _grads_to_heads_issue(lane, None, dki, dvi, tail, P, ulysses_pg)))
+                else:
+                    pend.append(_grads_to_heads_issue(lane, dqi, dki, dvi, tail, P, ulysses_pg))   # ONE exchange: dq | dk | dv
             dq = torch.empty((B, Sl, Hq, D), dtype=dout.dtype, device=dout.device)
             dk = torch.empty((B, Sl, Hkv, D), dtype=dout.dtype, device=dout.device)
             dv = torch.empty_like(dk)
             q5 = dq.view(B, Sl, P, ng, kvh * g, D)
             k5, v5 = dk.view(B, Sl, P, ng, kvh, D), dv.view(B, Sl, P, ng, kvh, D)
             hq = kvh * g
-            for i, (recv, ev) in enumerate(pend):
+            for i, item in enumerate(pend):
+                if isinstance(item[0], tuple):          # (dq exchange, dk | dv exchange)
+                    (rq, eq), (recv, ev) = item
+                    lane.wait(eq)
+                    A.unpack_head_group(rq, q5[:, :, :, i], 0)
+                    lane.wait(ev)
+                    A.unpack_head_group(recv, k5[:, :, :, i], 0)
+                    A.unpack_head_group(recv, v5[:, :, :, i], kvh)
+                    continue
+                recv, ev = item
                 lane.wait(ev)
                 A.unpack_head_group(recv, q5[:, :, :, i], 0)
                 A.unpack_head_group(recv, k5[:, :, :, i], hq)

@@ -78,17 +78,17 @@ class HipBlockBackend:
         return self._beside
 
     def fwd(self, q, k, v, softmax_scale, causal, lse, out=None, acc=None, merge_in=False,
-            final_begin=0, final_end=None, window=None):
+            final_begin=0, final_end=None, window=None, k_splits=None):
         _C.flash_fwd(q, k, v, softmax_scale, causal, lse, out, acc, merge_in, final_begin, final_end,
-                     interleave=self.interleave, window=window)
+                     interleave=self.interleave, window=window, k_splits=k_splits)
 
     def delta(self, dout, out, delta):
         _C.bwd_delta(dout, out, delta)
 
     def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
-            accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None, window=None):
+            accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None, window=None, only=None):
         _C.flash_bwd(dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq,
-                     accum_dk, accum_dv, dq16, dk16, dv16, interleave=self.interleave, window=window)
+                     accum_dk, accum_dv, dq16, dk16, dv16, interleave=self.interleave, window=window, only=only)
 
     def fwd_packed(self, q, k, v, seq_q, seq_k, max_q, max_k, softmax_scale, causal, lse, out=None,
                    acc=None, merge_in=False, final_begin=0, final_end=2):

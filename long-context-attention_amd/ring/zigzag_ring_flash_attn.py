@@ -99,18 +99,26 @@ def zigzag_bwd_step0_split(be, u, do_own, dout, wait, q, kk, vv, out, lse, delta
 
 
 def zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, dk_dst,
-                     dv_dst):
+                     dv_dst, only=None, dq16=None):
     """Block backward of ring step `step`: dq accumulates in place into dq_acc (fp32), the dK/dV
-    block is written to dk_dst/dv_dst (fp32; at step 0 these ARE the travelling accumulators)."""
+    block is written to dk_dst/dv_dst (fp32; at step 0 these ARE the travelling accumulators).
+    `only` = "dq" | "dkdv": just that launch of the two (steps > 0).  `dq16` (with only="dq"; the LAST step): dq is final
+    behind this launch -- accumulator + block, rounded in the epilogue into dq16's rows; the rows this step does not touch
+    are cast from the accumulator."""
     c = q.shape[1] // 2
+    kw = {} if only is None else {"only": only}
+    nz = lambda t, sl: None if t is None else t[:, sl]
     if step == 0:                                   # zigzag_ring_flash_attn.py:145-149
+        assert only is None
         be.bwd(dout, q, kk, vv, lse, delta, dq_acc, dk_dst, dv_dst, softmax_scale, True)
     elif step <= r:                                 # :151-155
-        be.bwd(dout, q, kk[:, :c], vv[:, :c], lse, delta, dq_acc, dk_dst[:, :c], dv_dst[:, :c],
-               softmax_scale, False, accum_dq=True)
+        be.bwd(dout, q, kk[:, :c], vv[:, :c], lse, delta, dq_acc, nz(dk_dst, slice(0, c)), nz(dv_dst, slice(0, c)),
+               softmax_scale, False, accum_dq=True, dq16=dq16, **kw)
     else:                                           # :156-159
-        be.bwd(dout[:, c:], q[:, c:], kk, vv, lse[:, :, c:], delta[:, :, c:], dq_acc[:, c:], dk_dst,
-               dv_dst, softmax_scale, False, accum_dq=True)
+        if dq16 is not None:
+            be.cast(dq16[:, :c], dq_acc[:, :c])     # final since step r
+        be.bwd(dout[:, c:], q[:, c:], kk, vv, lse[:, :, c:], delta[:, :, c:], nz(dq_acc, slice(c, None)), dk_dst,
+               dv_dst, softmax_scale, False, accum_dq=True, dq16=nz(dq16, slice(c, None)), **kw)
 
 
 def zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk):
@@ -155,16 +163,43 @@ def zigzag_fetch_plan(P, r, pieces, c, grouped=False):
     return plan
 
 
-def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, causal=True,
-                                   window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
-                                   deterministic=False, attn_type: AttnType = AttnType.HIP, overlap=False, first=None):
-    """`overlap`: the caller has transfers of its own in flight (pipelined Ulysses exchange), so the kernels are
-    launched so that collectives can run beside them even at ring degree 1.
-    `first` = (u, (q, k, v) of the owned chunk, wait): q / k / v are still in flight (the caller's Ulysses exchange at degree
-    2; `wait()` orders the calling stream behind it) and step 0 starts on the chunk this rank owns (zigzag_fwd_step0_own).
-    The K/V transfers of the ring are posted BEHIND the wait -- they read the exchanged k / v -- i.e. no later than without
-    the split, where everything waits for the exchange.  Ring degree > 1 only (degree 1: _split_first_forward)."""
-    assert causal == True, "zigzag ring is meaningless for causal=False"
+def tail_k_splits(B, H, rows, keys):
+    """K cuts of a row-chunked tail launch (forward; non-causal, merge mode): a chunk of `rows` query rows has B * H *
+    ceil(rows / 256) work items, every one as long as the others -- below one per CU the idle CUs are filled by cutting every
+    item's keys (usp_fwd_args.k_splits; cuts of at least 1024 keys, the merge launch costs a few microseconds)."""
+    from ..comm.link import device_cus
+    items = B * H * ((rows + 255) // 256)
+    n = min(8, device_cus() // max(1, items), keys // 1024)
+    return n if n > 1 else 0
+
+
+def _final_rows(be, q, kp, vp, softmax_scale, lse, out, acc, lo, hi, tail):
+    """The launch that FINALISES rows [lo, hi) of the block (a full, merge-mode launch against kp / vp; [lo, hi) is the whole
+    block or its back half): all of them emitted in 16 bits.  With `tail` = (n, emit) it is n launches over row pieces
+    instead -- piece j of every c-row chunk in [lo, hi) -- and `emit(j, out)` is called behind the launches of piece j: from then on
+    rows [chunk * c + j c / n, chunk * c + (j + 1) c / n) of EVERY chunk of the block are final on the calling stream, and the
+    caller's output exchange of those rows runs beside the launches of the pieces that follow (hybrid/async_attn_layer.py:
+    row-chunked tails; the last-out exchange of a pass is the one no head-group pipeline can hide)."""
+    if tail is None:
+        be.fwd(q[:, lo:hi] if (lo, hi) != (0, q.shape[1]) else q, kp, vp, softmax_scale, False, lse[:, :, lo:hi], out[:, lo:hi], acc[:, lo:hi],
+               True, 0, hi - lo)
+        return
+    n, emit = tail
+    c = q.shape[1] // 2
+    B, _, H, _ = q.shape
+    for j in range(n):
+        for ch in range(lo // c, hi // c):
+            a, b = ch * c + j * c // n, ch * c + (j + 1) * c // n
+            if b > a:
+                be.fwd(q[:, a:b], kp, vp, softmax_scale, False, lse[:, :, a:b], out[:, a:b], acc[:, a:b], True, 0, b - a,
+                       k_splits=tail_k_splits(B, H, b - a, kp.shape[1]))
+        emit(j, out)
+
+
+def zigzag_forward_phases(process_group, q, k, v, softmax_scale, overlap=False, first=None, tail=None):
+    """The zigzag ring forward as a generator of two phases.  With `first` it yields ONCE, behind the launch on the owned chunk
+    and in front of the wait for the caller's exchange -- the caller may start other head groups' owned chunks there -- and
+    returns (out, lse) through StopIteration; without `first` it never yields.  zigzag_ring_flash_attn_forward drives it to the end."""
     P, r = group_info(dist, process_group)
     be = get_block_backend(beside_transfers=P > 1 or overlap)
     B, S2, H, D = q.shape
@@ -176,9 +211,11 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
         be.fwd(q, k, v, softmax_scale, True, lse, out)
         return out, lse
     acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev)
+    c = S2 // 2
     if first is not None:
         u, own, wait = first
         zigzag_fwd_step0_own(be, r, u, own, softmax_scale, lse, out, acc)
+        yield
         wait()
 
     def step0():
@@ -188,12 +225,14 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
             zigzag_fwd_step(be, r, P, 0, q, k, v, softmax_scale, lse, out, acc)
 
     if P > 2 and kv_relay_mode(P) == "direct":      # mesh fetch in waves, only the halves the schedule reads
-        c = S2 // 2
         with ZigzagKVFetch(process_group, k, v, zigzag_fetch_pieces(k)) as fetch:
             step0()
-            for w, lo, hi, all_rows, fe in zigzag_fetch_plan(P, r, fetch.pieces, c, fetch.grouped):
+            plan = zigzag_fetch_plan(P, r, fetch.pieces, c, fetch.grouped)
+            for i, (w, lo, hi, all_rows, fe) in enumerate(plan):
                 kp, vp = fetch.get_range(w, lo, hi) if fetch.grouped else fetch.get(w, lo)
-                if all_rows:
+                if tail is not None and i == len(plan) - 1:       # the last launch of all finalises every row it computes
+                    _final_rows(be, q, kp, vp, softmax_scale, lse, out, acc, 0 if all_rows else c, S2, tail)
+                elif all_rows:
                     be.fwd(q, kp, vp, softmax_scale, False, lse, out, acc, True, 0, fe)
                 else:
                     be.fwd(q[:, c:], kp, vp, softmax_scale, False, lse[:, :, c:], out[:, c:], acc[:, c:], True, 0, fe)
@@ -203,16 +242,45 @@ def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropou
             kk, vv = relay.get(step)
             if step == 0:
                 step0()
+            elif tail is not None and step == P - 1:              # (step <= r: every row x the front keys; else the back rows)
+                if step <= r:
+                    _final_rows(be, q, kk[:, :c], vv[:, :c], softmax_scale, lse, out, acc, 0, S2, tail)
+                else:
+                    _final_rows(be, q, kk, vv, softmax_scale, lse, out, acc, c, S2, tail)
             else:
                 zigzag_fwd_step(be, r, P, step, q, kk, vv, softmax_scale, lse, out, acc)
     return out, lse
 
 
+def zigzag_ring_flash_attn_forward(process_group, q, k, v, softmax_scale, dropout_p=0, causal=True,
+                                   window_size=(-1, -1), softcap=0.0, alibi_slopes=None,
+                                   deterministic=False, attn_type: AttnType = AttnType.HIP, overlap=False, first=None, tail=None):
+    """`overlap`: the caller has transfers of its own in flight (pipelined Ulysses exchange), so the kernels are
+    launched so that collectives can run beside them even at ring degree 1.
+    `first` = (u, (q, k, v) of the owned chunk, wait): q / k / v are still in flight (the caller's Ulysses exchange at degree
+    2; `wait()` orders the calling stream behind it) and step 0 starts on the chunk this rank owns (zigzag_fwd_step0_own).
+    The K/V transfers of the ring are posted BEHIND the wait -- they read the exchanged k / v -- i.e. no later than without
+    the split, where everything waits for the exchange.  Ring degree > 1 only (degree 1: _split_first_forward).
+    `tail` = (n, emit): the launch that finalises the last rows runs in n row pieces, `emit(j, out)` behind piece j (_final_rows);
+    ring degree > 1 only."""
+    assert causal == True, "zigzag ring is meaningless for causal=False"
+    gen = zigzag_forward_phases(process_group, q, k, v, softmax_scale, overlap, first, tail)
+    try:
+        while True:
+            next(gen)
+    except StopIteration as done:
+        return done.value
+
+
 def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_lse, softmax_scale,
                                     dropout_p=0, causal=True, window_size=(-1, -1), softcap=0.0,
                                     alibi_slopes=None, deterministic=False,
-                                    attn_type: AttnType = AttnType.HIP, overlap=False, tail=None, first=None):
-    """`first` = (u, dO of the owned chunk, wait): dO is still in flight (see the forward); step 0 starts on the owned
+                                    attn_type: AttnType = AttnType.HIP, overlap=False, tail=None, first=None, dq_first=None):
+    """`dq_first(dq)`: the LAST ring step issues its dQ launch in front of its dK/dV launch and rounds dQ in that launch's
+    epilogue (rows the step does not touch are cast from the accumulator); `dq_first` is called with the final 16-bit dq
+    between the two launches, so that the caller's exchange of dq -- most of the bytes of the gradient exchange -- runs beside
+    the dK/dV launch instead of behind the whole step.  Ring degree > 1 only.
+    `first` = (u, dO of the owned chunk, wait): dO is still in flight (see the forward); step 0 starts on the owned
     rows (zigzag_bwd_step0_split).  Ring degree > 1 only.  Ordering differs from the forward's: k and v are SAVED tensors
     here, so travel_dkdv enters the K/V relay -- which posts the ring's transfers -- BEFORE block(0) calls `wait()` on the dO
     exchange; the ring's and the Ulysses communicator therefore have transfers in flight together from step 0 on (in the forward
@@ -236,10 +304,18 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
         return dq, dk, dv
     dq_acc = torch.empty((B, S2, H, D), dtype=torch.float32, device=dev)
 
+    dq_done = []
+
     def block(step, kk, vv, dk_dst, dv_dst):
         if step == 0 and first is not None:
             u, do_own, wait = first
             zigzag_bwd_step0_split(be, u, do_own, dout, wait, q, kk, vv, out, lse, delta, softmax_scale, dq_acc, dk_dst, dv_dst)
+        elif dq_first is not None and step == P - 1:
+            dq16 = torch.empty((B, S2, H, D), dtype=q.dtype, device=dev)
+            zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, None, None, only="dq", dq16=dq16)
+            dq_first(dq16)
+            dq_done.append(dq16)
+            zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, None, dk_dst, dv_dst, only="dkdv")
         else:
             zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, dk_dst, dv_dst)
 
@@ -249,7 +325,7 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
     # steps s <= rank carry gradients for the front-half K/V rows only (:151-155, :161-170)
     dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be, final_dtype=k.dtype, defer=tail,
                                  extent=lambda rank, step: slice(0, c) if step <= rank else FULL)
-    return final_grads(be, (q, k, v), (dq_acc, dk_acc, dv_acc))
+    return final_grads(be, (q, k, v), (dq_done[0] if dq_done else dq_acc, dk_acc, dv_acc))
 
 
 class ZigZagRingFlashAttnFunc(torch.autograd.Function):

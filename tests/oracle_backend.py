@@ -36,8 +36,8 @@ class OracleBlockBackend:
         self.calls = []
 
     def fwd(self, q, k, v, softmax_scale, causal, lse, out=None, acc=None, merge_in=False,
-            final_begin=0, final_end=None, window=None):
-        Sq = q.shape[1]
+            final_begin=0, final_end=None, window=None, k_splits=None):
+        Sq = q.shape[1]                 # (k_splits: how the device fills its CUs; the result does not depend on it)
         window = (-1, -1) if window is None else window
         fe = Sq if final_end is None else final_end
         for t, what in ((q, "q"), (k, "k"), (v, "v"), (acc, "acc")):
@@ -76,19 +76,23 @@ class OracleBlockBackend:
         _put(delta, np.einsum("bshd,bshd->bhs", _np(dout), _np(out)))
 
     def bwd(self, dout, q, k, v, lse, delta, dq, dk, dv, softmax_scale, causal, accum_dq=False,
-            accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None, window=None):
+            accum_dk=False, accum_dv=False, dq16=None, dk16=None, dv16=None, window=None, only=None):
         window = (-1, -1) if window is None else window
+        assert only in (None, "dq", "dkdv")
         for t, what in ((dout, "dout"), (q, "q"), (k, "k"), (v, "v"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
             _operand(t, what)
         for t, what in ((dq16, "dq16"), (dk16, "dk16"), (dv16, "dv16")):
             _operand(t, what, 8, 8)
         assert q.shape[3] in (32, 64, 128) and q.dtype in (torch.bfloat16, torch.float16) and dout.dtype == q.dtype
         assert lse.dtype == torch.float32 and delta.dtype == torch.float32 and lse.shape == delta.shape
+        wanted = {None: ("dq", "dk", "dv"), "dq": ("dq",), "dkdv": ("dk", "dv")}[only]    # (a skipped launch needs no outputs and touches none)
         for g32, g16, ref, nm in ((dq, dq16, q, "dq"), (dk, dk16, k, "dk"), (dv, dv16, v, "dv")):
+            if nm not in wanted:
+                continue
             assert g32 is not None or g16 is not None, f"{nm}: no destination"
             assert g32 is None or (g32.dtype == torch.float32 and g32.shape == ref.shape), nm
             assert g16 is None or (g16.dtype == q.dtype and g16.shape == ref.shape), nm
-        self.calls.append(("bwd", tuple(q.shape), tuple(k.shape), bool(causal)))
+        self.calls.append(("bwd", tuple(q.shape), tuple(k.shape), bool(causal)) + ((only,) if only else ()))
         # block_bwd derives delta from `out`; feed it an `out` whose rowsum(dout*out) equals the
         # supplied delta is not possible in general, so restate with delta directly:
         qn, kn, vn, don = _np(q), _np(k), _np(v), _np(dout)
@@ -105,8 +109,10 @@ class OracleBlockBackend:
         ds = p * (dp - dl[..., None]) * softmax_scale
         gdq = np.einsum("bhts,bshd->bthd", ds, kk)
         gdk = np.einsum("bhts,bthd->bshd", ds, qn).reshape(B, Sk, Hkv, g, D).sum(3)
-        for dst, d16, val, accum in ((dq, dq16, gdq, accum_dq), (dk, dk16, gdk, accum_dk),
-                                     (dv, dv16, gdv, accum_dv)):
+        for nm, dst, d16, val, accum in (("dq", dq, dq16, gdq, accum_dq), ("dk", dk, dk16, gdk, accum_dk),
+                                         ("dv", dv, dv16, gdv, accum_dv)):
+            if nm not in wanted:
+                continue
             tot = val + _np(dst) if accum else val
             _put(d16 if d16 is not None else dst, tot)
 

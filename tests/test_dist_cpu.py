@@ -166,6 +166,9 @@ def _async_worker(rank, ws, ud, rd, impl, Hq, Hkv):
     truth = [ext(torch.from_numpy(np.ascontiguousarray(t)), rank, world_size=ws, rd=rd, ud=ud).float()
              for t in (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, True))]
     res = []
+    # (the claim is about REGROUPING the exchange: the self-chunk start and the row-chunked tails -- defaults since round 6 --
+    # change the launches and with them the fp32 summation order; they have tests of their own below)
+    AL._COMM_OVERRIDE.update(self_chunk="0", tails="0")
     # the pipelined packed exchange (default), one packed exchange, the reference's three exchanges, the async layer
     # (+ the layer's default and USP_SAFE_COMM=1, which beside a ring are the one-exchange form)
     for cls, env in ((Y.LongContextAttention, {"USP_PIPELINE_ULYSSES": "1"}), (Y.LongContextAttention, {"USP_PIPELINE_ULYSSES": "0"}),
@@ -182,6 +185,7 @@ def _async_worker(rank, ws, ud, rd, impl, Hq, Hkv):
             for key in env:
                 del os.environ[key]
         res.append([t.detach().float() for t in (out, lq.grad, lk.grad, lv.grad)])
+    AL._COMM_OVERRIDE.clear()
     # same maths per head, only the exchange is regrouped: the four must be identical ...
     same = all(torch.equal(a, b) for other in res[1:] for a, b in zip(res[0], other))
     # ... and right (bf16 tolerances of golden_util.TOL: out 2e-2, grads 5e-2)
@@ -268,6 +272,95 @@ def test_self_chunk_start_beside_a_zigzag_ring(rd, Hq, Hkv, B, S, env):
     """The same start at ring degree > 1 (ulysses 2 x ring 2 / 4, zigzag): step 0 of the ring schedule is split, every K/V
     transport (chain relay, mesh fetch) and both dK/dV return forms behind it."""
     assert all(run_distributed(_self_chunk_worker, 2 * rd, "zigzag", Hq, Hkv, B, S, rd, env))
+
+
+def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env):
+    """Row-chunked tails (hybrid/async_attn_layer.py:tails_mode; round 6, default beside a zigzag ring at ulysses degree 2): the
+    LAST head group's last forward launch runs in n row pieces, each followed by an exchange of its rows; the last ring step
+    of its backward issues dQ first and dq travels ahead of dk | dv; beside that, every group's owned chunk is launched in
+    front of the first wait.  Against the schedule without tails and self-chunk (same sums, another order: tight), against
+    exact attention and its gradients; the exchanges must be posted INSIDE the ring pass, in the same number on every rank."""
+    import os
+    import yunchang_amd as Y
+    import yunchang_amd.hybrid.async_attn_layer as AL
+    import yunchang_amd.comm.all_to_all as A
+    import yunchang_amd.ring.zigzag_ring_flash_attn as ZZ
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    from oracle import usp_oracle as O
+    for kv in (env or ()):
+        os.environ.__setitem__(*kv.split("="))
+    be = OracleBlockBackend()
+    set_block_backend(be)
+    Y.set_seq_parallel_pg(2, rd, rank, ws)
+    AL._FILL_ITEMS = 1
+    torch.manual_seed(3)
+    D = 32
+    q, k, v, do = (torch.randn(B, S, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
+    ext = Y.EXTRACT_FUNC_DICT["zigzag"]
+    qn, kn, vn, don = (t.float().numpy().astype(np.float64) for t in (q, k, v, do))
+    ro, rl = O.attention_ref(qn, kn, vn, causal=True)
+    truth = [ext(torch.from_numpy(np.ascontiguousarray(t)), rank, world_size=ws, rd=rd, ud=2).float()
+             for t in (ro,) + tuple(O.block_bwd(don, qn, kn, vn, ro, rl, None, True))]
+    res, log = [], []
+    real_x, real_wait = A._exchange, AL._Lane.wait
+
+    def spy_x(send, group, use_sync):
+        log.append(("exchange", tuple(send.shape), len(be.calls)))
+        return real_x(send, group, use_sync)
+    A._exchange = spy_x
+    AL._Lane.wait = lambda self, ev: (log.append(("wait", len(be.calls))), real_wait(self, ev))[1]
+    counts = []
+    try:
+        for on in (False, True):
+            AL._COMM_OVERRIDE.update(self_chunk="1" if on else "0", tails=str(n) if on else "0")
+            lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=rd, ud=2).detach().clone() for t in (q, k, v, do))
+            for t in (lq, lk, lv):
+                t.requires_grad_(True)
+            log.clear(); be.calls.clear()
+            out = Y.LongContextAttention(ring_impl_type="zigzag")(lq, lk, lv, causal=True)
+            n_fwd_calls = len(be.calls)
+            fwd_log = list(log)
+            log.clear()
+            out.backward(ldo)
+            bwd_log = list(log)
+            res.append([t.detach().float() for t in (out, lq.grad, lk.grad, lv.grad)])
+            fx = [e for e in fwd_log if e[0] == "exchange"]
+            bx = [e for e in bwd_log if e[0] == "exchange"]
+            counts.append((len(fx), len(bx)))
+            if on:
+                ng = Hkv // 2
+                c = S // (2 * rd)
+                pieces = min(n, c)
+                # forward: ng input exchanges, ng - 1 whole output exchanges, `pieces` row pieces of the last group's output,
+                # all but the last piece posted while kernel calls were still to come
+                assert len(fx) == 2 * ng - 1 + pieces, (fx, ng, pieces)
+                assert sum(e[1][1] for e in fx[-pieces:]) == c, fx          # the pieces' rows make up a chunk
+                assert all(e[2] < n_fwd_calls for e in fx[-pieces:-1]) and fx[-1][2] == n_fwd_calls, (fx, n_fwd_calls)
+                # every group's owned chunk is launched in front of the first wait
+                first_wait = next(e for e in fwd_log if e[0] == "wait")
+                assert first_wait[1] >= ng, (fwd_log[:6], ng)
+                # backward: ng input exchanges, ng - 1 packed gradient exchanges, then dq alone and dk | dv alone
+                assert len(bx) == 2 * ng + 1, bx
+                assert bx[-2][1][3] == Hq // Hkv and bx[-1][1][3] == 2, bx
+                only = [c_ for c_ in be.calls if c_[0] == "bwd" and len(c_) == 5]
+                assert [c_[4] for c_ in only] == ["dq", "dkdv"], only
+    finally:
+        AL._COMM_OVERRIDE.clear()
+        A._exchange, AL._Lane.wait = real_x, real_wait
+    close = all(torch.allclose(a, b, atol=tol, rtol=tol) for a, b, tol in zip(res[0], res[1], (8e-3, 3e-2, 3e-2, 3e-2)))
+    right = all(torch.allclose(a, t, atol=tol, rtol=tol) for a, t, tol in zip(res[1], truth, (2e-2, 5e-2, 5e-2, 5e-2)))
+    return close and right, counts[1]
+
+
+@pytest.mark.parametrize("rd,Hq,Hkv,B,S,n,env", [(2, 8, 4, 1, 128, 2, None),                           # chain relay (ring 2), two head groups
+                                                 (4, 8, 4, 1, 256, 4, None),                           # the 8-GPU grid: mesh fetch, grouped launches
+                                                 (4, 8, 2, 2, 256, 3, None),                           # batch 2 (ungrouped pieces), ONE head group, uneven pieces
+                                                 (4, 4, 4, 1, 128, 2, ("USP_KV_RELAY=chain", "USP_DKDV_RETURN=direct"))])
+def test_row_chunked_tails_beside_a_zigzag_ring(rd, Hq, Hkv, B, S, n, env):
+    res = run_distributed(_tails_worker, 2 * rd, rd, Hq, Hkv, B, S, n, env)
+    assert all(r[0] for r in res)
+    assert len({r[1] for r in res}) == 1, "every rank posts the same number of exchanges"
 
 
 @pytest.mark.parametrize("ws,ud,rd,impl,Hq,Hkv", [(4, 2, 2, "zigzag", 8, 4), (2, 2, 1, "basic", 4, 4),
@@ -420,8 +513,10 @@ def test_varlen_ring_matches_exact_attention(ws, impl, lens, Hq, Hkv):
 
 
 # ---- launches inside a ring (or a pipelined exchange) must ask for interleavable launches ---------------------
-def _overlap_worker(rank, ws, ud, rd, use_async, force_groups):
+def _overlap_worker(rank, ws, ud, rd, use_async, force_groups, self_chunk="1"):
     import yunchang_amd as Y
+    import yunchang_amd.hybrid.async_attn_layer as AL0
+    AL0._COMM_OVERRIDE["self_chunk"] = self_chunk
     from yunchang_amd.kernels import set_block_backend
     from oracle_backend import OracleBlockBackend
 
@@ -462,16 +557,17 @@ def _overlap_worker(rank, ws, ud, rd, use_async, force_groups):
     return be.seen
 
 
-@pytest.mark.parametrize("ud,rd,use_async,force_groups,expect",
-                         [(1, 2, False, False, True),      # a ring relay is in flight
-                          (2, 1, False, False, False),     # one packed exchange, nothing to overlap: persistent
-                          (2, 1, False, True, True),       # head-group pipeline in LongContextAttention (default)
-                          (2, 1, True, True, True)])       # ... and in AsyncLongContextAttention
-def test_kernels_inside_a_transfer_window_are_launched_interleavable(ud, rd, use_async, force_groups, expect):
+@pytest.mark.parametrize("ud,rd,use_async,force_groups,expect,self_chunk",
+                         [(1, 2, False, False, True, "1"),      # a ring relay is in flight
+                          (2, 1, False, False, False, "0"),     # one packed exchange, no self-chunk start: nothing to overlap, persistent
+                          (2, 1, False, False, True, "1"),      # ... with the self-chunk start (default) the group's kernels run beside ITS exchange
+                          (2, 1, False, True, True, "1"),       # head-group pipeline in LongContextAttention (default)
+                          (2, 1, True, True, True, "1")])       # ... and in AsyncLongContextAttention
+def test_kernels_inside_a_transfer_window_are_launched_interleavable(ud, rd, use_async, force_groups, expect, self_chunk):
     """Persistent launches hold every CU until they end, so a ring relay or a pipelined exchange could not
     overlap them: exactly the launches made while such transfers are in flight must come from
     `backend.beside_transfers()` (USP_LAUNCH_INTERLEAVE on the C ABI).  The backend holds no mutable state."""
-    for seen in run_distributed(_overlap_worker, 2, ud, rd, use_async, force_groups):
+    for seen in run_distributed(_overlap_worker, 2, ud, rd, use_async, force_groups, self_chunk):
         assert seen and all(d == expect for _, d in seen), seen
 
 
