@@ -972,7 +972,8 @@ def main(argv=None, dev=None):
         if ms2 < ms:
             ms, dms = ms2, dms2
             line = make_line(ms, dms, "overlapped (the library default): Ulysses exchange pipelined over head groups beside "
-                                      "the ring, two communicators in flight")
+                                      "the ring, two communicators in flight; head groups start on the rank's own rows, the last "
+                                      "group's output leaves in row pieces (USP_SELF_CHUNK / USP_TAILS defaults)")
         else:                                       # the overlap probe below runs in the mode that was reported
             AL._COMM_OVERRIDE.update(safe=True)
             AL._COMM_OVERRIDE.pop("pipeline", None)
@@ -997,30 +998,9 @@ def main(argv=None, dev=None):
                 RX._OVERRIDE.clear()
         if line is not None:
             line["comm_modes_ms_per_step"] = modes
-    # Ulysses degree 2 (the 2-GPU grid, and the 8-GPU grid 2 x 4 beside its zigzag ring): the first head group can start on
-    # the rows the rank already holds (USP_SELF_CHUNK=1, hybrid/async_attn_layer.py:self_chunk_mode -- hides the first
-    # exchange of each pass; opt-in in the library because it has never met two devices).  Measured as one more
-    # deadline-guarded mode on top of the fastest so far; the faster one is reported.
-    if (cfg["ud"] == 2 and (cfg["rd"] == 1 or cfg["impl"] == "zigzag") and "USP_SELF_CHUNK" not in os.environ
-            and not args.async_ulysses):
-        modes = modes if two_comms else {"default": round(ms, 4)}
-        fallback = _LineOnce(None if line is None else
-                             {**line, "comm_modes_ms_per_step": modes,
-                              "comm_mode_note": "the self-chunk start (USP_SELF_CHUNK=1) did not finish before its deadline; this is "
-                                                "the measurement without it"})
-        budget = float(os.environ.get("USP_BENCH_MODE_DEADLINE_S", str(60 + 20 * ms * 1e-3 * (args.warmup + args.steps))))
-        with _Deadline(budget, fallback, None):
-            AL._COMM_OVERRIDE["self_chunk"] = "1"
-            ms2, dms2 = measure()
-        modes["self_chunk_start"] = round(ms2, 4)
-        if ms2 < ms:
-            ms, dms = ms2, dms2
-            line = make_line(ms, dms, ((line["config"]["comm_mode"] if line and two_comms else "library default") +
-                                       " + first head group started on the rank's own rows (USP_SELF_CHUNK=1)"))
-        else:
-            AL._COMM_OVERRIDE.pop("self_chunk", None)
-        if line is not None:
-            line["comm_modes_ms_per_step"] = modes
+    # (Round 5 measured the self-chunk start as one more deadline-guarded mode.  Since round 6 it is part of the library default
+    # -- with the row-chunked tails beside a zigzag ring -- so the staged modes are: safe -> default -> + relayed pair exchange;
+    # USP_SELF_CHUNK=0 / USP_TAILS=0 in the environment restore round 5's schedule for an A/B run.)
     value = flops / (ms * 1e-3) / 1e12
 
     # The measurement is complete here.  What follows is informative and must never cost the line: the overlap probe

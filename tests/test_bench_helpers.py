@@ -183,15 +183,12 @@ def _main_worker(rank, ws):
         assert line["roofline"]["stub"] is True and line["scaling"] == "strong" and line["config"]["pass"] == "fwd+bwd"
     else:
         assert set(line["overlap"]) >= {"value", "ms_iter", "ms_compute_only", "ms_comm_only"}
-    if ws == 8:       # ulysses 2 x ring 4: two communicators -> the safe mode is measured first, then the overlapped one, the relayed
-                      # pair exchange and the self-chunk start beside the ring, each under its deadline on top of the fastest so far
-        assert set(line["comm_modes_ms_per_step"]) == {"safe", "overlapped", "relayed", "self_chunk_start"}
+    if ws == 8:       # ulysses 2 x ring 4: two communicators -> the safe mode is measured first, then the library default (overlapped:
+                      # pipelined exchange, self-chunk start, row-chunked tails) and the relayed pair exchange on top, each under its deadline
+        assert set(line["comm_modes_ms_per_step"]) == {"safe", "overlapped", "relayed"}
         assert line["config"]["comm_mode"].startswith(("safe", "overlapped"))
         assert line["ms_per_step"] == min(line["comm_modes_ms_per_step"].values())
-    elif ws == 2:     # ulysses 2, ring degree 1: the default, then the self-chunk start under a deadline; the faster is the line
-        assert set(line["comm_modes_ms_per_step"]) == {"default", "self_chunk_start"}
-        assert line["ms_per_step"] == min(line["comm_modes_ms_per_step"].values())
-    else:
+    else:             # (ulysses 2 at ring degree 1: one communicator, the library default is the only mode since round 6)
         assert "comm_modes_ms_per_step" not in line
     return True
 
@@ -288,3 +285,27 @@ def test_sampled_parity_and_parity_check_propagate_nan():
     out[0, 63] = float("nan")                                                  # the last row of a range is always sampled
     _, worst_rows = b.parity_check(cfg, 0, 1, out, q16, k16, v16)
     assert worst_rows != worst_rows
+
+
+def _first_contact_worker(rank, ws, mode):
+    """tools/r06/first_contact.py's stages on gloo ranks (CPU tensors, the test oracle as block kernel): the link stage's pair
+    exchange and the parity stage of the real layer on BASELINE's grid for that rank count, in the three communicator modes."""
+    spec = importlib.util.spec_from_file_location("first_contact", os.path.join(ROOT, "tools", "r06", "first_contact.py"))
+    fc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fc)
+    os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(ws)
+    link = fc.main(["--stage", "link", "--backend", "gloo"])
+    par = fc.main(["--stage", "parity", "--mode", mode, "--backend", "gloo"])
+    return link, par
+
+
+@pytest.mark.parametrize("ws,mode", [(2, "default"), (8, "safe"), (8, "default"), (8, "relay")])
+def test_first_contact_stages_run_on_gloo(ws, mode):
+    """The command a multi-GPU lease starts with (tools/r06/first_contact.sh N) is exercised here stage by stage, so that the
+    first thing that can fail on real devices is the devices."""
+    for link, par in run_distributed(_first_contact_worker, ws, mode):
+        assert link["stage"] == "link" and link["pair_all_to_all_GBs_per_direction_min_over_pairs"] > 0
+        assert par["ok"] and par["mode"] == mode and par["grid"] == {2: "ulysses2xring1", 8: "ulysses2xring4"}[ws], par
+    sh = open(os.path.join(ROOT, "tools", "r06", "first_contact.sh")).read()
+    for needle in ("--stage link", "--stage parity", "USP_SAFE_COMM=1", "bench.py --gpus $N", "first_contact.json"):
+        assert needle in sh

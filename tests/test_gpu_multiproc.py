@@ -94,8 +94,8 @@ def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D, self_chunk=False):
     _order_p2p_like_rccl()
     AL._FILL_ITEMS = 1
     calls = []
+    AL._COMM_OVERRIDE["self_chunk"] = "1" if self_chunk else "0"       # (the default since round 6: pinned either way)
     if self_chunk:
-        AL._COMM_OVERRIDE["self_chunk"] = "1"
         real_f, real_b = AL._split_first_forward, AL._split_first_backward
         AL._split_first_forward = lambda *a: (calls.append("f"), real_f(*a))[1]
         AL._split_first_backward = lambda *a: (calls.append("b"), real_b(*a))[1]

@@ -256,11 +256,11 @@ def test_pipelined_exchange_beside_a_ring_through_rccl(nccl_single, monkeypatch,
 @pytest.mark.parametrize("n_gpus,relay,harness", [(8, False, "barrier"), (4, False, "barrier"), (2, False, "barrier"),
                                                   (8, True, "barrier"), (8, False, "pairwise"), (4, False, "pairwise"),
                                                   (-4, False, "barrier"), (-2, False, "barrier"), (-2, False, "barrier-selfchunk"),
-                                                  (-8, False, "barrier-selfchunk")],
+                                                  (-8, False, "barrier-selfchunk"), (-8, False, "pairwise-selfchunk")],
                          ids=["configs4_8gpu_u2r4_gqa_fwd_bwd", "configs3_4gpu_r4_fwd", "configs2_2gpu_u2_fwd",
                               "configs4_8gpu_relayed_pair_exchange", "configs4_8gpu_drifting_ranks", "configs3_4gpu_drifting_ranks",
                               "bench_4gpu_r4_64k_gqa_fwd_bwd", "bench_2gpu_u2_64k_gqa_fwd_bwd", "bench_2gpu_u2_64k_self_chunk_start",
-                              "bench_8gpu_u2r4_64k_self_chunk_start"])
+                              "bench_8gpu_u2r4_64k_self_chunk_start_and_tails", "bench_8gpu_u2r4_64k_defaults_drifting_ranks"])
 def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatch, n_gpus, relay, harness):
     """BASELINE's multi-GPU configs AT THEIR OWN SIZE with the ranks as virtual ranks of one GPU -- configs[4]: 8 ranks,
     ulysses 2 x ring 4, zigzag, B1 S65536 H32/Hkv4 D128 bf16 causal, forward + backward; configs[3]: 4 ranks, ring 4
@@ -303,9 +303,14 @@ def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatc
     # "pairwise": no host rendezvous of a group at its collectives, random host delays -- the ranks drift apart (virtual_grid.py)
     grid = _VirtualGrid(ud, rd, nccl_single) if harness.startswith("barrier") else VirtualGridPairwise(ud, rd, nccl_single, jitter=(5, 0.004))
     AL = patch_dist(monkeypatch, grid)
-    split_calls = []
-    if harness.endswith("selfchunk"):            # USP_SELF_CHUNK=1: the first head group starts on the rank's own rows
-        monkeypatch.setitem(AL._COMM_OVERRIDE, "self_chunk", "1")
+    split_calls, tail_calls = [], []
+    if not harness.endswith("selfchunk"):        # rounds 3-5's schedule (still selectable): no self-chunk start, no tails
+        monkeypatch.setitem(AL._COMM_OVERRIDE, "self_chunk", "0")
+        monkeypatch.setitem(AL._COMM_OVERRIDE, "tails", "0")
+    if harness.endswith("selfchunk"):            # the library's defaults since round 6: head groups start on the rank's own rows,
+        import yunchang_amd.comm.all_to_all as A_    # the last group's output leaves in row pieces, its dq ahead of dk | dv
+        real_pack = A_.pack_seq_rows
+        monkeypatch.setattr(A_, "pack_seq_rows", lambda *a: (tail_calls.append(a[2:]), real_pack(*a))[1])
         real_f, real_b = AL._split_first_forward, AL._split_first_backward
         monkeypatch.setattr(AL, "_split_first_forward", lambda *a: (split_calls.append("f"), real_f(*a))[1])
         monkeypatch.setattr(AL, "_split_first_backward", lambda *a: (split_calls.append("b"), real_b(*a))[1])
@@ -338,7 +343,10 @@ def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatc
     res = run_grid(grid, ws, rank_fn)
     torch.cuda.synchronize()
     if harness.endswith("selfchunk"):
-        assert sorted(split_calls) == ["b"] * ws + ["f"] * ws, split_calls            # every rank took the split path, both passes
+        ngr = res[0][1] if rd > 1 else 1          # beside a ring EVERY head group's owned chunk starts in front of the first wait
+        assert sorted(split_calls) == ["b"] * ws + ["f"] * (ws * ngr), split_calls    # every rank took the split path, both passes
+        if rd > 1:                                # ... and the last group's output left in 4 row pieces on every rank
+            assert len(tail_calls) == 4 * ws and len(set(tail_calls)) == 4, tail_calls
     if not metric:
         assert {n for _, n in res} == {{8: 2, 4: 1, 2: 4}[n_gpus]}        # head groups per rank: the default pipeline
     kinds = {"ulysses", "ring"} - ({"ulysses"} if ud == 1 else set()) - ({"ring"} if rd == 1 else set())

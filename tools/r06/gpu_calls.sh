@@ -42,4 +42,21 @@ PY
 tail -45 gpurun_out/r06/02_pytest_gpu.log
 }
 
+# tails + self-chunk defaults on the GPU: virtual-grid RCCL tests, multi-process tests; then one rank of the 8-GPU grid on one GPU
+# (wire = local copies) with the round-5 schedule, with the self-chunk start only, and with the defaults (self-chunk + tails)
+run03_tails() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
+( time timeout 1500 python -m pytest tests/test_gpu_rccl_order.py tests/test_gpu_multiproc.py -q -x -rP 2>&1 | grep -E "virtual grid at full size|passed|failed|Error|error|seconds per|s  tests" | tail -40 ) > gpurun_out/r06/03_tails_tests.log 2>&1
+tail -30 gpurun_out/r06/03_tails_tests.log
+for rank in 0 5; do
+for rep in 1 2; do
+  for e in "USP_SELF_CHUNK=0 USP_TAILS=0" "USP_SELF_CHUNK=1 USP_TAILS=0" "USP_SELF_CHUNK=1 USP_TAILS=4" "USP_SELF_CHUNK=1 USP_TAILS=2"; do
+    echo "== rank $rank  $e"
+    env $e timeout 200 python tools/rank_emulation.py --gpus 8 --rank $rank --iters 6 2>&1 | grep -A1 "^configs" | tail -1
+  done
+done
+done > gpurun_out/r06/03_rank_emulation.txt 2>&1
+cat gpurun_out/r06/03_rank_emulation.txt
+}
+
 "$@"
