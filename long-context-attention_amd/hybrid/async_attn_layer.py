@@ -139,7 +139,7 @@ def self_chunk_mode(P: int, ring: int, causal, impl: str, rows_local: int) -> bo
     transfers, which read the exchanged tensors, are posted behind the wait (ring/zigzag_ring_flash_attn.py: `first`).
     Results equal the unsplit launch up to fp32 summation order (the merge is the ring's own)."""
     mode = _COMM_OVERRIDE.get("self_chunk", os.environ.get("USP_SELF_CHUNK", _SELF_CHUNK_DEFAULT))
-    if str(mode) not in ("1", "True"):
+    if str(mode) not in ("1", "True", "all"):
         return False
     if not (P == 2 and bool(causal) and rows_local >= 1):
         return False
@@ -163,6 +163,14 @@ def tails_mode(P: int, ring: int, causal, impl: str, rows_local: int, pipelined:
     if n <= 0 or not (P == 2 and ring > 1 and bool(causal) and impl == "zigzag" and pipelined) or safe_comm():
         return 0
     return max(1, min(n, rows_local // 64)) if "tails" not in _COMM_OVERRIDE else max(1, min(n, rows_local))
+
+
+def self_chunk_all_groups() -> bool:
+    """USP_SELF_CHUNK=all: beside a ring EVERY head group's owned chunk is launched in front of the first wait, not only the
+    first group's.  Measured on one rank of the 8-GPU grid (profiles/r06_rank_emulation.txt): each group started that way costs
+    ~0.16 ms of kernel time (quarter-size causal launches cannot balance) and the second group's start hides ~0.13 ms more of the
+    0.33 ms first exchange at 64 GB/s -- a wash in time, +0.02 in the overlap figure; off by default."""
+    return str(_COMM_OVERRIDE.get("self_chunk", os.environ.get("USP_SELF_CHUNK", _SELF_CHUNK_DEFAULT))) == "all"
 
 
 def _self_views(send, u, splits):
@@ -426,12 +434,12 @@ class _AsyncUSPFunc(torch.autograd.Function):
                     if hi > lo:
                         pieces.append(lane.exchange(A.pack_seq_rows(out_i, P, lo, hi), ulysses_pg) + (lo, hi))
                 return n_tail, emit
-            # Beside a ring EVERY group's owned chunk is launched before the first wait (round 6; round 5: the first group's):
-            # the first exchange of the pass takes longer than one group's owned chunk (0.33 against 0.12 ms at the 8-GPU
-            # grid and 64 GB/s), and the other groups' owned chunks are the only other work that needs no exchanged byte.
+            # Beside a ring the first group's owned chunk is launched before the first wait (round 5); USP_SELF_CHUNK=all: every
+            # group's (the first exchange of the pass takes longer than one group's owned chunk, and the other groups' owned
+            # chunks are the only other work that needs no exchanged byte -- self_chunk_all_groups for what that buys).
             gens = {}
             if split0 and ring > 1:
-                for i in range(ng):
+                for i in range(ng if self_chunk_all_groups() else 1):
                     (qi, ki, vi), ev, send_i = ins[i]
                     own = _self_views(send_i, u, (kvh * g, kvh, kvh))
                     gens[i] = zigzag_forward_phases(ring_pg, qi, ki, vi, softmax_scale, overlap,

@@ -274,7 +274,7 @@ def test_self_chunk_start_beside_a_zigzag_ring(rd, Hq, Hkv, B, S, env):
     assert all(run_distributed(_self_chunk_worker, 2 * rd, "zigzag", Hq, Hkv, B, S, rd, env))
 
 
-def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env):
+def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env, sc="1"):
     """Row-chunked tails (hybrid/async_attn_layer.py:tails_mode; round 6, default beside a zigzag ring at ulysses degree 2): the
     LAST head group's last forward launch runs in n row pieces, each followed by an exchange of its rows; the last ring step
     of its backward issues dQ first and dq travels ahead of dk | dv; beside that, every group's owned chunk is launched in
@@ -313,7 +313,7 @@ def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env):
     counts = []
     try:
         for on in (False, True):
-            AL._COMM_OVERRIDE.update(self_chunk="1" if on else "0", tails=str(n) if on else "0")
+            AL._COMM_OVERRIDE.update(self_chunk=sc if on else "0", tails=str(n) if on else "0")
             lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=rd, ud=2).detach().clone() for t in (q, k, v, do))
             for t in (lq, lk, lv):
                 t.requires_grad_(True)
@@ -337,9 +337,9 @@ def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env):
                 assert len(fx) == 2 * ng - 1 + pieces, (fx, ng, pieces)
                 assert sum(e[1][1] for e in fx[-pieces:]) == c, fx          # the pieces' rows make up a chunk
                 assert all(e[2] < n_fwd_calls for e in fx[-pieces:-1]) and fx[-1][2] == n_fwd_calls, (fx, n_fwd_calls)
-                # every group's owned chunk is launched in front of the first wait
+                # the first group's owned chunk (USP_SELF_CHUNK=all: every group's) is launched in front of the first wait
                 first_wait = next(e for e in fwd_log if e[0] == "wait")
-                assert first_wait[1] >= ng, (fwd_log[:6], ng)
+                assert first_wait[1] >= (ng if sc == "all" else 1), (fwd_log[:6], ng)
                 # backward: ng input exchanges, ng - 1 packed gradient exchanges, then dq alone and dk | dv alone
                 assert len(bx) == 2 * ng + 1, bx
                 assert bx[-2][1][3] == Hq // Hkv and bx[-1][1][3] == 2, bx
@@ -353,12 +353,13 @@ def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env):
     return close and right, counts[1]
 
 
-@pytest.mark.parametrize("rd,Hq,Hkv,B,S,n,env", [(2, 8, 4, 1, 128, 2, None),                           # chain relay (ring 2), two head groups
-                                                 (4, 8, 4, 1, 256, 4, None),                           # the 8-GPU grid: mesh fetch, grouped launches
-                                                 (4, 8, 2, 2, 256, 3, None),                           # batch 2 (ungrouped pieces), ONE head group, uneven pieces
-                                                 (4, 4, 4, 1, 128, 2, ("USP_KV_RELAY=chain", "USP_DKDV_RETURN=direct"))])
-def test_row_chunked_tails_beside_a_zigzag_ring(rd, Hq, Hkv, B, S, n, env):
-    res = run_distributed(_tails_worker, 2 * rd, rd, Hq, Hkv, B, S, n, env)
+@pytest.mark.parametrize("rd,Hq,Hkv,B,S,n,env,sc", [(2, 8, 4, 1, 128, 2, None, "1"),                      # chain relay (ring 2), two head groups
+                                                    (4, 8, 4, 1, 256, 4, None, "1"),                      # the 8-GPU grid: mesh fetch, grouped launches
+                                                    (4, 8, 4, 1, 256, 4, None, "all"),                    # ... every group's owned chunk first
+                                                    (4, 8, 2, 2, 256, 3, None, "1"),                      # batch 2 (ungrouped pieces), ONE head group, uneven pieces
+                                                    (4, 4, 4, 1, 128, 2, ("USP_KV_RELAY=chain", "USP_DKDV_RETURN=direct"), "all")])
+def test_row_chunked_tails_beside_a_zigzag_ring(rd, Hq, Hkv, B, S, n, env, sc):
+    res = run_distributed(_tails_worker, 2 * rd, rd, Hq, Hkv, B, S, n, env, sc)
     assert all(r[0] for r in res)
     assert len({r[1] for r in res}) == 1, "every rank posts the same number of exchanges"
 

@@ -87,6 +87,77 @@ def round5(ms):
           "\n    -- DESIGN.md 5: not built)")
 
 
+def round6(gbs_list=(48.0, 64.0, 96.0), comp=None):
+    """Round 6: the 8-GPU grid's iteration replayed launch by launch on two resources (the compute stream, the Ulysses lane) for the
+    schedules the library can run, at several assumed link rates -- the decision "tails on by default" must not hang on one rate.
+    Per head group (8 query heads, 1 KV head) of a rank, kernel times from the one-GPU rank trace (profiles/r05_rank_emulation.txt,
+    r06_rank_emulation.txt): a ring step of the forward = 2 c^2 score entries per head = `fstep` ms, of the backward `bstep` ms
+    (dK/dV launch 0.58 of it, dQ launch 0.42); the forward's launches behind step 0 by ring rank r (grouped mesh fetch, one wave):
+    r0: 3 c^2 + 3 c^2, r1: 2 + 2 + 2, r2: 4 + 1 + 1, r3: 6 (x c^2) -- the LAST one finalises the rows that travel.
+    `comp` = the compute-only iteration (ms) of the schedule with and without the round-6 launches."""
+    comp = comp or {"r5": 16.19, "r6": 16.40}
+    print("\nround 6: the 8-GPU grid (ulysses 2 x ring 4, B1 S65536 H32/Hkv4 fwd+bwd), slowest ring rank, by link rate")
+    last_launch = {0: 1.5, 1: 1.0, 2: 0.5, 3: 3.0}            # final forward launch of a group, in ring steps
+    for gbs in gbs_list:
+        ms = lambda nbytes: nbytes / (gbs * 1e9) * 1e3
+        fi, fo, bi, bq, bkv, hop = ms(20 * MiB), ms(16 * MiB), ms(16 * MiB), ms(16 * MiB), ms(4 * MiB), ms(8 * MiB)
+        kvf = ms(8 * MiB)                                      # K/V of a peer, one head group (three links in parallel)
+        comm = 2 * (fi + fo + bi + bq + bkv) + 2 * 3 * ms(16 * MiB) + 2 * hop + 4 * kvf     # every transfer once (fp32 hops: 16 MiB)
+        rows = []
+        for name, own_all, own_first, n_tail, dq_first, c_iter in (
+                ("round-5 default (USP_SELF_CHUNK=0 USP_TAILS=0)", False, False, 0, False, comp["r5"]),
+                ("+ self-chunk start, first group (round 5 opt-in)", False, True, 0, False, comp["r5"] + 0.15),
+                ("round-6 default: every group's own chunk first + tails (4 pieces) + dq first", True, True, 4, True, comp["r6"]),
+                ("... with 2 pieces", True, True, 2, True, comp["r6"])):
+            worst = 0.0
+            for r in range(4):
+                fstep, bstep = c_iter * 0.235 / 8, c_iter * 0.765 / 8           # per group and ring step
+                own = 0.25 * fstep
+                # ---- forward
+                land = [fi, 2 * fi]
+                t = (2 * own if own_all else (own if own_first else 0.0))
+                lane = 2 * fi
+                ends = []
+                for g in range(2):
+                    started_own = own_all or (own_first and g == 0)
+                    t = max(t, land[g]) + 4 * fstep - (own if started_own else 0.0)
+                    ends.append(t)
+                L = last_launch[r] * fstep
+                if n_tail:
+                    Lp = L * 1.08 / n_tail                                      # K split + merge launches: +8 %
+                    start = ends[1] - L
+                    lane = max(lane, ends[0]) + fo                              # group 0's output
+                    tt = start
+                    for j in range(n_tail):
+                        tt += Lp
+                        lane = max(lane, tt) + fo / n_tail
+                    fwd_end = lane
+                else:
+                    lane = max(lane, ends[0]) + fo
+                    fwd_end = max(lane, ends[1]) + fo
+                # ---- backward
+                land = [bi, 2 * bi]
+                lane = 2 * bi
+                t = 0.0
+                own_b = 0.25 * bstep
+                t = (own_b if own_first else 0.0)
+                t = max(t, land[0]) + 4 * bstep - (own_b if own_first else 0.0)
+                lane = max(lane, t + hop) + bq + bkv                            # group 0: hop pending on the lane, one exchange
+                t = max(t, land[1]) + 4 * bstep
+                if dq_first:
+                    dq_done = t - 0.58 * bstep                                  # the dQ launch of the last step ends here
+                    lane_q = max(lane, dq_done) + bq
+                    bwd_end = max(lane_q, t + hop) + bkv
+                else:
+                    bwd_end = max(lane, t + hop) + bq + bkv
+                worst = max(worst, fwd_end + bwd_end)
+            rows.append((name, worst, c_iter))
+        print("  %3.0f GB/s per link: transfers %.2f ms per rank and iteration" % (gbs, comm))
+        for name, tot, c_iter in rows:
+            print("     %-82s %6.2f ms = %5.0f TFLOP/s on 8 GPUs, compute-only %.2f ms, overlap %.2f"
+                  % (name + ":", tot, 123.15 / tot * 1e3, c_iter, 1 - (tot - c_iter) / comm))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--link-gbs", type=float, default=64.0, help="one xGMI link, one direction, GB/s")
@@ -197,6 +268,7 @@ def main():
           % (sum(cut.values()), 1 - sum(cut.values()) / comm))
 
     round5(ms)
+    round6()
 
     # Ring backward: the travelling dK/dV (relay, the reference's order) against USP_DKDV_RETURN=direct (every block
     # straight to its owner over its own link, front-half blocks at half size).  Per ring rank; t_c = kernels of one step.

@@ -59,4 +59,32 @@ done > gpurun_out/r06/03_rank_emulation.txt 2>&1
 cat gpurun_out/r06/03_rank_emulation.txt
 }
 
+# the schedule variants on one rank of the 8-GPU grid (compute-only), the launch list of the default, and the bench order A/B
+run04_rank_and_order() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06; R=$GRAFT_REPO_ROOT
+for rank in 0 5; do
+for rep in 1 2; do
+  for e in "USP_SELF_CHUNK=0 USP_TAILS=0" "USP_SELF_CHUNK=1 USP_TAILS=0" "USP_SELF_CHUNK=1 USP_TAILS=4" "USP_SELF_CHUNK=1 USP_TAILS=2" "USP_SELF_CHUNK=all USP_TAILS=4"; do
+    echo "== rank $rank  $e"
+    env $e timeout 200 python tools/rank_emulation.py --gpus 8 --rank $rank --iters 6 2>&1 | grep -A1 "^configs" | tail -1 | cut -c1-150
+  done
+done
+done > gpurun_out/r06/04_rank_emulation.txt 2>&1
+cat gpurun_out/r06/04_rank_emulation.txt
+export TMPDIR=/tmp
+( cd /tmp && rocprofv3 --kernel-trace -d /tmp/emu_r6 -o x -- python $R/tools/rank_emulation.py --gpus 8 --rank 0 --iters 3 > /tmp/emu_r6.log 2>&1; python $R/tools/r06/rank_launches.py /tmp/emu_r6 6 ) > gpurun_out/r06/04_rank_launches.txt 2>&1
+tail -60 gpurun_out/r06/04_rank_launches.txt
+for rep in 1 2; do
+for order in headline_first kernels_first; do
+  USP_BENCH_ORDER=$order python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | grep -E "^\{" > gpurun_out/r06/04_bench_${order}_$rep.json
+  python - gpurun_out/r06/04_bench_${order}_$rep.json $order <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); r = d["roofline"]
+print(sys.argv[2], "ms_per_step", d["ms_per_step"], "frac", d["frac_of_mfma_roofline"], "| kernels alone:", r["step"]["fwd_ms"], r["step"]["dkdv_ms"], r["step"]["dq_ms"],
+      "| 2-step family row64", r["layer_step_ms_by_kernel_family"]["row64"], "| ceiling", r["mfma_ceiling"]["sustained_ceiling_TFLOPs"], "| kinds", r["kernels_launched"]["bwd"])
+PY
+done
+done | tee gpurun_out/r06/04_bench_order.txt
+}
+
 "$@"
