@@ -42,6 +42,7 @@ struct BwdParams {
   int* sched;                         // packed mode: control block of the dynamic item queue, or NULL
   int sched_lds;                      // byte offset of the queue's two LDS slots
   int interleave;                     // USP_LAUNCH_INTERLEAVE: one workgroup per item (collectives can slip in)
+  int walk_g;                         // 64-row dQ kernel: query heads of a KV group walked side by side (usp_item_deal.h); 1 = off
   int wide16;                         // 64-row kernels: bit 0 / 1 / 2 = the dq16 / dk16 / dv16 rows are 16-byte aligned and nothing
                                       // is accumulated into them: whole-row-piece stores (usp_mfma64.hpp: store_row16_wide)
 };

@@ -172,6 +172,8 @@ struct ItemWalk {
   // Fewer than 8 heads: the tiles of a head that spans several XCDs are dealt to them evenly (usp_item_deal.h).
   // `w` = item id as returned by at(); returns the id to decode (head * n_inner + tile).
   USP_DEV int dealt(int w, int n_inner) const { return usp_deal_item(w, n_inner, items_l); }
+  // ... and the query heads of one KV group side by side inside a run that holds several whole heads (round 6; walk_g = G, or 1 = off)
+  USP_DEV int grouped(int w, int n_inner, int walk_g) const { return usp_group_item(w, n_inner, items_l, walk_g); }
 };
 
 // Dynamic item queue, used for packed batches (sequences of unequal length defeat any static split: the

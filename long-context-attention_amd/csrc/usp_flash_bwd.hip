@@ -1070,6 +1070,10 @@ extern "C" int usp_flash_bwd(const usp_bwd_args* a, void* stream) {
   p.sched = packed ? a->sched : nullptr;
   p.sched_lds = 0;
   p.interleave = (a->flags & USP_LAUNCH_INTERLEAVE) ? 1 : 0;
+  {   // USP_ITEM_GROUP=0 (read once): the head-major item walk of rounds 1-5 instead of a KV group's heads side by side
+    static const bool group_heads = [] { const char* e = getenv("USP_ITEM_GROUP"); return !(e && e[0] == '0'); }();
+    p.walk_g = group_heads ? p.G : 1;
+  }
   p.wide16 = 0;                                   // (set by the 64-row launches for their own copy)
   p.ws_rows = ws_rows_of(a);
   if (packed) {

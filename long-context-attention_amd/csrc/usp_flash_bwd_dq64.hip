@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256, 1) void flash_bwd_dq64_kernel(const BwdParams 
   asm volatile("" : "+s"(p));
   USP_TM(const uint64_t tm_item = __builtin_amdgcn_s_memtime();)
   w = walk.dealt(w, p->nblk);
+  if (p->ksplit <= 1) w = walk.grouped(w, p->nblk, p->walk_g);
   const int qt_r = w % p->nblk;
   int rest = w / p->nblk;
   const int qt = CAUSAL ? (p->nblk - 1 - qt_r) : qt_r;    // heavy (late) tiles first

@@ -814,6 +814,10 @@ extern "C" int usp_flash_fwd(const usp_fwd_args* a, void* stream) {
   p.seq_q = a->seq_q; p.seq_k = a->seq_k;
   p.sched = packed ? a->sched : nullptr;
   p.interleave = (a->flags & USP_LAUNCH_INTERLEAVE) ? 1 : 0;
+  {   // USP_ITEM_GROUP=0 (read once): the head-major item walk of rounds 1-5 instead of a KV group's heads side by side
+    static const bool group_heads = [] { const char* e = getenv("USP_ITEM_GROUP"); return !(e && e[0] == '0'); }();
+    p.walk_g = group_heads ? p.G : 1;
+  }
   p.ksplit = 1; p.ws_o = nullptr; p.ws_lse = nullptr;
   p.win_on = wl >= 0 ? 1 : 0; p.win_lo = a->Sk - a->Sq - (wl >= 0 ? wl : 0);
   if (a->k_splits > 1 && a->workspace != nullptr) {

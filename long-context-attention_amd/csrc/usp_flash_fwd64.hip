@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(const FwdArgsT<SPLI
     w = walk.dealt(w, p->nq * p->ksplit);                 // the cuts of a tile are dealt like tiles
     ks = w % p->ksplit; w /= p->ksplit;
   } else {
-    w = walk.dealt(w, p->nq);
+    w = walk.grouped(walk.dealt(w, p->nq), p->nq, p->walk_g);
   }
   const int qt_r = w % p->nq;
   int rest = w / p->nq;

@@ -22,6 +22,7 @@ struct FwdParams {
   const int* seq_q; const int* seq_k;   // packed variable-length batch: B (first row, rows) pairs, or NULL
   int* sched;                           // packed mode: control block of the dynamic item queue, or NULL
   int interleave;                       // USP_LAUNCH_INTERLEAVE: one workgroup per item (collectives can slip in)
+  int walk_g;                           // 64-row kernel: query heads of a KV group walked side by side (usp_item_deal.h: usp_group_item); 1 = off
 };
 
 // K split (dense mode): every (batch, head, query tile) is cut into `ksplit` items along K; partial results go to

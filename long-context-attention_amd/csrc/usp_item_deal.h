@@ -36,4 +36,26 @@ USP_DEAL_FN int usp_deal_item(int w, int n_inner, int items_l) {
   }
 }
 
+/* Round 6: the query heads of ONE KV group side by side.  An XCD's run that holds several whole heads is walked head-major by the
+ * ids above: its 32 workgroups stream the K / V of one query head's tiles, then the same K / V again for the next head of the
+ * group.  Here the run's ids are re-read tile-major inside blocks of m = min(heads per run, G) heads (m | G, so a block never
+ * leaves its KV group): consecutive ids -- what the XCD's workgroups hold at any one time -- are the same tile of m heads, which
+ * read the same K / V rows through the same L2.  Still a bijection, still heaviest first, the alternating passes still pair equal
+ * weights (tests/test_host_api.py).  w: id in run order, after usp_deal_item (which only deals when a head spans several runs:
+ * then this map is the identity). */
+USP_DEAL_FN int usp_group_item(int w, int n_inner, int items_l, int G) {
+  if (G <= 1 || items_l < 2 * n_inner || items_l % n_inner != 0) return w;
+  {
+    const int hr = items_l / n_inner;             /* whole heads per run */
+    const int m = hr < G ? hr : G;
+    if (G % m != 0 || hr % m != 0) return w;
+    {
+      const int x = w / items_l, loc = w - x * items_l;
+      const int blk = loc / (m * n_inner), j = loc - blk * (m * n_inner);
+      return (x * hr + blk * m + j % m) * n_inner + j / m;
+    }
+  }
+}
+
+
 #endif

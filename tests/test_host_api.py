@@ -254,6 +254,41 @@ def test_item_deal_is_a_balanced_bijection(tmp_path):
     assert dealt_cases > 30
     # without the XCD split (items_l = all items) nothing is remapped
     assert all(deal(w, 64, 256) == w for w in range(256))
+    # round 6: usp_group_item -- the query heads of one KV group side by side inside a run of whole heads: a bijection of every
+    # run onto itself, every head's tiles still heaviest first, consecutive ids = the same tile of m heads of ONE KV group, and the
+    # alternating passes of an XCD's 32 workgroups still give every workgroup the same weight
+    group = ctypes.CDLL(str(lib)).usp_group_item
+    group.restype = ctypes.c_int
+    grouped_cases = 0
+    for heads, G in ((32, 8), (16, 1), (16, 2), (16, 16), (64, 8), (8, 4), (24, 3), (32, 4), (40, 8)):
+        for n_inner in (4, 32, 64, 256):
+            n = heads * n_inner
+            items_l = n // 8
+            ids = [group(deal(w, n_inner, items_l), n_inner, items_l, G) for w in range(n)]
+            assert sorted(ids) == list(range(n)), (heads, G, n_inner)
+            if ids == list(range(n)):
+                assert G == 1 or items_l < 2 * n_inner or (items_l // n_inner) % min(items_l // n_inner, G) or G % min(items_l // n_inner, G)
+                continue
+            grouped_cases += 1
+            hr = items_l // n_inner
+            m = min(hr, G)
+            for x in range(8):
+                run = ids[x * items_l:(x + 1) * items_l]
+                assert sorted(run) == list(range(x * items_l, (x + 1) * items_l))          # a run stays a run
+                per_head = {}
+                for t in run:
+                    per_head.setdefault(t // n_inner, []).append(t % n_inner)
+                assert all(v == sorted(v) for v in per_head.values())                      # heaviest first per head
+                for i in range(0, items_l, m):                                             # m consecutive ids: one tile, one KV group
+                    blk = run[i:i + m]
+                    assert len({t % n_inner for t in blk}) == 1 and len({(t // n_inner) // G for t in blk}) == 1, (heads, G, n_inner, blk)
+                if items_l % 64 == 0:                                                       # 32 workgroups, alternating passes
+                    wg = [0] * 32
+                    for loc, t in enumerate(run):
+                        ps, k = divmod(loc, 32)
+                        wg[k if ps % 2 == 0 else 31 - k] += n_inner - t % n_inner
+                    assert max(wg) - min(wg) <= max(1, n_inner // 8), (heads, G, n_inner, wg)
+    assert grouped_cases >= 12
 
 
 def test_zigzag_fetch_plan_and_wave_matching():

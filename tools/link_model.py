@@ -95,7 +95,9 @@ def round6(gbs_list=(48.0, 64.0, 96.0), comp=None):
     (dK/dV launch 0.58 of it, dQ launch 0.42); the forward's launches behind step 0 by ring rank r (grouped mesh fetch, one wave):
     r0: 3 c^2 + 3 c^2, r1: 2 + 2 + 2, r2: 4 + 1 + 1, r3: 6 (x c^2) -- the LAST one finalises the rows that travel.
     `comp` = the compute-only iteration (ms) of the schedule with and without the round-6 launches."""
-    comp = comp or {"r5": 16.19, "r6": 16.40}
+    # compute-only iteration of the SLOWEST rank (ring rank 2) per schedule, one box, alternating (profiles/r06_rank_emulation.txt);
+    # ring rank 0 on the same box: 14.30 / 14.60 / 14.79 / 14.64 / 14.92
+    comp = comp or {"r5": 15.72, "sc": 15.98, "sc_t4": 16.15, "sc_t2": 16.08, "all_t4": 16.29}
     print("\nround 6: the 8-GPU grid (ulysses 2 x ring 4, B1 S65536 H32/Hkv4 fwd+bwd), slowest ring rank, by link rate")
     last_launch = {0: 1.5, 1: 1.0, 2: 0.5, 3: 3.0}            # final forward launch of a group, in ring steps
     for gbs in gbs_list:
@@ -106,13 +108,14 @@ def round6(gbs_list=(48.0, 64.0, 96.0), comp=None):
         rows = []
         for name, own_all, own_first, n_tail, dq_first, c_iter in (
                 ("round-5 default (USP_SELF_CHUNK=0 USP_TAILS=0)", False, False, 0, False, comp["r5"]),
-                ("+ self-chunk start, first group (round 5 opt-in)", False, True, 0, False, comp["r5"] + 0.15),
-                ("round-6 default: every group's own chunk first + tails (4 pieces) + dq first", True, True, 4, True, comp["r6"]),
-                ("... with 2 pieces", True, True, 2, True, comp["r6"])):
+                ("+ self-chunk start of the first group (round 5 opt-in; USP_TAILS=0)", False, True, 0, False, comp["sc"]),
+                ("round-6 default: self-chunk start + tails in 4 row pieces + dq first", False, True, 4, True, comp["sc_t4"]),
+                ("... with 2 pieces (USP_TAILS=2)", False, True, 2, True, comp["sc_t2"]),
+                ("... every group's own chunk first (USP_SELF_CHUNK=all), 4 pieces", True, True, 4, True, comp["all_t4"])):
             worst = 0.0
             for r in range(4):
                 fstep, bstep = c_iter * 0.235 / 8, c_iter * 0.765 / 8           # per group and ring step
-                own = 0.25 * fstep
+                own = 0.164                      # the owned chunk's launch + its K-split merge (profiles/r06_rank_launches.txt)
                 # ---- forward
                 land = [fi, 2 * fi]
                 t = (2 * own if own_all else (own if own_first else 0.0))
@@ -124,7 +127,7 @@ def round6(gbs_list=(48.0, 64.0, 96.0), comp=None):
                     ends.append(t)
                 L = last_launch[r] * fstep
                 if n_tail:
-                    Lp = L * 1.08 / n_tail                                      # K split + merge launches: +8 %
+                    Lp = L / n_tail                                             # (the pieces' K split + merge launches are in c_iter)
                     start = ends[1] - L
                     lane = max(lane, ends[0]) + fo                              # group 0's output
                     tt = start
@@ -139,7 +142,7 @@ def round6(gbs_list=(48.0, 64.0, 96.0), comp=None):
                 land = [bi, 2 * bi]
                 lane = 2 * bi
                 t = 0.0
-                own_b = 0.25 * bstep
+                own_b = 0.444                    # delta + dK/dV + dQ (+ reduces) on the owned rows
                 t = (own_b if own_first else 0.0)
                 t = max(t, land[0]) + 4 * bstep - (own_b if own_first else 0.0)
                 lane = max(lane, t + hop) + bq + bkv                            # group 0: hop pending on the lane, one exchange
