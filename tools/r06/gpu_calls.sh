@@ -87,4 +87,37 @@ done
 done | tee gpurun_out/r06/04_bench_order.txt
 }
 
+# the query heads of a KV group side by side in the item walk (usp_group_item): time and HBM fetch of the forward and the dQ kernel
+# at the N = 1 workload's shape, against the head-major walk (USP_ITEM_GROUP=0); native harness, alternating
+run05_item_group() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench; mkdir -p $R/gpurun_out/r06; cd $R
+( timeout 900 $K suite bwd 2>&1 | grep -E "FAIL|SUITE" ) | tail -3
+for rep in 1 2 3; do
+for g in 1 0; do
+  echo "USP_ITEM_GROUP=$g fwd: $(USP_ITEM_GROUP=$g timeout 200 $K fwd 1 65536 65536 32 4 128 1 0 0 3 2>&1 | grep TIME)"
+  echo "USP_ITEM_GROUP=$g dq : $(USP_ITEM_GROUP=$g USP_KBENCH_FLAGS=32 timeout 200 $K bwd 1 65536 65536 32 4 128 1 0 0 3 2>&1 | grep TIME)"
+done
+done | tee gpurun_out/r06/05_item_group_time.txt
+for g in 1 0; do
+  echo "USP_ITEM_GROUP=$g fwd C2: $(USP_ITEM_GROUP=$g timeout 200 $K fwd 2 8192 8192 16 16 128 1 0 0 20 2>&1 | grep TIME)"
+  echo "USP_ITEM_GROUP=$g fwd 16K GQA 16/2: $(USP_ITEM_GROUP=$g timeout 200 $K fwd 1 16384 16384 16 2 128 1 0 0 10 2>&1 | grep TIME)"
+done | tee -a gpurun_out/r06/05_item_group_time.txt
+export TMPDIR=/tmp; cd /tmp
+for g in 1 0; do
+  USP_ITEM_GROUP=$g rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_f$g -o x -- $K fwd 1 65536 65536 32 4 128 1 0 0 1 > /dev/null 2>&1
+  USP_ITEM_GROUP=$g USP_KBENCH_FLAGS=32 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_q$g -o x -- $K bwd 1 65536 65536 32 4 128 1 0 0 1 > /dev/null 2>&1
+  for d in f q; do
+  python3 - /tmp/pmc_$d$g $g <<'PY'
+import glob, sqlite3, sys
+db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
+c = sqlite3.connect(db)
+rows = c.execute("select name, sum(counter_value), count(distinct dispatch_id) from pmc_events where counter_name = 'FETCH_SIZE' group by name").fetchall()
+for name, v, n in rows:
+    if "flash_" in name:
+        print(f"USP_ITEM_GROUP={sys.argv[2]}  {name.split('(')[0][:60]:60s} dispatches {n}  FETCH_SIZE {v / n:14.1f} KiB/launch -> HBM read {v / n * 2 * 1024 / 1e6:9.1f} MB (x2 gfx950 correction)")
+PY
+  done
+done 2>&1 | tee $R/gpurun_out/r06/05_item_group_fetch.txt
+}
+
 "$@"
