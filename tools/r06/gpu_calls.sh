@@ -120,4 +120,12 @@ PY
 done 2>&1 | tee $R/gpurun_out/r06/05_item_group_fetch.txt
 }
 
+# the whole GPU suite as the driver runs it (serial, -x), with per-file durations; then smoke
+run06_suite() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
+( time timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -40 ) > gpurun_out/r06/06_pytest_gpu.log 2>&1
+tail -32 gpurun_out/r06/06_pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4
+}
+
 "$@"
