@@ -482,10 +482,10 @@ ROOFLINE_ALGORITHMIC_MB = round((2 * 65536 * 32 * 128 * 2 + 2 * 65536 * 4 * 128 
 def pmc_traffic():
     """HBM bytes per launch of the roofline kernel (flash_bwd_dkdv64_kernel at the N = 1 workload's shape) from the committed
     rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes; tools/prof_round.sh).  Hardware
-    counters cannot be collected from inside this process, so the numbers come from profiles/r05_rocprof_summary.txt -- but
+    counters cannot be collected from inside this process, so the numbers come from profiles/r06_rocprof_summary.txt -- but
     ONLY if that profile was taken from the kernel sources of this tree (the summary carries their hash) or from the same
     MACHINE CODE of that kernel (tools/kernel_isa.py); otherwise null."""
-    name = "r05_rocprof_summary.txt"
+    name = "r06_rocprof_summary.txt"
     path = os.path.join(ROOT, "profiles", name)
     try:
         rd = wr = sha = isa = None
@@ -503,8 +503,8 @@ def pmc_traffic():
         res = {"kernel": ROOFLINE_KERNEL, "read_MB": rd, "write_MB": wr, "algorithmic_MB": ROOFLINE_ALGORITHMIC_MB,
                "kernel_src_sha16": sha,
                "note": "above the algorithmic bytes by the flash tiling: every 128-key item re-streams its head's Q / dO tiles (served "
-                       "by L2 / MALL, the misses are the HBM reads), and the GQA head split writes one fp32 dK / dV partial per query "
-                       "head that reduce_heads_kernel sums -- 3-4 % of the HBM roof over the launch: the kernel is MFMA-bound by 25x",
+                       "by L2 / MALL, the misses are the HBM reads), and with four query heads per work item (round 6) two fp32 dK / dV slabs "
+                       "are written for reduce_heads_kernel to sum -- 3 % of the HBM roof over the launch: the kernel is MFMA-bound by 25x",
                "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources)"}
         if sha == kernel_source_sha16():
             return res

@@ -211,7 +211,7 @@ def test_profile_is_quoted_only_for_the_kernel_it_was_taken_from(monkeypatch):
     import kernel_isa
     roof, allp, n = kernel_isa.isa_identity(os.path.join(ROOT, "long-context-attention_amd", "libusp_hip.so"))
     assert n == 24 and len(roof) == 16
-    newest = os.path.join(ROOT, "profiles", "r05_rocprof_summary.txt")              # what pmc_traffic reads
+    newest = os.path.join(ROOT, "profiles", "r06_rocprof_summary.txt")              # what pmc_traffic reads
     t = b.pmc_traffic()
     if not os.path.exists(newest):
         assert t is None

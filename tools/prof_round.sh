@@ -7,7 +7,7 @@
 # the flash_bwd_dkdv64_kernel lines of the FIRST derived block = the N = 1 workload's shape)
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT/w64k $OUT/c2set
 cd /tmp
