@@ -11,6 +11,7 @@ device first (a send posted right after the kernel that produces its payload wou
 that kernel -- observed on the travelling dK/dV accumulators at world size 8).  With that, the ordering
 these tests check is the package's own: the relay stream vs the compute stream, buffer reuse across
 iterations, and the all-to-all pack / unpack kernels between processes."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -231,6 +232,11 @@ def test_varlen_ring_multiprocess_one_gpu(gloo_cuda, path):
 
 
 RING_BWD = [f for f in DENSE if Golden(f).rd > 1 and Golden(f).bwd]
+# (an opt-in transport, bit-identical to the relay on EVERY ring fixture on gloo -- tests/test_dist_cpu.py -- and on the GPU in rounds
+# 3-5; the driver's GPU suite has a time limit, so by default four fixtures run here: the 8-GPU grid, a zigzag ring 4, a stripe ring
+# and the non-causal batch-2 GQA ring.  USP_GPU_ALL_FIXTURES=1: all of them.)
+if os.environ.get("USP_GPU_ALL_FIXTURES") != "1":
+    RING_BWD = [f for f in RING_BWD if any(t in f for t in ("c5_w8_u2r4_gqa_bf16", "c4_w4_u1r4", "n_w4_u2r2_strip", "f_w4_u2r2_full_b2_gqa"))]
 
 
 @pytest.mark.parametrize("path", RING_BWD, ids=lambda p: p.split("/")[-1][:-4])
