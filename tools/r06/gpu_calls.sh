@@ -128,4 +128,11 @@ tail -32 gpurun_out/r06/06_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -4
 }
 
+# the round's rocprofv3 record of the product path (kernel trace + PMC passes: tools/prof_round.sh) -> profiles/r06_rocprof_summary.txt
+run07_prof() {
+cd $GRAFT_REPO_ROOT
+bash tools/prof_round.sh r06 2>&1 | tail -45
+cp gpurun_out/prof_r06/bench_line.json gpurun_out/prof_r06/bench_under_rocprof.json 2>/dev/null
+}
+
 "$@"
