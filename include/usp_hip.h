@@ -216,7 +216,8 @@ int usp_flash_bwd(const usp_bwd_args* args, void* stream);
  *   - GQA (Hq > Hkv): a dK/dV work item streams dkdv_heads query heads of its KV group (ABI v7; rounds 1-5: one or all).
  *     With fewer than Hq/Hkv heads per item there are (Hq/Hkv)/dkdv_heads times more items -- what balances the causal
  *     triangle when B*Hkv*ceil(Sk/128) is small -- and as many fp32 partial slabs.  dkdv_heads = 0: the largest divisor of
- *     Hq/Hkv up to 4 that leaves two work items per CU (one for launches without a causal / window triangle) -- measured:
+ *     Hq/Hkv up to 2 that leaves two work items per CU for causal / windowed launches (more heads per item let the concurrent
+ *     workgroups' Q / dO streams drift out of one L2), up to 4 and one item per CU for full ones -- measured:
  *     profiles/r06_gqa_loop.txt; packed batches: 1;
  *   - dkdv_splits = n (ABI v5): every such item is cut into n items over equal runs of the query tiles that see its keys;
  *   - dq_splits = n (ABI v5): every (head, 256-row query block) item of the dQ launch is cut into n items over equal runs

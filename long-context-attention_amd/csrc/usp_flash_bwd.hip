@@ -958,13 +958,17 @@ static int device_cus() {
 // of G = Hq / Hkv).  More heads per item: K / V fragments, their pre-scale and the epilogue once per run of heads, fewer fp32
 // partial slabs (none when the item takes the whole group and nothing is cut) and a shorter reduce; fewer heads: more items,
 // which is what balances a causal launch of few (batch, KV head, key block) triangles.  0 = the library decides, from what
-// was measured on MI355X (profiles/r06_gqa_loop.txt; dK/dV launch + reduce alone, G = 8): the largest divisor <= 4 that
-// leaves two items per CU (causal; one when every item is equally long) --
+// was measured on MI355X (profiles/r06_gqa_loop.txt; dK/dV launch + reduce alone, G = 8):
 //   B1 S65536 H32/4 causal   55.1 (1) 54.8 (2) 54.7 (4) 55.2 (8) ms      one KV head of 16384 keys, causal  0.915 (1) 0.896 (2) 1.329 (4) ms
 //   B1 S32768 H32/4 causal   14.07    13.91    13.86    14.05            two KV heads, 16384 keys, causal   1.847 (1) 1.798 (2) 1.776 (4) 2.713 (8)
 //   one KV head, 8192 rows x 16384 keys, full  0.907 (1) 0.883 (2) 0.871 (4) 1.218 (8)
-// (eight heads per item lose to four even where there are plenty of items: the per-item saving halves again while every CU's
-// static list shortens to a handful of long items.)  Packed batches keep 1.  USP_BWD_GSUB=n (read once) overrides the automatic
+//   HBM fetch per launch at B1 S65536 (second box: 52.34 / 52.03 / 52.19 ms):  11.4 GB (1)  13.6 GB (2)  33.5 GB (4)
+// -> the largest divisor that leaves two items per CU (causal; one when every item is equally long), capped at 4 (eight heads
+// per item lose to four even with plenty of items: the per-item saving halves again while every CU's static list shortens to a
+// handful of long items) and, for CAUSAL launches, at 2: the 32 workgroups an XCD runs side by side hold 32 consecutive key
+// blocks, whose first visible tiles lie up to 62 tiles apart; head after head inside an item that lead adds up, and from three
+// heads on the window of Q / dO tiles they stream together (62 tiles x 32 KiB x heads) no longer fits the XCD's 4 MiB L2 -- the
+// fetch triples for a time gain inside the noise.  Packed batches keep 1.  USP_BWD_GSUB=n (read once) overrides the automatic
 // choice for A/B runs.
 static int dkdv_heads_of(const usp_bwd_args* a) {
   const int G = a->Hq / a->Hkv;
@@ -981,7 +985,8 @@ static int dkdv_heads_of(const usp_bwd_args* a) {
   const bool triangles = a->causal || ((a->flags & USP_ATTN_WINDOW) && a->window_right >= 0);
   const int64_t want = (triangles ? 2LL : 1LL) * device_cus();
   int best = 1;
-  for (int g = 2; g <= G && g <= 4; ++g)
+  const int cap = triangles ? 2 : 4;
+  for (int g = 2; g <= G && g <= cap; ++g)
     if (G % g == 0 && base * (G / g) >= want) best = g;
   return best;
 }

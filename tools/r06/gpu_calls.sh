@@ -135,4 +135,27 @@ bash tools/prof_round.sh r06 2>&1 | tail -45
 cp gpurun_out/prof_r06/bench_line.json gpurun_out/prof_r06/bench_under_rocprof.json 2>/dev/null
 }
 
+# dK/dV launch: HBM fetch and time by query heads per work item (the in-item head loop lets the 32 concurrent workgroups of an XCD drift
+# apart head by head: does their window still fit the L2?)
+run08_gsub_fetch() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench; mkdir -p $R/gpurun_out/r06; cd $R
+export USP_KBENCH_FLAGS=16 TMPDIR=/tmp
+for rep in 1 2; do for h in 1 2 4; do
+  echo "heads/item $h: $(USP_KBENCH_BWD_HEADS=$h timeout 300 $K bwd 1 65536 65536 32 4 128 1 0 0 3 2>&1 | grep TIME | cut -c1-110)"
+done; done | tee gpurun_out/r06/08_gsub_time.txt
+cd /tmp
+for h in 1 2 4; do
+  USP_KBENCH_BWD_HEADS=$h rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pmc_g$h -o x -- $K bwd 1 65536 65536 32 4 128 1 0 0 1 > /dev/null 2>&1
+  python3 - /tmp/pmc_g$h $h <<'PY'
+import glob, sqlite3, sys
+db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
+c = sqlite3.connect(db)
+rows = c.execute("select name, sum(counter_value), count(distinct dispatch_id) from pmc_events where counter_name = 'FETCH_SIZE' group by name").fetchall()
+for name, v, n in rows:
+    if "dkdv" in name or "reduce" in name:
+        print(f"heads/item {sys.argv[2]}  {name.split('(')[0][:50]:50s} dispatches {n}  HBM read {v / n * 2 * 1024 / 1e6:9.1f} MB per launch (FETCH_SIZE x2)")
+PY
+done 2>&1 | tee $R/gpurun_out/r06/08_gsub_fetch.txt
+}
+
 "$@"
