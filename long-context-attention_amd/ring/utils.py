@@ -443,7 +443,7 @@ def last_hop_16bit() -> bool:
 
 
 def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=None, be=None, final_dtype=None,
-                defer=None):
+                defer=None, split_block: bool = False):
     """The travelling dK/dV of every ring backward (zigzag_ring_flash_attn.py:139-183, ring_flash_attn.py:
     86-147): the fp32 accumulators of K/V block j visit every rank that attends to it, one hop per step,
     each rank adding its block result; after P hops they are back home.
@@ -467,8 +467,13 @@ def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=Non
             consumes it on the exchange lane, so the next group's kernels start behind this group's last kernels, not
             behind its last hop).
 
-    The hop of step s is posted from the compute stream right after the kernels of step s, and runs beside
-    the kernels of step s+1.  `zero`: start every buffer from zeros (packed batches: the kernels do not touch
+        split_block: `block` takes `only=` ("dkdv" | "dq") and is called TWICE per step: the dK/dV launch, then -- behind the
+            fold and the posting of the step's hop -- the dQ launch.  The hop then runs beside the step's own dQ launch as well,
+            and the LAST hop, which nothing used to hide on a ring-only grid (the 4-GPU grid: 32 MiB = 0.5 ms at 64 GB/s of a
+            30 ms iteration), runs beside the last step's dQ launch.  Same kernels, same sums, same order: bit-identical.
+
+    The hop of step s is posted from the compute stream right after the kernels of step s (split_block: after its dK/dV
+    launch), and runs beside the kernels of step s+1.  `zero`: start every buffer from zeros (packed batches: the kernels do not touch
     rows outside every sequence's range, which would otherwise travel -- and be summed -- uninitialised).
     Returns the final (dk, dv): fp32 accumulators, or `final_dtype` tensors."""
     P = group_info(dist, process_group)[0]
@@ -483,11 +488,12 @@ def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=Non
     with KVRelay(process_group, k, v) as relay:
         for step in range(P):
             kk, vv = relay.get(step)
+            bkw = {"only": "dkdv"} if split_block else {}
             if step == 0:
                 dk_acc, dv_acc = new(k), new(v)
-                block(0, kk, vv, dk_acc, dv_acc)
+                block(0, kk, vv, dk_acc, dv_acc, **bkw)
             else:
-                computed = block(step, kk, vv, dk_blk, dv_blk)
+                computed = block(step, kk, vv, dk_blk, dv_blk, **bkw)
                 d_comm.wait()                       # the travelling accumulators of step-1 have landed
                 dk_acc, dv_acc = next_dk, next_dv
                 if computed is not False:
@@ -498,6 +504,8 @@ def travel_dkdv(process_group, k, v, block, fold, zero: bool = False, extent=Non
             next_dk = d_comm.send_recv(dk_acc)
             next_dv = d_comm.send_recv(dv_acc)
             d_comm.commit()
+            if split_block:                         # the step's dQ launch, beside its own hop
+                block(step, kk, vv, None, None, only="dq")
         if defer is None or not round_last:      # (an fp32 arrival still has to be rounded on this stream)
             d_comm.wait()
         else:

@@ -109,8 +109,7 @@ def zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale,
     kw = {} if only is None else {"only": only}
     nz = lambda t, sl: None if t is None else t[:, sl]
     if step == 0:                                   # zigzag_ring_flash_attn.py:145-149
-        assert only is None
-        be.bwd(dout, q, kk, vv, lse, delta, dq_acc, dk_dst, dv_dst, softmax_scale, True)
+        be.bwd(dout, q, kk, vv, lse, delta, dq_acc, dk_dst, dv_dst, softmax_scale, True, **kw)
     elif step <= r:                                 # :151-155
         be.bwd(dout, q, kk[:, :c], vv[:, :c], lse, delta, dq_acc, nz(dk_dst, slice(0, c)), nz(dv_dst, slice(0, c)),
                softmax_scale, False, accum_dq=True, dq16=dq16, **kw)
@@ -119,6 +118,13 @@ def zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale,
             be.cast(dq16[:, :c], dq_acc[:, :c])     # final since step r
         be.bwd(dout[:, c:], q[:, c:], kk, vv, lse[:, :, c:], delta[:, :, c:], nz(dq_acc, slice(c, None)), dk_dst,
                dv_dst, softmax_scale, False, accum_dq=True, dq16=nz(dq16, slice(c, None)), **kw)
+
+
+def split_steps() -> bool:
+    """USP_BWD_SPLIT_STEPS=0: one dK/dV + dQ call per ring step as in rounds 1-5 (A/B switch; the default issues the dQ launch of
+    a step behind the posting of the step's hop)."""
+    import os
+    return os.environ.get("USP_BWD_SPLIT_STEPS", "1") != "0"
 
 
 def zigzag_bwd_fold(be, r, step, c, dk_acc, dv_acc, dk_blk, dv_blk):
@@ -306,16 +312,28 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
 
     dq_done = []
 
-    def block(step, kk, vv, dk_dst, dv_dst):
+    # Every step is issued as dK/dV launch | fold + hop posted | dQ launch (travel_dkdv: split_block), so a step's hop also runs
+    # beside its own dQ launch -- the LAST hop included, which on a ring-only grid nothing else hides.  Two exceptions: a step 0
+    # that starts on the owned rows (`first`) keeps its two launch pairs together, and the last step under `dq_first` runs dQ
+    # FIRST (its dq exchange is the bigger transfer; the hop then follows the dK/dV launch as before).
+    def block(step, kk, vv, dk_dst, dv_dst, only=None):
         if step == 0 and first is not None:
+            if only == "dq":
+                return
             u, do_own, wait = first
             zigzag_bwd_step0_split(be, u, do_own, dout, wait, q, kk, vv, out, lse, delta, softmax_scale, dq_acc, dk_dst, dv_dst)
         elif dq_first is not None and step == P - 1:
+            if only == "dq":
+                return
             dq16 = torch.empty((B, S2, H, D), dtype=q.dtype, device=dev)
             zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, None, None, only="dq", dq16=dq16)
             dq_first(dq16)
             dq_done.append(dq16)
             zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, None, dk_dst, dv_dst, only="dkdv")
+        elif only == "dkdv":
+            zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, None, dk_dst, dv_dst, only="dkdv")
+        elif only == "dq":
+            zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, None, None, only="dq")
         else:
             zigzag_bwd_block(be, r, P, step, dout, q, kk, vv, lse, delta, softmax_scale, dq_acc, dk_dst, dv_dst)
 
@@ -324,7 +342,7 @@ def zigzag_ring_flash_attn_backward(process_group, dout, q, k, v, out, softmax_l
 
     # steps s <= rank carry gradients for the front-half K/V rows only (:151-155, :161-170)
     dk_acc, dv_acc = travel_dkdv(process_group, k, v, block, fold, be=be, final_dtype=k.dtype, defer=tail,
-                                 extent=lambda rank, step: slice(0, c) if step <= rank else FULL)
+                                 extent=lambda rank, step: slice(0, c) if step <= rank else FULL, split_block=split_steps())
     return final_grads(be, (q, k, v), (dq_done[0] if dq_done else dq_acc, dk_acc, dv_acc))
 
 

@@ -343,8 +343,9 @@ def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env, sc="1"):
                 # backward: ng input exchanges, ng - 1 packed gradient exchanges, then dq alone and dk | dv alone
                 assert len(bx) == 2 * ng + 1, bx
                 assert bx[-2][1][3] == Hq // Hkv and bx[-1][1][3] == 2, bx
-                only = [c_ for c_ in be.calls if c_[0] == "bwd" and len(c_) == 5]
-                assert [c_[4] for c_ in only] == ["dq", "dkdv"], only
+                only = [c_[4] for c_ in be.calls if c_[0] == "bwd" and len(c_) == 5]
+                # every ring step is issued dK/dV | hop | dQ (travel_dkdv: split_block); the LAST step of the last group dQ first
+                assert only[-2:] == ["dq", "dkdv"] and all(only[i:i + 2] == ["dkdv", "dq"] for i in range(0, len(only) - 2, 2)), only
     finally:
         AL._COMM_OVERRIDE.clear()
         A._exchange, AL._Lane.wait = real_x, real_wait
@@ -886,3 +887,51 @@ def _relay_dp_worker(rank, ws):
 
 def test_relayed_exchange_agrees_inside_its_sequence_parallel_block_only():
     assert all(run_distributed(_relay_dp_worker, 8))
+
+
+def _split_steps_worker(rank, ws):
+    """A ring-only grid (the 4-GPU grid: ulysses 1 x ring 4, zigzag): every backward step is issued dK/dV launch | hop posted | dQ
+    launch, so the LAST hop -- which nothing else hides there -- runs beside the last step's dQ launch; bit-identical to one call
+    per step (USP_BWD_SPLIT_STEPS=0)."""
+    import os
+    import yunchang_amd as Y
+    import yunchang_amd.ring.utils as U
+    from yunchang_amd.kernels import set_block_backend
+    from oracle_backend import OracleBlockBackend
+    be = OracleBlockBackend()
+    set_block_backend(be)
+    Y.set_seq_parallel_pg(1, ws, rank, ws)
+    torch.manual_seed(5)
+    q, k, v, do = (torch.randn(1, 64 * ws, h, 32).to(torch.bfloat16) for h in (4, 2, 2, 4))
+    ext = Y.EXTRACT_FUNC_DICT["zigzag"]
+    events = []
+    real_commit = U.RingComm.commit
+    U.RingComm.commit = lambda self: (events.append(("commit", len(self._ops))), real_commit(self))[1]
+    res = []
+    try:
+        for split in ("1", "0"):
+            os.environ["USP_BWD_SPLIT_STEPS"] = split
+            lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=ws, ud=1).detach().clone() for t in (q, k, v, do))
+            for t in (lq, lk, lv):
+                t.requires_grad_(True)
+            out = Y.LongContextAttention(ring_impl_type="zigzag")(lq, lk, lv, causal=True)
+            events.clear(); be.calls.clear()
+            real_bwd = be.bwd
+            be.bwd = lambda *a, **kw: (events.append(("bwd", kw.get("only"))), real_bwd(*a, **kw))[1]
+            out.backward(ldo)
+            be.bwd = real_bwd
+            res.append([t.detach().clone() for t in (lq.grad, lk.grad, lv.grad)])
+            if split == "1":
+                kinds = [e for e in events if e[0] == "bwd"]
+                assert [e[1] for e in kinds] == ["dkdv", "dq"] * ws, kinds
+                i_last_dkdv = max(i for i, e in enumerate(events) if e == ("bwd", "dkdv"))
+                i_last_dq = max(i for i, e in enumerate(events) if e == ("bwd", "dq"))
+                assert any(e[0] == "commit" for e in events[i_last_dkdv:i_last_dq]), events       # the last hop is posted in between
+    finally:
+        U.RingComm.commit = real_commit
+        os.environ.pop("USP_BWD_SPLIT_STEPS", None)
+    return all(torch.equal(a, b) for a, b in zip(*res))
+
+
+def test_ring_backward_steps_are_split_around_their_hop():
+    assert all(run_distributed(_split_steps_worker, 4))

@@ -98,6 +98,17 @@ def round6(gbs_list=(48.0, 64.0, 96.0), comp=None):
     # compute-only iteration of the SLOWEST rank (ring rank 2) per schedule, one box, alternating (profiles/r06_rank_emulation.txt);
     # ring rank 0 on the same box: 14.30 / 14.60 / 14.79 / 14.64 / 14.92
     comp = comp or {"r5": 15.72, "sc": 15.98, "sc_t4": 16.15, "sc_t2": 16.08, "all_t4": 16.29}
+    # N = 4 (ring 4 zigzag, no exchange): round 6 issues every backward step as dK/dV launch | hop | dQ launch, so the last hop
+    # (rounded: 32 MiB) runs beside the last step's dQ launch (0.42 of a 5.6 ms step) instead of behind it
+    print("\nround 6: the 4-GPU grid (ring 4 zigzag, same workload), compute-only 29.54 ms (profiles/r05_rank_emulation.txt)")
+    for gbs in gbs_list:
+        ms = lambda nbytes: nbytes / (gbs * 1e9) * 1e3
+        comp4, kv, hop = 29.54, ms(32 * MiB), ms(64 * MiB)
+        step_b = comp4 * 0.765 / 4
+        comm = 2 * kv + 3 * hop + hop / 2
+        for name, last in (("round 5 (one call per step)", hop / 2), ("round 6 (steps split around their hop)", max(0.0, hop / 2 - 0.42 * step_b))):
+            tot = comp4 + max(0.0, kv - comp4 * 0.235 / 4) + max(0.0, hop - step_b) * 3 + last
+            print("  %3.0f GB/s: %-42s %.2f ms per iteration = %5.0f TFLOP/s on 4 GPUs, overlap %.2f" % (gbs, name + ":", tot, 123.15 / tot * 1e3, 1 - (tot - comp4) / comm))
     print("\nround 6: the 8-GPU grid (ulysses 2 x ring 4, B1 S65536 H32/Hkv4 fwd+bwd), slowest ring rank, by link rate")
     last_launch = {0: 1.5, 1: 1.0, 2: 0.5, 3: 3.0}            # final forward launch of a group, in ring steps
     for gbs in gbs_list:
