@@ -157,10 +157,13 @@ def tails_mode(P: int, ring: int, causal, impl: str, rows_local: int, pipelined:
     exposed.  The BACKWARD's counterpart needs no pieces: the last ring step issues its dQ launch first and dq -- 4/5 of the
     gradient exchange's bytes at G = 8 -- travels beside the step's dK/dV launch (`dq_first`); what stays exposed is the last
     dK/dV hop and the small dk | dv exchange.  Ulysses degree 2 beside a zigzag ring (the 8-GPU grid), pipelined mode only (in
-    the safe mode a second communicator must not start inside a ring pass); USP_TAILS=0 | n overrides (default 4)."""
+    the safe mode a second communicator must not start inside a ring pass), and at ring degree 1 (the 2-GPU grid), where the
+    last group's one causal block is issued in the layer as 2 n row-range launches (_tail_last_forward) and its backward dQ
+    first (_tail_last_backward); USP_TAILS=0 | n overrides (default 4)."""
     mode = _COMM_OVERRIDE.get("tails", os.environ.get("USP_TAILS", "4"))
     n = int(mode)
-    if n <= 0 or not (P == 2 and ring > 1 and bool(causal) and impl == "zigzag" and pipelined) or safe_comm():
+    ok = P == 2 and bool(causal) and pipelined and (impl == "zigzag" if ring > 1 else impl in ("basic", "zigzag"))
+    if n <= 0 or not ok or (ring > 1 and safe_comm()):
         return 0
     return max(1, min(n, rows_local // 64)) if "tails" not in _COMM_OVERRIDE else max(1, min(n, rows_local))
 
@@ -239,6 +242,38 @@ def _split_first_backward(be, u, do_self, do_full, wait, q, k, v, o, lse, scale)
                True, accum_dk=True, accum_dv=True, dq16=dq[:, :c], dk16=dk[:, :c], dv16=dv[:, :c])
         be.cast(dk[:, c:], dk32[:, c:])              # keys [c, 2c) got gradients from the first launch only
         be.cast(dv[:, c:], dv32[:, c:])
+    return dq, dk, dv
+
+
+def _tail_last_forward(be, q, k, v, scale, n, emit):
+    """The LAST head group's causal block at ring degree 1 (ulysses degree 2) in row pieces: piece j of the front chunk, piece j
+    of the back chunk (each a bottom-right-aligned causal launch over the keys its rows see), then `emit(j, out)` -- the piece's
+    output exchange runs beside the next piece's launches.  Same rows x keys as one launch; returns (out, lse)."""
+    B, S, hq, D = q.shape
+    c = S // 2
+    out = torch.empty((B, S, hq, D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, hq, S), dtype=torch.float32, device=q.device)
+    for j in range(n):
+        for ch in (0, 1):
+            a, b = ch * c + j * c // n, ch * c + (j + 1) * c // n
+            if b > a:
+                be.fwd(q[:, a:b], k[:, :b], v[:, :b], scale, True, lse[:, :, a:b], out[:, a:b])
+        emit(j, out)
+    return out, lse
+
+
+def _tail_last_backward(be, dout, q, k, v, o, lse, scale, dq_first):
+    """... and its backward: delta, the dQ launch (rounded in its epilogue), `dq_first(dq)` -- dq travels beside the dK/dV launch
+    --, the dK/dV launch.  Returns (dq, dk, dv) in q.dtype."""
+    B, S, hq, D = q.shape
+    delta = torch.empty((B, hq, S), dtype=torch.float32, device=q.device)
+    dq = torch.empty((B, S, hq, D), dtype=q.dtype, device=q.device)
+    dk = torch.empty((B, S, k.shape[2], D), dtype=k.dtype, device=q.device)
+    dv = torch.empty_like(dk)
+    be.delta(dout, o, delta)
+    be.bwd(dout, q, k, v, lse, delta, None, None, None, scale, True, dq16=dq, only="dq")
+    dq_first(dq)
+    be.bwd(dout, q, k, v, lse, delta, None, None, None, scale, True, dk16=dk, dv16=dv, only="dkdv")
     return dq, dk, dv
 
 
@@ -426,8 +461,8 @@ class _AsyncUSPFunc(torch.autograd.Function):
             pieces = []                       # the last group's output exchange in row pieces: (recv, event, lo, hi)
 
             def tail_of(i):
-                if not n_tail or i != ng - 1:
-                    return None
+                if not n_tail or i != ng - 1 or (ring == 1 and split0 and i == 0):     # (ring degree 1, one group: the self-chunk
+                    return None                                                      #  split owns that block)
 
                 def emit(j, out_i):           # piece j of both chunks is final on this stream: its exchange starts now
                     lo, hi = j * Sl // n_tail, (j + 1) * Sl // n_tail
@@ -458,13 +493,17 @@ class _AsyncUSPFunc(torch.autograd.Function):
                     own = _self_views(send_i, u, (kvh * g, kvh, kvh))
                     oi, lse_i = _split_first_forward(get_block_backend(beside_transfers=True), u, own, (qi, ki, vi),
                                                      lambda ev=ev: lane.wait(ev), softmax_scale)
+                elif ring == 1 and tail_of(i) is not None:       # the 2-GPU grid: the last group's one causal block in row pieces
+                    from ..kernels.attention import get_block_backend
+                    lane.wait(ev)
+                    oi, lse_i = _tail_last_forward(get_block_backend(beside_transfers=True), qi, ki, vi, softmax_scale, *tail_of(i))
                 else:
                     lane.wait(ev)
                     t = tail_of(i)
                     kw = {} if t is None else {"tail": t}
                     oi, lse_i = fwd(ring_pg, qi, ki, vi, softmax_scale=softmax_scale, causal=causal, overlap=overlap, **kw)
                 saved += [qi, ki, vi, oi, lse_i]
-                if n_tail and i == ng - 1:
+                if tail_of(i) is not None:
                     outs.append(None)         # (travelled in `pieces`)
                 else:
                     outs.append(_to_heads_issue(lane, [oi], P, ulysses_pg))
@@ -482,7 +521,7 @@ class _AsyncUSPFunc(torch.autograd.Function):
         ctx.save_for_backward(*saved)
         ctx.meta = (softmax_scale, causal, ulysses_pg, ring_pg, impl, P, ng, kvh, g, Hq, Hkv)
         ctx.split0 = (split0, u, ring)
-        ctx.n_tail = n_tail
+        ctx.n_tail = n_tail if tail_of(ng - 1) is not None else 0
         return out
 
     @staticmethod
@@ -514,6 +553,12 @@ class _AsyncUSPFunc(torch.autograd.Function):
                     else:
                         dqi, dki, dvi = bwd(ring_pg, doi, qi, ki, vi, oi, lse_i, softmax_scale=softmax_scale, causal=causal,
                                             overlap=overlap, tail=tail, first=(u, do_own, lambda ev=ev: lane.wait(ev)), **kw)
+                elif ring == 1 and kw:         # the 2-GPU grid's last group: dQ launch, dq exchange, dK/dV launch
+                    from ..kernels.attention import get_block_backend
+                    lane.wait(ev)
+                    tail = []
+                    dqi, dki, dvi = _tail_last_backward(get_block_backend(beside_transfers=True), doi, qi, ki, vi, oi, lse_i,
+                                                        softmax_scale, kw["dq_first"])
                 else:
                     lane.wait(ev)
                     tail = []                  # the ring backward's last dK/dV hop, left pending (ring/utils.py:travel_dkdv)

@@ -274,7 +274,7 @@ def test_self_chunk_start_beside_a_zigzag_ring(rd, Hq, Hkv, B, S, env):
     assert all(run_distributed(_self_chunk_worker, 2 * rd, "zigzag", Hq, Hkv, B, S, rd, env))
 
 
-def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env, sc="1"):
+def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env, sc="1", impl="zigzag"):
     """Row-chunked tails (hybrid/async_attn_layer.py:tails_mode; round 6, default beside a zigzag ring at ulysses degree 2): the
     LAST head group's last forward launch runs in n row pieces, each followed by an exchange of its rows; the last ring step
     of its backward issues dQ first and dq travels ahead of dk | dv; beside that, every group's owned chunk is launched in
@@ -297,7 +297,7 @@ def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env, sc="1"):
     torch.manual_seed(3)
     D = 32
     q, k, v, do = (torch.randn(B, S, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
-    ext = Y.EXTRACT_FUNC_DICT["zigzag"]
+    ext = Y.EXTRACT_FUNC_DICT[impl]
     qn, kn, vn, don = (t.float().numpy().astype(np.float64) for t in (q, k, v, do))
     ro, rl = O.attention_ref(qn, kn, vn, causal=True)
     truth = [ext(torch.from_numpy(np.ascontiguousarray(t)), rank, world_size=ws, rd=rd, ud=2).float()
@@ -318,7 +318,7 @@ def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env, sc="1"):
             for t in (lq, lk, lv):
                 t.requires_grad_(True)
             log.clear(); be.calls.clear()
-            out = Y.LongContextAttention(ring_impl_type="zigzag")(lq, lk, lv, causal=True)
+            out = Y.LongContextAttention(ring_impl_type=impl)(lq, lk, lv, causal=True)
             n_fwd_calls = len(be.calls)
             fwd_log = list(log)
             log.clear()
@@ -358,9 +358,12 @@ def _tails_worker(rank, ws, rd, Hq, Hkv, B, S, n, env, sc="1"):
                                                     (4, 8, 4, 1, 256, 4, None, "1"),                      # the 8-GPU grid: mesh fetch, grouped launches
                                                     (4, 8, 4, 1, 256, 4, None, "all"),                    # ... every group's owned chunk first
                                                     (4, 8, 2, 2, 256, 3, None, "1"),                      # batch 2 (ungrouped pieces), ONE head group, uneven pieces
-                                                    (4, 4, 4, 1, 128, 2, ("USP_KV_RELAY=chain", "USP_DKDV_RETURN=direct"), "all")])
+                                                    (4, 4, 4, 1, 128, 2, ("USP_KV_RELAY=chain", "USP_DKDV_RETURN=direct"), "all"),
+                                                    (1, 8, 4, 1, 128, 4, None, "1"),                      # the 2-GPU grid (ring degree 1): the block in the layer
+                                                    (1, 8, 4, 2, 96, 3, None, "basic")])                  # ... contiguous layout, batch 2, uneven pieces
 def test_row_chunked_tails_beside_a_zigzag_ring(rd, Hq, Hkv, B, S, n, env, sc):
-    res = run_distributed(_tails_worker, 2 * rd, rd, Hq, Hkv, B, S, n, env, sc)
+    impl = "basic" if sc == "basic" else "zigzag"
+    res = run_distributed(_tails_worker, 2 * rd, rd, Hq, Hkv, B, S, n, env, "1" if sc == "basic" else sc, impl)
     assert all(r[0] for r in res)
     assert len({r[1] for r in res}) == 1, "every rank posts the same number of exchanges"
 

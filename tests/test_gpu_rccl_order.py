@@ -344,8 +344,9 @@ def test_baseline_configs_at_full_size_on_a_virtual_grid(nccl_single, monkeypatc
     torch.cuda.synchronize()
     if harness.endswith("selfchunk"):
         assert sorted(split_calls) == ["b"] * ws + ["f"] * ws, split_calls            # every rank took the split path, both passes
-        if rd > 1:                                # ... and the last group's output left in 4 row pieces on every rank
-            assert len(tail_calls) == 4 * ws and len(set(tail_calls)) == 4, tail_calls
+        # ... and the last group's output left in 4 row pieces on every rank (beside the ring: pieces of the final launch; at ring
+        # degree 1: the last group's causal block issued in the layer as row-range launches)
+        assert len(tail_calls) == 4 * ws and len(set(tail_calls)) == 4, tail_calls
     if not metric:
         assert {n for _, n in res} == {{8: 2, 4: 1, 2: 4}[n_gpus]}        # head groups per rank: the default pipeline
     kinds = {"ulysses", "ring"} - ({"ulysses"} if ud == 1 else set()) - ({"ring"} if rd == 1 else set())

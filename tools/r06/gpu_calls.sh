@@ -158,4 +158,26 @@ PY
 done 2>&1 | tee $R/gpurun_out/r06/08_gsub_fetch.txt
 }
 
+# final schedule code: the RCCL virtual-grid tests again, then compute-only iterations of one rank of every grid with and without the
+# round-6 schedule pieces
+run09_schedules() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
+( time timeout 1200 python -m pytest tests/test_gpu_rccl_order.py -q -x 2>&1 | tail -12 ) > gpurun_out/r06/09_rccl_order.log 2>&1
+tail -10 gpurun_out/r06/09_rccl_order.log
+for rep in 1 2; do
+  for e in "USP_SELF_CHUNK=0 USP_TAILS=0" "USP_SELF_CHUNK=1 USP_TAILS=0" "USP_SELF_CHUNK=1 USP_TAILS=4" "USP_SELF_CHUNK=1 USP_TAILS=2"; do
+    echo "== N=2 rank 0  $e"; env $e timeout 300 python tools/rank_emulation.py --gpus 2 --rank 0 --iters 3 2>&1 | grep -A1 "^configs" | tail -1 | cut -c1-150
+  done
+  for e in "USP_BWD_SPLIT_STEPS=0" "USP_BWD_SPLIT_STEPS=1"; do
+    echo "== N=4 rank 0  $e"; env $e timeout 300 python tools/rank_emulation.py --gpus 4 --rank 0 --iters 4 2>&1 | grep -A1 "^configs" | tail -1 | cut -c1-150
+    echo "== N=4 rank 2  $e"; env $e timeout 300 python tools/rank_emulation.py --gpus 4 --rank 2 --iters 4 2>&1 | grep -A1 "^configs" | tail -1 | cut -c1-150
+  done
+  for e in "USP_SELF_CHUNK=0 USP_TAILS=0 USP_BWD_SPLIT_STEPS=0" "USP_SELF_CHUNK=1 USP_TAILS=4"; do
+    echo "== N=8 rank 0  $e"; env $e timeout 300 python tools/rank_emulation.py --gpus 8 --rank 0 --iters 6 2>&1 | grep -A1 "^configs" | tail -1 | cut -c1-150
+    echo "== N=8 rank 5  $e"; env $e timeout 300 python tools/rank_emulation.py --gpus 8 --rank 5 --iters 6 2>&1 | grep -A1 "^configs" | tail -1 | cut -c1-150
+  done
+done > gpurun_out/r06/09_rank_emulation_all.txt 2>&1
+cat gpurun_out/r06/09_rank_emulation_all.txt
+}
+
 "$@"
