@@ -98,12 +98,27 @@ def round6(gbs_list=(48.0, 64.0, 96.0), comp=None):
     # compute-only iteration of the SLOWEST rank (ring rank 2) per schedule, one box, alternating (profiles/r06_rank_emulation.txt);
     # ring rank 0 on the same box: 14.30 / 14.60 / 14.79 / 14.64 / 14.92
     comp = comp or {"r5": 15.72, "sc": 15.98, "sc_t4": 16.15, "sc_t2": 16.08, "all_t4": 16.29}
-    # N = 4 (ring 4 zigzag, no exchange): round 6 issues every backward step as dK/dV launch | hop | dQ launch, so the last hop
-    # (rounded: 32 MiB) runs beside the last step's dQ launch (0.42 of a 5.6 ms step) instead of behind it
-    print("\nround 6: the 4-GPU grid (ring 4 zigzag, same workload), compute-only 29.54 ms (profiles/r05_rank_emulation.txt)")
+    # N = 2 (ulysses 2, ring degree 1): two head groups; compute-only iteration of a rank by schedule, one box, alternating
+    # (profiles/r06_rank_emulation_all_grids.txt): 60.79 (round 5) / 60.95 (+ self-chunk start) / 61.28 (+ tails in 4 pieces + dq first) /
+    # 61.05 (2 pieces).  Per group: q|k|v in 80 MiB, out 64 MiB, dO in 64 MiB, dq 64 + dk|dv 16 MiB out, all over ONE link.
+    print("\nround 6: the 2-GPU grid (ulysses 2, ring degree 1, same workload)")
     for gbs in gbs_list:
         ms = lambda nbytes: nbytes / (gbs * 1e9) * 1e3
-        comp4, kv, hop = 29.54, ms(32 * MiB), ms(64 * MiB)
+        fi, fo, bi, bq, bkv = ms(80 * MiB), ms(64 * MiB), ms(64 * MiB), ms(64 * MiB), ms(16 * MiB)
+        comm = 2 * (fi + fo + bi + bq + bkv)
+        for name, c_iter, exposed in (("round-5 default", 60.79, fi + fo + bi + bq + bkv),
+                                      ("+ self-chunk start (first-in exchanges hidden: the owned quarter lasts 1.8 / 5.8 ms)", 60.95, fo + bq + bkv),
+                                      ("round-6 default: + tails in 4 pieces + dq first", 61.28, fo / 4 + bkv),
+                                      ("... 2 pieces", 61.05, fo / 2 + bkv)):
+            tot = c_iter + exposed
+            print("  %3.0f GB/s: %-86s %.2f ms per iteration = %5.0f TFLOP/s on 2 GPUs, overlap %.2f"
+                  % (gbs, name + ":", tot, 123.15 / tot * 1e3, 1 - exposed / comm))
+    # N = 4 (ring 4 zigzag, no exchange): round 6 issues every backward step as dK/dV launch | hop | dQ launch, so the last hop
+    # (rounded: 32 MiB) runs beside the last step's dQ launch (0.42 of a 5.6 ms step) instead of behind it
+    print("\nround 6: the 4-GPU grid (ring 4 zigzag, same workload), compute-only 31.43 ms on the slowest ring rank (2), 28.4 on rank 0 -- the split costs nothing (profiles/r06_rank_emulation_all_grids.txt)")
+    for gbs in gbs_list:
+        ms = lambda nbytes: nbytes / (gbs * 1e9) * 1e3
+        comp4, kv, hop = 31.43, ms(32 * MiB), ms(64 * MiB)
         step_b = comp4 * 0.765 / 4
         comm = 2 * kv + 3 * hop + hop / 2
         for name, last in (("round 5 (one call per step)", hop / 2), ("round 6 (steps split around their hop)", max(0.0, hop / 2 - 0.42 * step_b))):
