@@ -17,4 +17,4 @@ from .comm.extract_local import (
 )
 from .kernels import AttnType, select_flash_attn_impl
 
-__version__ = "0.4.0"
+__version__ = "0.6.0"
