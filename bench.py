@@ -503,7 +503,7 @@ def pmc_traffic():
         res = {"kernel": ROOFLINE_KERNEL, "read_MB": rd, "write_MB": wr, "algorithmic_MB": ROOFLINE_ALGORITHMIC_MB,
                "kernel_src_sha16": sha,
                "note": "above the algorithmic bytes by the flash tiling: every 128-key item re-streams its head's Q / dO tiles (served "
-                       "by L2 / MALL, the misses are the HBM reads), and with four query heads per work item (round 6) two fp32 dK / dV slabs "
+                       "by L2 / MALL, the misses are the HBM reads), and with two query heads per work item (round 6: the GQA loop; causal launches) four fp32 dK / dV slabs "
                        "are written for reduce_heads_kernel to sum -- 3 % of the HBM roof over the launch: the kernel is MFMA-bound by 25x",
                "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources)"}
         if sha == kernel_source_sha16():
