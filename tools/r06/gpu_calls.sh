@@ -180,4 +180,24 @@ done > gpurun_out/r06/09_rank_emulation_all.txt 2>&1
 cat gpurun_out/r06/09_rank_emulation_all.txt
 }
 
+# the final tree: the driver's command twice, the GPU suite as the driver runs it, smoke, then the seeded sweeps at 10x their default size
+run10_final() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
+for i in 1 2; do
+  python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | grep -E "^\{" > gpurun_out/r06/10_bench_driver_cmd_$i.json
+  python - gpurun_out/r06/10_bench_driver_cmd_$i.json <<'PY'
+import json, sys
+d = json.load(open(sys.argv[1])); r = d["roofline"]
+print("ms_per_step", d["ms_per_step"], "value", d["value"], "frac", d["frac_of_mfma_roofline"], "| kernels alone:", r["step"]["fwd_ms"], r["step"]["dkdv_ms"], r["step"]["dq_ms"],
+      "| bwd_frac", r["step"]["bwd_frac"], "| roofline.frac", r["frac"], "| ceiling", r["mfma_ceiling"]["sustained_ceiling_TFLOPs"], "| traffic", (r.get("traffic") or {}).get("read_MB"),
+      "| kinds", r["kernels_launched"], "| c2", r["c2"]["fwd_kernel_ms"], r["c2"]["bwd_ms"], "| parity", r["sampled_parity"]["max_err_over_tolerance"])
+PY
+done
+( time timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -24 ) > gpurun_out/r06/10_pytest_gpu.log 2>&1
+tail -22 gpurun_out/r06/10_pytest_gpu.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+( time USP_FUZZ_ROW64_FWD=400 USP_FUZZ_DENSE=300 USP_FUZZ_PACKED=100 USP_FUZZ_ROW64=200 timeout 2400 python -m pytest tests/test_gpu_fuzz.py tests/test_gpu_row64.py -q -x -k "fuzz or sweep or seed" 2>&1 | tail -12 ) > gpurun_out/r06/10_fuzz.log 2>&1
+tail -10 gpurun_out/r06/10_fuzz.log
+}
+
 "$@"
