@@ -518,10 +518,10 @@ def test_varlen_ring_matches_exact_attention(ws, impl, lens, Hq, Hkv):
 
 
 # ---- launches inside a ring (or a pipelined exchange) must ask for interleavable launches ---------------------
-def _overlap_worker(rank, ws, ud, rd, use_async, force_groups, self_chunk="1"):
+def _overlap_worker(rank, ws, ud, rd, use_async, force_groups, self_chunk="1", tails="4"):
     import yunchang_amd as Y
     import yunchang_amd.hybrid.async_attn_layer as AL0
-    AL0._COMM_OVERRIDE["self_chunk"] = self_chunk
+    AL0._COMM_OVERRIDE.update(self_chunk=self_chunk, tails=tails)
     from yunchang_amd.kernels import set_block_backend
     from oracle_backend import OracleBlockBackend
 
@@ -562,17 +562,18 @@ def _overlap_worker(rank, ws, ud, rd, use_async, force_groups, self_chunk="1"):
     return be.seen
 
 
-@pytest.mark.parametrize("ud,rd,use_async,force_groups,expect,self_chunk",
-                         [(1, 2, False, False, True, "1"),      # a ring relay is in flight
-                          (2, 1, False, False, False, "0"),     # one packed exchange, no self-chunk start: nothing to overlap, persistent
-                          (2, 1, False, False, True, "1"),      # ... with the self-chunk start (default) the group's kernels run beside ITS exchange
-                          (2, 1, False, True, True, "1"),       # head-group pipeline in LongContextAttention (default)
-                          (2, 1, True, True, True, "1")])       # ... and in AsyncLongContextAttention
-def test_kernels_inside_a_transfer_window_are_launched_interleavable(ud, rd, use_async, force_groups, expect, self_chunk):
+@pytest.mark.parametrize("ud,rd,use_async,force_groups,expect,self_chunk,tails",
+                         [(1, 2, False, False, True, "1", "4"),      # a ring relay is in flight
+                          (2, 1, False, False, False, "0", "0"),     # one packed exchange, no self-chunk start, no tails: nothing to overlap, persistent
+                          (2, 1, False, False, True, "1", "0"),      # ... with the self-chunk start (default) the group's kernels run beside ITS exchange
+                          (2, 1, False, False, True, "0", "4"),      # ... with tails (default) its last pieces run beside the first pieces' exchanges
+                          (2, 1, False, True, True, "1", "4"),       # head-group pipeline in LongContextAttention (default)
+                          (2, 1, True, True, True, "1", "4")])       # ... and in AsyncLongContextAttention
+def test_kernels_inside_a_transfer_window_are_launched_interleavable(ud, rd, use_async, force_groups, expect, self_chunk, tails):
     """Persistent launches hold every CU until they end, so a ring relay or a pipelined exchange could not
     overlap them: exactly the launches made while such transfers are in flight must come from
     `backend.beside_transfers()` (USP_LAUNCH_INTERLEAVE on the C ABI).  The backend holds no mutable state."""
-    for seen in run_distributed(_overlap_worker, 2, ud, rd, use_async, force_groups, self_chunk):
+    for seen in run_distributed(_overlap_worker, 2, ud, rd, use_async, force_groups, self_chunk, tails):
         assert seen and all(d == expect for _, d in seen), seen
 
 
