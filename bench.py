@@ -650,7 +650,9 @@ def derived_decisions(cfg, attn, lq, lk, ws):
         pipelined = bool(AL.pipeline_mode(rd))
         d["self_chunk_start"] = bool(AL.self_chunk_mode(ud, rd, True, cfg["impl"], lq.shape[1])) and (pipelined or rd == 1)
         d["self_chunk_all_groups"] = bool(AL.self_chunk_all_groups())
-        d["tail_row_pieces"] = int(AL.tails_mode(ud, rd, True, cfg["impl"], lq.shape[1], pipelined))       # (> 0: also dq ahead of dk | dv)
+        _, kvh_g, g_g = AL._groups(cfg["Hq"], cfg["Hkv"], ud, cfg["B"], S, link_bound=lb, k_split=ks)
+        d["tail_row_pieces"] = int(AL.tails_mode(ud, rd, True, cfg["impl"], lq.shape[1], pipelined,
+                                                 cfg["B"] * kvh_g * g_g * ((lq.shape[1] + 255) // 256)))    # (> 0: also dq ahead of dk | dv)
     return d
 
 

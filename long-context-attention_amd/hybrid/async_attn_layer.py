@@ -146,7 +146,7 @@ def self_chunk_mode(P: int, ring: int, causal, impl: str, rows_local: int) -> bo
     return impl in ("basic", "zigzag") if ring == 1 else impl == "zigzag"
 
 
-def tails_mode(P: int, ring: int, causal, impl: str, rows_local: int, pipelined: bool) -> int:
+def tails_mode(P: int, ring: int, causal, impl: str, rows_local: int, pipelined: bool, chunk_items: int = None) -> int:
     """Row pieces of the LAST head group's output exchange (0: one exchange behind the group's last kernel, rounds 1-5).
 
     The head-group pipeline hides every exchange but the first input and the last output of a pass.  The last output waits
@@ -165,7 +165,19 @@ def tails_mode(P: int, ring: int, causal, impl: str, rows_local: int, pipelined:
     ok = P == 2 and bool(causal) and pipelined and (impl == "zigzag" if ring > 1 else impl in ("basic", "zigzag"))
     if n <= 0 or not ok or (ring > 1 and safe_comm()):
         return 0
-    return max(1, min(n, rows_local // 64)) if "tails" not in _COMM_OVERRIDE else max(1, min(n, rows_local))
+    if "tails" in _COMM_OVERRIDE:                  # tests: any piece count the rows allow
+        return max(1, min(n, rows_local))
+    n = max(1, min(n, rows_local // 64))
+    # A piece must still fill the part: `chunk_items` = 256-row work items of ONE c-row chunk of the last group (B x its query
+    # heads x c / 256).  Beside a ring a piece is cut along K up to 8 times (tail_k_splits), at ring degree 1 it is a plain causal
+    # launch over both chunks: pieces of fewer than one item per CU (after the cuts) are not made -- BASELINE's configs[2]
+    # (2 GPUs, S16384 H16, two-head groups of 64 items) keeps its one launch per group, the metric's 2-GPU grid (1024 items per
+    # chunk and group) gets 4 pieces, the 8-GPU grid (256 items per chunk, x 4 cuts per piece) gets 4.
+    if chunk_items is not None:
+        from ..comm.link import device_cus
+        per_cu = device_cus() // (8 if ring > 1 else 2)
+        n = min(n, chunk_items // max(1, per_cu))
+    return n if n > 1 else 0
 
 
 def self_chunk_all_groups() -> bool:
@@ -453,7 +465,7 @@ class _AsyncUSPFunc(torch.autograd.Function):
         overlap = ng > 1                # kernels run beside later groups' exchanges
         split0 = self_chunk_mode(P, ring, causal, impl, Sl)          # groups start on this rank's own rows
         u = dist.get_rank(ulysses_pg) if split0 else 0
-        n_tail = tails_mode(P, ring, causal, impl, Sl, ng_cap is None or ng_cap > 1)
+        n_tail = tails_mode(P, ring, causal, impl, Sl, ng_cap is None or ng_cap > 1, B * kvh * g * ((Sl + 255) // 256))
         saved, outs = [], []
         with _Lane(q) as lane:
             # every input exchange is queued before any attention runs
