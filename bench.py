@@ -855,6 +855,13 @@ def main(argv=None, dev=None):
         and "USP_SAFE_COMM" not in os.environ
     if two_comms:
         AL._COMM_OVERRIDE.update(safe=True)
+    # ulysses degree 2 at ring degree 1 (the 2-GPU grid): ONE communicator, but round 6's defaults (self-chunk start, row-chunked
+    # tails, dq ahead of dk | dv) have never met two devices either -- the same staging: round 5's schedule first, the default
+    # under a deadline behind it
+    plain_first = cfg["ud"] == 2 and cfg["rd"] == 1 and not args.async_ulysses and "USP_SELF_CHUNK" not in os.environ \
+        and "USP_TAILS" not in os.environ and "USP_PIPELINE_ULYSSES" not in os.environ
+    if plain_first:
+        AL._COMM_OVERRIDE.update(self_chunk="0", tails="0")
     q, k, v, do = make_global(cfg, dev)
     ext = Y.EXTRACT_FUNC_DICT[cfg["impl"]]
     lq, lk, lv, ldo = (ext(t, rank, world_size=ws, rd=cfg["rd"], ud=cfg["ud"]).detach().clone()
@@ -963,6 +970,7 @@ def main(argv=None, dev=None):
     # rank leaves with exit code 0.
     ms, dms = measure()
     comm_mode = ("safe: one communicator in flight at a time" if (two_comms or AL.safe_comm()) else
+                 "plain: head-group pipeline without the self-chunk start and the tails (round 5's schedule)" if plain_first else
                  "library default" + (" (USP_PIPELINE_ULYSSES=%s)" % os.environ["USP_PIPELINE_ULYSSES"]
                                       if "USP_PIPELINE_ULYSSES" in os.environ else ""))
     line = make_line(ms, dms, comm_mode)
@@ -1002,6 +1010,26 @@ def main(argv=None, dev=None):
                                  " + pair exchanges striped over the mesh (USP_EXCHANGE_RELAY=1)")
             else:
                 RX._OVERRIDE.clear()
+        if line is not None:
+            line["comm_modes_ms_per_step"] = modes
+    if plain_first:
+        modes = {"plain": round(ms, 4)}
+        fallback = _LineOnce(None if line is None else
+                             {**line, "comm_modes_ms_per_step": modes,
+                              "comm_mode_note": "the library default (self-chunk start + row-chunked tails) did not finish before its "
+                                                "deadline; this is the measurement of round 5's schedule"})
+        budget = float(os.environ.get("USP_BENCH_MODE_DEADLINE_S", str(60 + 20 * ms * 1e-3 * (args.warmup + args.steps))))
+        with _Deadline(budget, fallback, None):
+            AL._COMM_OVERRIDE.pop("self_chunk", None)
+            AL._COMM_OVERRIDE.pop("tails", None)
+            ms2, dms2 = measure()
+        modes["default"] = round(ms2, 4)
+        if ms2 < ms:
+            ms, dms = ms2, dms2
+            line = make_line(ms, dms, "library default: head groups start on the rank's own rows, the last group's output leaves in row "
+                                      "pieces, its dq ahead of dk | dv (USP_SELF_CHUNK / USP_TAILS defaults)")
+        else:
+            AL._COMM_OVERRIDE.update(self_chunk="0", tails="0")
         if line is not None:
             line["comm_modes_ms_per_step"] = modes
     # (Round 5 measured the self-chunk start as one more deadline-guarded mode.  Since round 6 it is part of the library default

@@ -143,6 +143,8 @@ def self_chunk_mode(P: int, ring: int, causal, impl: str, rows_local: int) -> bo
         return False
     if not (P == 2 and bool(causal) and rows_local >= 1):
         return False
+    if ring > 1 and safe_comm():      # (the split backward posts the ring's K/V transfers before it waits for the dO exchange:
+        return False                  #  two communicators in flight -- not in the mode whose contract is "one at a time")
     return impl in ("basic", "zigzag") if ring == 1 else impl == "zigzag"
 
 

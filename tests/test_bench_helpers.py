@@ -188,7 +188,10 @@ def _main_worker(rank, ws):
         assert set(line["comm_modes_ms_per_step"]) == {"safe", "overlapped", "relayed"}
         assert line["config"]["comm_mode"].startswith(("safe", "overlapped"))
         assert line["ms_per_step"] == min(line["comm_modes_ms_per_step"].values())
-    else:             # (ulysses 2 at ring degree 1: one communicator, the library default is the only mode since round 6)
+    elif ws == 2:     # ulysses 2 at ring degree 1: round 5's schedule first, the library default (self-chunk start + tails) under a deadline
+        assert set(line["comm_modes_ms_per_step"]) == {"plain", "default"}
+        assert line["ms_per_step"] == min(line["comm_modes_ms_per_step"].values())
+    else:
         assert "comm_modes_ms_per_step" not in line
     return True
 
