@@ -200,4 +200,15 @@ python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
 tail -10 gpurun_out/r06/10_fuzz.log
 }
 
+# development smoke of bench.py --gpus 8 and --gpus 2 (N processes sharing ONE GPU over gloo: the staged modes, the parity of every
+# rank's shard, the overlap probe, with the real kernels) -- NOT a measurement; then the driver's command once more on this box
+run11_smoke_multi() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
+( time bash tools/smoke_multi.sh 8 ) > gpurun_out/r06/11_smoke_n8.log 2>&1; tail -4 gpurun_out/r06/11_smoke_n8.log | cut -c1-1500
+( time bash tools/smoke_multi.sh 2 ) > gpurun_out/r06/11_smoke_n2.log 2>&1; tail -4 gpurun_out/r06/11_smoke_n2.log | cut -c1-1500
+python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | grep -E "^\{" > gpurun_out/r06/11_bench_driver_cmd_3.json
+python -c "
+import json; d=json.load(open('gpurun_out/r06/11_bench_driver_cmd_3.json')); print('ms_per_step', d['ms_per_step'], 'frac', d['frac_of_mfma_roofline'], 'ceiling', d['roofline']['mfma_ceiling']['sustained_ceiling_TFLOPs'])"
+}
+
 "$@"
