@@ -181,15 +181,11 @@ def tail_k_splits(B, H, rows, keys):
 
 def _final_rows(be, q, kp, vp, softmax_scale, lse, out, acc, lo, hi, tail):
     """The launch that FINALISES rows [lo, hi) of the block (a full, merge-mode launch against kp / vp; [lo, hi) is the whole
-    block or its back half): all of them emitted in 16 bits.  With `tail` = (n, emit) it is n launches over row pieces
-    instead -- piece j of every c-row chunk in [lo, hi) -- and `emit(j, out)` is called behind the launches of piece j: from then on
+    block or its back half: all of them emitted in 16 bits) as `tail` = (n, emit) asks for it: n launches over row pieces
+    -- piece j of every c-row chunk in [lo, hi) -- with `emit(j, out)` called behind the launches of piece j: from then on
     rows [chunk * c + j c / n, chunk * c + (j + 1) c / n) of EVERY chunk of the block are final on the calling stream, and the
     caller's output exchange of those rows runs beside the launches of the pieces that follow (hybrid/async_attn_layer.py:
     row-chunked tails; the last-out exchange of a pass is the one no head-group pipeline can hide)."""
-    if tail is None:
-        be.fwd(q[:, lo:hi] if (lo, hi) != (0, q.shape[1]) else q, kp, vp, softmax_scale, False, lse[:, :, lo:hi], out[:, lo:hi], acc[:, lo:hi],
-               True, 0, hi - lo)
-        return
     n, emit = tail
     c = q.shape[1] // 2
     B, _, H, _ = q.shape
