@@ -211,4 +211,28 @@ python -c "
 import json; d=json.load(open('gpurun_out/r06/11_bench_driver_cmd_3.json')); print('ms_per_step', d['ms_per_step'], 'frac', d['frac_of_mfma_roofline'], 'ceiling', d['roofline']['mfma_ceiling']['sustained_ceiling_TFLOPs'])"
 }
 
+# launch lists of ring rank 0 and ring rank 2 of the 8-GPU grid (default schedule), same box, back to back
+run12_rank_compare() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06; R=$GRAFT_REPO_ROOT; export TMPDIR=/tmp
+for rank in 0 5 0 5; do
+  ( cd /tmp && rm -rf /tmp/emu_rk && rocprofv3 --kernel-trace -d /tmp/emu_rk -o x -- python $R/tools/rank_emulation.py --gpus 8 --rank $rank --iters 3 > /tmp/emu_rk.log 2>&1; echo "######## rank $rank: $(grep 'per iteration' /tmp/emu_rk.log | cut -c1-110)"; python $R/tools/r06/rank_launches.py /tmp/emu_rk 6 )
+done > gpurun_out/r06/12_rank_compare.txt 2>&1
+grep -c . gpurun_out/r06/12_rank_compare.txt
+}
+
+# the two non-causal ring-step shapes of the 8-GPU grid in isolation: q[c:] x all keys (ring ranks' steps s > r) against all rows x front keys
+# (steps s <= r), dK/dV and dQ launches alone, by heads per item
+run13_step_shapes() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench; cd $R; mkdir -p gpurun_out/r06
+for rep in 1 2; do
+for shape in "8192 16384" "16384 8192"; do
+  for h in 0 1 2 4; do
+    echo "dkdv rows x keys $shape heads/item $h: $(USP_KBENCH_FLAGS=16 USP_KBENCH_BWD_HEADS=$h timeout 100 $K bwd 1 $shape 8 1 128 0 0 0 20 2>&1 | grep TIME | awk '{print $(NF-5), $(NF-4)}')"
+  done
+  echo "dq   rows x keys $shape: $(USP_KBENCH_FLAGS=32 timeout 100 $K bwd 1 $shape 8 1 128 0 0 0 20 2>&1 | grep TIME | awk '{print $(NF-5), $(NF-4)}')"
+  echo "fwd  rows x keys $shape: $(timeout 100 $K fwd 1 $shape 8 1 128 0 0 0 20 2>&1 | grep TIME | awk '{print $(NF-5), $(NF-4)}')"
+done
+done | tee gpurun_out/r06/13_step_shapes.txt
+}
+
 "$@"
