@@ -235,4 +235,12 @@ done
 done | tee gpurun_out/r06/13_step_shapes.txt
 }
 
+# the driver's command alone (every gpurun call lands on another box of the pool: the spread of the headline)
+run14_bench_only() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
+python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | grep -E "^\{" > gpurun_out/r06/14_bench_$1.json
+python -c "
+import json; d=json.load(open('gpurun_out/r06/14_bench_$1.json')); r=d['roofline']; print('ms_per_step', d['ms_per_step'], 'frac', d['frac_of_mfma_roofline'], 'ceiling', r['mfma_ceiling']['sustained_ceiling_TFLOPs'], 'kernels', r['step']['fwd_ms'], r['step']['dkdv_ms'], r['step']['dq_ms'])"
+}
+
 "$@"
