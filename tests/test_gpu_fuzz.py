@@ -12,8 +12,8 @@ from oracle import usp_oracle as O
 pytestmark = pytest.mark.gpu
 
 import os
-_N_DENSE = int(os.environ.get("USP_FUZZ_DENSE", "32"))      # larger sweeps: USP_FUZZ_DENSE=400 USP_FUZZ_PACKED=200
-_N_PACKED = int(os.environ.get("USP_FUZZ_PACKED", "16"))
+_N_DENSE = int(os.environ.get("USP_FUZZ_DENSE", "28"))      # larger sweeps: USP_FUZZ_DENSE=400 USP_FUZZ_PACKED=200
+_N_PACKED = int(os.environ.get("USP_FUZZ_PACKED", "14"))
 
 
 @pytest.fixture(scope="module")
@@ -59,7 +59,7 @@ def test_fuzz_dense(dev, seed):
     _run_dense(dev, rs, _dense_case(rs))
 
 
-_N_ROW64 = int(os.environ.get("USP_FUZZ_ROW64", "18"))      # larger sweeps: USP_FUZZ_ROW64=300
+_N_ROW64 = int(os.environ.get("USP_FUZZ_ROW64", "16"))      # larger sweeps: USP_FUZZ_ROW64=300
 
 
 def _row64_case(rs):

@@ -85,7 +85,7 @@ def _usp_gpu_worker(rank, ws, path, pipelined=False):
     return res
 
 
-def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D, self_chunk=False):
+def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D, self_chunk=False, tails=None):
     """No fixture has batch > 1 on a ulysses x ring grid: exact attention (fp64 oracle) on the unsharded
     tensors is the reference here.  Batch 2 is what gives the seq-major views the exchange hands the ring a
     real batch stride (the P > 1 gradient cast used to reject them)."""
@@ -96,7 +96,13 @@ def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D, self_chunk=False):
     AL._FILL_ITEMS = 1
     calls = []
     AL._COMM_OVERRIDE["self_chunk"] = "1" if self_chunk else "0"       # (the default since round 6: pinned either way)
-    if self_chunk:
+    pieces = []
+    if tails:            # row-chunked tails with an explicit piece count (the override skips the fill cap of tails_mode)
+        AL._COMM_OVERRIDE["tails"] = str(tails)
+        import yunchang_amd.comm.all_to_all as A_
+        real_pack = A_.pack_seq_rows
+        A_.pack_seq_rows = lambda *a: (pieces.append(a[2:]), real_pack(*a))[1]
+    if self_chunk and rd == 1:
         real_f, real_b = AL._split_first_forward, AL._split_first_backward
         AL._split_first_forward = lambda *a: (calls.append("f"), real_f(*a))[1]
         AL._split_first_backward = lambda *a: (calls.append("b"), real_b(*a))[1]
@@ -104,7 +110,8 @@ def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D, self_chunk=False):
     torch.cuda.set_device(dev)
     Y.set_seq_parallel_pg(ud, rd, rank, ws)
     torch.manual_seed(0)
-    B, S = 2, (64 if not self_chunk else 333 * 2) * ws
+    rows = 64 if not (self_chunk or tails) else (333 * 2 if not tails else (99 * 2 if ws <= 4 else 65 * 2))
+    B, S = 2, rows * ws                  # (with tails: smaller, the fp64 truth costs S^2 per process and the GPU suite has a time limit)
     q, k, v, do = (torch.randn(B, S, h, D).to(torch.bfloat16) for h in (Hq, Hkv, Hkv, Hq))
     ext = Y.EXTRACT_FUNC_DICT[impl]
     qn, kn, vn, don = (t.float().numpy().astype(np.float64) for t in (q, k, v, do))
@@ -118,7 +125,10 @@ def _batch2_worker(rank, ws, ud, rd, impl, Hq, Hkv, D, self_chunk=False):
     out.backward(ldo)
     torch.cuda.synchronize()
     got = [t.detach().float().cpu().numpy() for t in (out, lq.grad, lk.grad, lv.grad)]
-    assert calls == (["f", "b"] if self_chunk else []), calls          # the split path ran (forward and backward), or did not
+    if rd == 1:
+        assert calls == (["f", "b"] if self_chunk else []), calls      # the split path ran (forward and backward), or did not
+    if tails:
+        assert len(pieces) == tails, pieces                            # the last group's output left in `tails` row pieces
     return got, truth
 
 
@@ -185,7 +195,8 @@ def test_batch2_on_a_ulysses_x_ring_grid(gloo_cuda, ws, ud, rd, impl, Hq, Hkv, D
             assert_close(a, t, *TOL["bfloat16"]["out" if key == "out" else "grad"], f"B=2 {impl} {key}")
 
 
-@pytest.mark.parametrize("impl,Hq,Hkv,D", [("basic", 8, 2, 128), ("zigzag", 4, 4, 128), ("basic", 4, 4, 64)])
+@pytest.mark.parametrize("impl,Hq,Hkv,D", [("basic", 8, 2, 128), ("zigzag", 4, 4, 128)] +
+                         ([("basic", 4, 4, 64)] if os.environ.get("USP_GPU_ALL_FIXTURES") == "1" else []))
 def test_self_chunk_start_two_processes_one_gpu(gloo_cuda, impl, Hq, Hkv, D):
     """USP_SELF_CHUNK=1 on the 2-GPU grid with the HIP kernels (two processes sharing the GPU): the first head group's block as
     two / three launches on views of the send and receive buffers (odd row counts: 666 rows per rank, the split at 666; merge-in
@@ -194,6 +205,18 @@ def test_self_chunk_start_two_processes_one_gpu(gloo_cuda, impl, Hq, Hkv, D):
     for got, truth in run_distributed(_batch2_worker, 2, 2, 1, impl, Hq, Hkv, D, True):
         for a, t, key in zip(got, truth, ("out", "dq", "dk", "dv")):
             assert_close(a, t, *TOL["bfloat16"]["out" if key == "out" else "grad"], f"self-chunk {impl} {key}")
+
+
+@pytest.mark.parametrize("ws,rd,impl,Hq,Hkv,self_chunk,tails", [(4, 2, "zigzag", 8, 4, True, 3),      # beside a ring: K-cut pieces of the final launch
+                                                                (8, 4, "zigzag", 8, 2, True, 2),      # the 8-GPU grid's shape of schedule, ONE head group
+                                                                (2, 1, "basic", 8, 4, False, 3)])     # ring degree 1: the block in the layer
+def test_row_chunked_tails_on_the_gpu(gloo_cuda, ws, rd, impl, Hq, Hkv, self_chunk, tails):
+    """The round-6 tails with the HIP kernels on ragged sizes (198 rows per rank -- 130 on the 8-rank grid --: pieces of 66 / 33 / 65 rows, K cuts of the pieces
+    beside a ring, merge-in with partial final ranges, dq rounded in the last step's dQ epilogue), batch 2, processes sharing
+    the GPU, against exact attention and its gradients.  (The full-size RCCL virtual grids run the even default shapes.)"""
+    for got, truth in run_distributed(_batch2_worker, ws, 2, rd, impl, Hq, Hkv, 128, self_chunk, tails):
+        for a, t, key in zip(got, truth, ("out", "dq", "dk", "dv")):
+            assert_close(a, t, *TOL["bfloat16"]["out" if key == "out" else "grad"], f"tails {impl} {key}")
 
 
 def _varlen_gpu_worker(rank, ws, path):

@@ -243,4 +243,9 @@ python -c "
 import json; d=json.load(open('gpurun_out/r06/14_bench_$1.json')); r=d['roofline']; print('ms_per_step', d['ms_per_step'], 'frac', d['frac_of_mfma_roofline'], 'ceiling', r['mfma_ceiling']['sustained_ceiling_TFLOPs'], 'kernels', r['step']['fwd_ms'], r['step']['dkdv_ms'], r['step']['dq_ms'])"
 }
 
+run15_tails_gpu_test() {
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
+( time timeout 900 python -m pytest tests/test_gpu_multiproc.py -q -x -k "tails or self_chunk" 2>&1 | tail -12 ) 2>&1 | tee gpurun_out/r06/15_tails_gpu.log | tail -14
+}
+
 "$@"
