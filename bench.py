@@ -502,9 +502,11 @@ def pmc_traffic():
             return None
         res = {"kernel": ROOFLINE_KERNEL, "read_MB": rd, "write_MB": wr, "algorithmic_MB": ROOFLINE_ALGORITHMIC_MB,
                "kernel_src_sha16": sha,
-               "note": "above the algorithmic bytes by the flash tiling: every 128-key item re-streams its head's Q / dO tiles (served "
-                       "by L2 / MALL, the misses are the HBM reads), and with two query heads per work item (round 6: the GQA loop; causal launches) four fp32 dK / dV slabs "
-                       "are written for reduce_heads_kernel to sum -- 3 % of the HBM roof over the launch: the kernel is MFMA-bound by 25x",
+               "note": "above the algorithmic bytes by the flash tiling: every 128-key item re-streams its heads' Q / dO tiles.  The 32 workgroups an "
+                       "XCD runs side by side share one stream through that XCD's L2, so the tiling's own floor is (items / 32) x the average "
+                       "stream = 16384 / 32 x 16 MB = 8.2 GB per launch (the 1.36 GB would need ONE L2 for all 256 CUs); the rest is "
+                       "workgroups drifting apart inside a pass, plus the fp32 dK / dV slabs of the two-heads-per-item launch that "
+                       "reduce_heads_kernel sums.  3 % of the HBM roof over the launch: the kernel is MFMA-bound by 25x",
                "source": f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources)"}
         if sha == kernel_source_sha16():
             return res
