@@ -248,4 +248,17 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r06
 ( time timeout 900 python -m pytest tests/test_gpu_multiproc.py -q -x -k "tails or self_chunk" 2>&1 | tail -12 ) 2>&1 | tee gpurun_out/r06/15_tails_gpu.log | tail -14
 }
 
+# (NOT adopted: -0.45 % at the metric's shape, +1.2 % at C2, -0.7 % on a 16K full launch -- profiles/r06_fwd_lds0_experiment.txt)
+# forward 4 x 64: LDS addresses from the integer 0 instead of the symbol (12 v_add of 0 less per two tiles) against the library before
+# (abl/fwd_old), alternating; native suite first
+run16_fwd_lds0() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench; cd $R; mkdir -p gpurun_out/r06
+( timeout 900 $K suite 2>&1 | grep -E "FAIL|SUITE" ) | tail -3
+for rep in 1 2 3 4; do
+  echo "new 64K: $(timeout 200 $K fwd 1 65536 65536 32 4 128 1 0 0 3 2>&1 | grep TIME | awk '{print $(NF-6)}')  old 64K: $(LD_LIBRARY_PATH=$R/abl/fwd_old timeout 200 $K fwd 1 65536 65536 32 4 128 1 0 0 3 2>&1 | grep TIME | awk '{print $(NF-6)}')"
+  echo "new C2 : $(timeout 200 $K fwd 2 8192 8192 16 16 128 1 0 0 30 2>&1 | grep TIME | awk '{print $(NF-6)}')  old C2 : $(LD_LIBRARY_PATH=$R/abl/fwd_old timeout 200 $K fwd 2 8192 8192 16 16 128 1 0 0 30 2>&1 | grep TIME | awk '{print $(NF-6)}')"
+  echo "new 16K full 8/1: $(timeout 200 $K fwd 1 8192 16384 8 1 128 0 0 0 20 2>&1 | grep TIME | awk '{print $(NF-6)}')  old: $(LD_LIBRARY_PATH=$R/abl/fwd_old timeout 200 $K fwd 1 8192 16384 8 1 128 0 0 0 20 2>&1 | grep TIME | awk '{print $(NF-6)}')"
+done | tee gpurun_out/r06/16_fwd_lds0.txt
+}
+
 "$@"
