@@ -261,4 +261,13 @@ for rep in 1 2 3 4; do
 done | tee gpurun_out/r06/16_fwd_lds0.txt
 }
 
+# what D = 64 launches run at (8-wave family; the reference's test default is D = 64, BASELINE configs[0] is B1 S1024 H8 D64)
+run17_d64() {
+R=$GRAFT_REPO_ROOT; K=$R/long-context-attention_amd/kbench; cd $R; mkdir -p gpurun_out/r06
+for shape in "1 1024 1024 8 8 64" "2 8192 8192 16 16 64" "1 16384 16384 32 32 64" "2 8192 8192 16 16 128"; do
+  echo "fwd $shape: $(timeout 100 $K fwd $shape 1 0 0 20 2>&1 | grep TIME | awk '{print $(NF-6), "ms", $(NF-4), "TFLOP/s"}')"
+  echo "bwd $shape: $(timeout 100 $K bwd $shape 1 0 0 10 2>&1 | grep TIME | awk '{print $(NF-6), "ms", $(NF-4), "TFLOP/s"}')"
+done | tee gpurun_out/r06/17_d64.txt
+}
+
 "$@"
