@@ -250,7 +250,7 @@ class VirtualGridPairwise(VirtualGrid):
                 if self.aborted.is_set():
                     raise RuntimeError("virtual grid aborted")
                 self._waited = getattr(self, "_waited", 0) + 1
-                if self._waited > 300:
+                if self._waited > 900:        # (cumulative over the grid's rank threads: minutes of real waiting, i.e. a deadlock, not a loaded host)
                     raise TimeoutError(f"rank {self.tls.rank}: no message from rank {src} -- the ranks' posting orders differ")
         assert msg["t"].shape == tensor.shape and msg["t"].dtype == tensor.dtype, (src, self.tls.rank, msg["t"].shape, tensor.shape)
         if self.d is not None:
