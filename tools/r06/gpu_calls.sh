@@ -270,4 +270,11 @@ for shape in "1 1024 1024 8 8 64" "2 8192 8192 16 16 64" "1 16384 16384 32 32 64
 done | tee gpurun_out/r06/17_d64.txt
 }
 
+# microbenchmark: the forward's per-tile instruction budget on one wave per SIMD, on two role-split waves per SIMD and on two symmetric
+# waves per SIMD (tools/r06/ubench_roles.hip; built here: hipcc --offload-arch=gfx950 -O2 ... -o gpurun_tools/ubench_roles)
+run18_ubench_roles() {
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/r06
+timeout 120 $R/gpurun_tools/ubench_roles 2>&1 | tee gpurun_out/r06/18_ubench_roles.txt
+}
+
 "$@"
